@@ -1,0 +1,146 @@
+// driver.cpp - see driver.h.  Pure host code: no HIP calls here, only Prims launches.
+#include "driver.h"
+
+namespace bayens {
+
+static inline int split_point(int n) {
+  int leaves = n / LEAF;
+  return (leaves / 2) * LEAF;   // >= LEAF whenever leaves >= 2
+}
+
+static inline const double* inv_at(const double* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
+static inline double* inv_at(double* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
+
+// X L^T = B.  L = [L11 0; L21 L22]  =>  X1 = B1 L11^-T ; B2 -= X1 L21^T ; X2 = B2 L22^-T
+void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B) {
+  if (m <= 0 || n <= 0) return;
+  if (n == LEAF) {
+    Mat I{const_cast<double*>(inv), LEAF, inv_stride};
+    // X = B * inv^T  (in place: one column tile, each block reads only its own rows)
+    P.gemm(nb, m, LEAF, LEAF, 1.0, B, I, 0.0, B, GEMM_TB, 0.0);
+    return;
+  }
+  int n1 = split_point(n), n2 = n - n1;
+  trsm_rlt(P, nb, m, n1, L, inv, inv_stride, B);
+  P.gemm(nb, m, n2, n1, -1.0, B, L.sub(n1, 0), 1.0, B.sub(0, n1), GEMM_TB, 0.0);
+  trsm_rlt(P, nb, m, n2, L.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, B.sub(0, n1));
+}
+
+// X L = B.  X2 = B2 L22^-1 ; B1 -= X2 L21 ; X1 = B1 L11^-1
+static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride,
+                         Mat B, bool rhs_lower, int c0) {
+  // B here is the column block [c0, c0+n) of the caller's right-hand side, all m rows.
+  // With rhs_lower the rows < c0 of this column block are zero: start at row r0 = c0.
+  if (m <= 0 || n <= 0) return;
+  int r0 = rhs_lower ? c0 : 0;
+  if (r0 >= m) return;
+  if (n == LEAF) {
+    Mat I{const_cast<double*>(inv), LEAF, inv_stride};
+    P.gemm(nb, m - r0, LEAF, LEAF, 1.0, B.sub(r0, 0), I, 0.0, B.sub(r0, 0), 0, 0.0);
+    return;
+  }
+  int n1 = split_point(n), n2 = n - n1;
+  trsm_rln_rec(P, nb, m, n2, L.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, B.sub(0, n1), rhs_lower,
+               c0 + n1);
+  int r2 = rhs_lower ? c0 + n1 : 0;   // X2 is zero above row c0+n1
+  if (r2 < m)
+    P.gemm(nb, m - r2, n1, n2, -1.0, B.sub(r2, n1), L.sub(n1, 0), 1.0, B.sub(r2, 0), 0, 0.0);
+  trsm_rln_rec(P, nb, m, n1, L, inv, inv_stride, B, rhs_lower, c0);
+}
+
+void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B,
+              bool rhs_lower) {
+  trsm_rln_rec(P, nb, m, n, L, inv, inv_stride, B, rhs_lower, 0);
+}
+
+static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int base) {
+  if (n == LEAF) {
+    P.potrf_leaf(nb, A, inv, inv_stride, base, info);
+    return;
+  }
+  int n1 = split_point(n), n2 = n - n1;
+  potrf_rec(P, nb, n1, A, inv, inv_stride, info, base);
+  // L21 = A21 L11^-T
+  trsm_rlt(P, nb, n2, n1, A, inv, inv_stride, A.sub(n1, 0));
+  // A22 -= L21 L21^T   (lower 64-blocks only)
+  P.gemm(nb, n2, n2, n1, -1.0, A.sub(n1, 0), A.sub(n1, 0), 1.0, A.sub(n1, n1), GEMM_TB | GEMM_TRI_OUT, 0.0);
+  potrf_rec(P, nb, n2, A.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, info, base + n1);
+}
+
+void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info) {
+  potrf_rec(P, nb, n, A, inv, inv_stride, info, 0);
+}
+
+void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
+            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp) {
+  const int nb = ws.nb, Np = ws.Np, N = fp.N;
+  const long is = ws.inv_stride();
+  P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info);
+
+  for (int it = 0; it < fp.n_iters; ++it) {
+    // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
+    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
+    potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    // natural-gradient step:  Lam <- (1-g) Lam + g (I + L^T D L),  theta1 <- (1-g) theta1 + g L^T D y
+    P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
+    P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 1.0 - fp.gamma, ws.Lam,
+           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, fp.gamma);
+    P.theta_update(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, ws.theta1);
+    P.tri_copy(nb, Np, ws.Lam, ws.Cb);
+    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
+    P.trsv2(nb, Np, ws.Cb, ws.invC, is, ws.theta1, ws.mvec);          // m = Lam^-1 theta1
+    // Adam step on the hypers with (m, S) fixed: Cholesky-backward of the data term  (models.py:210)
+    P.copy(nb, Np, ws.Lb, ws.T1);
+    trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);               // L C^-T
+    trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1, false);        // L C^-T C^-1 = L S
+    P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
+    P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))
+    P.gemm(nb, Np, Np, Np, 1.0, ws.Lb, ws.T1, 0.0, ws.T2,
+           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI, 0.0);   // Phi(L^T Lbar)
+    trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
+    P.transpose_lower(nb, Np, ws.T2, ws.T1);                          // W^T
+    trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1, false);        // Kbar^T = W^T L^-1
+    P.grad_adam(nb, N, Np, fp.R, X, fp.kernel, ws.T1, ws.ustate, fp.lr);
+  }
+
+  // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
+  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
+  potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+  P.copy(nb, Np, ws.K0, ws.T1);
+  trsm_rlt(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1);                 // A^T = K0 L^-T
+  P.gemv_n(nb, Np, ws.T1, ws.mvec, ws.muvec);                         // mu = A^T m
+  P.extract_vec(nb, N, Np, ws.muvec, mu);
+  P.copy(nb, Np, ws.T1, ws.T2);
+  trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2);                 // A^T C^-T
+  P.cov_init(nb, Np, ws.K0, ws.nu, ws.Lam);                           // Lam reused: K0 + diag(nu)
+  P.gemm(nb, Np, Np, Np, -1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
+  P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
+  P.extract(nb, N, ws.Lam, cov, 1);
+  if (chol || logdet) {
+    // Distribution.__post_init__ : distrax caches chol(cov) and its log-determinant  (data.py:38-39)
+    P.tri_copy(nb, Np, ws.Lam, ws.T1);
+    potrf(P, nb, Np, ws.T1, ws.invL, is, ws.info);
+    if (chol) P.extract(nb, N, ws.T1, chol, 2);
+    if (logdet) P.logdet(nb, N, ws.T1, logdet);
+  }
+  if (hyp) P.hyp_out(nb, ws.ustate, hyp);
+}
+
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, double* chol, double* logdet) {
+  const int nb = ws.nb, Np = ws.Np;
+  P.tri_copy(nb, Np, ws.T1, ws.T2);
+  potrf(P, nb, Np, ws.T2, ws.invL, ws.inv_stride(), ws.info);
+  if (chol) P.extract(nb, N, ws.T2, chol, 2);
+  if (logdet) P.logdet(nb, N, ws.T2, logdet);
+}
+
+double fit_flops(int N, int R, int n_iters) {
+  // per iteration: chol K 1/3, L^T D L 1/3, chol Lam 1/3, L C^-T 1, (.) C^-1 1, L^T Lbar 1/3,
+  //                Phi L^-1 1/3, W^T L^-1 1  => 14/3 N^3 ; kernel matrix 2 N^2 R
+  // prediction: chol K 1/3, K0 L^-T 1, (.) C^-T 1, two symmetric rank-N updates 1 + 1 => 13/3 N^3,
+  //             chol(cov) 1/3
+  double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
+  return n_iters * (14.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0;
+}
+
+}  // namespace bayens

@@ -1,0 +1,64 @@
+// driver.h - host-side sequencing of the batched GP fit on top of the device primitives (prims.h).
+//
+// Reference behaviour being reproduced: GPDTW1D.fit after the DBA stage (ensembles/models.py:179-220),
+// i.e. T x [ closed-form natural-gradient step (gamma) ; Adam step on (variance, lengthscale) ] followed by
+// the whitened full-covariance prediction + diag(y_var) and the distrax Cholesky/logdet of the result
+// (ensembles/data.py:38-39).  Formulas: SURVEY.md Appendix A.
+//
+// Every N^3 operation is expressed as recursive blocked Cholesky / triangular solves whose only heavy
+// primitive is the batched fp64 GEMM; the recursion bottoms out at 64x64 diagonal blocks that are
+// factored and inverted by one workgroup (potrf_leaf) and applied as a GEMM with the inverted block.
+#pragma once
+#include "prims.h"
+
+namespace bayens {
+
+inline int pad_to_leaf(int n) { return ((n + LEAF - 1) / LEAF) * LEAF; }
+
+// Device workspace for a batch of nb members of padded size Np (all pointers device pointers).
+struct FitWorkspace {
+  int nb = 0, Np = 0;
+  Mat K0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each
+  double* invL = nullptr;          // [nb][Np/64][64][64]
+  double* invC = nullptr;
+  double* theta1 = nullptr;        // [nb][Np]
+  double* mvec = nullptr;
+  double* avec = nullptr;
+  double* y = nullptr;             // padded y_mean
+  double* nu = nullptr;            // padded y_var (1 in the padded part)
+  double* muvec = nullptr;
+  double* ustate = nullptr;        // [nb][8]
+  int* info = nullptr;             // [nb]
+  long inv_stride() const { return (long)Np * LEAF; }
+};
+
+// Blocked Cholesky (lower, in place) of the n x n matrices A; inv receives the inverted diagonal blocks
+// ([leaf][64][64] per member, leaf index relative to A's first row).  A's strictly-upper 64-blocks are
+// never touched (callers keep them zero).
+void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info);
+
+// B[m x n] <- B * L^-T  (solve X L^T = B), L n x n lower with inverted diagonal blocks in inv.
+void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B);
+// B[m x n] <- B * L^-1  (solve X L = B).  rhs_lower: B is n x n lower triangular (rows above the
+// diagonal block of each column block are zero and are skipped; the result is lower triangular).
+void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B,
+              bool rhs_lower);
+
+struct FitParams {
+  int N, R, kernel, n_iters;
+  double gamma, lr, jitter;
+};
+
+// Runs the whole fit on resident inputs.  X [nb][N][R], y_in/nu_in [nb][N] (compact, device).
+// Outputs (device, compact): mu [nb][N], cov [nb][N][N], chol (nullable), logdet (nullable, [nb]),
+// hyp (nullable, [nb][2]).  info: ws.info (device).
+void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
+            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp);
+
+// chol/logdet of caller-supplied covariances already placed (padded, full) in ws.T1.
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, double* chol, double* logdet);
+
+// Algorithmic flop of one member fit (2 flop per FMA, triangular structure exploited).
+double fit_flops(int N, int R, int n_iters);
+
+}  // namespace bayens

@@ -1,0 +1,87 @@
+// prims.h - the batched device primitives the host-side driver sequences.
+//
+// Everything is fp64, row-major, batched over `nb` independent ensemble members.  A `Mat` is a
+// strided view: element (b, i, j) lives at p[b*stride + i*ld + j].  All matrix dimensions handed to
+// the primitives are multiples of LEAF (64): the driver pads every member to Np = ceil(N/64)*64 with
+// an identity block, which keeps the padded part decoupled from the real part through every
+// factorisation, solve and product (block-diagonal stays block-diagonal).
+//
+// The HIP implementation is in kernels.hip / gemm.hip (the product).  oracle/hostcheck/ holds a naive
+// CPU implementation of the same interface that is used ONLY by the CPU test-suite to validate the
+// driver's sequencing without a GPU; the product never links it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace bayens {
+
+constexpr int LEAF = 64;   // diagonal-block size of the blocked factorisations / solves
+
+struct Mat {
+  double* p;
+  int ld;
+  long stride;
+  Mat sub(int i, int j) const { return Mat{p + (long)i * ld + j, ld, stride}; }
+};
+
+// gemm flags
+enum : int {
+  GEMM_TA = 1,             // A is stored k x m (use A^T)
+  GEMM_TB = 2,             // B is stored n x k (use B^T)
+  GEMM_TRI_OUT = 4,        // C square: skip 64x64 blocks strictly above the diagonal (not written)
+  GEMM_KTRIM_TN_LOWER = 8, // with TA, !TB: A and B are lower triangular => k starts at max(i0, j0)
+  GEMM_EPI_PHI = 16,       // epilogue: zero where i<j, halve where i==j   (Cholesky-backward Phi)
+};
+
+struct Prims {
+  virtual ~Prims() {}
+
+  // C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C  (+ diag_add where i == j).
+  // C may alias A when n <= 128 and C/A address the same rows (used by the in-place leaf solves).
+  virtual void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C,
+                    int flags, double diag_add) = 0;
+
+  // Cholesky of one 64x64 diagonal block per member, in place (lower; strict upper set to 0), plus its
+  // inverse into inv (64x64 row-major per member, member stride inv_stride).  A non-positive pivot j
+  // (0-based inside the block) records info[b] = pivot_base + j + 1 if info[b] was 0.
+  virtual void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) = 0;
+
+  virtual void copy(int nb, int n, Mat src, Mat dst) = 0;        // full n x n copy
+  virtual void tri_copy(int nb, int n, Mat src, Mat dst) = 0;    // dst = tril(src), zeros above
+  virtual void transpose_lower(int nb, int n, Mat W, Mat Wt) = 0;  // Wt = tril(W)^T (zeros below diag)
+
+  // state initialisation: Lam = I (n x n); theta1 = m = 0; u = softplus^-1(1); adam = 0; y/nu padded
+  virtual void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
+                          const double* y_in, const double* nu_in, double* y_pad, double* nu_pad,
+                          int* info) = 0;
+
+  // K0 (full, no jitter; identity in the padded part) and Lb = tril(K0) + jitter*I from the current
+  // hypers softplus(ustate[b][0..1]).  X is [nb][N][R] compact.
+  virtual void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel,
+                    double jitter, Mat K0, Mat Lb) = 0;
+
+  virtual void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
+  // theta1 = (1-gamma) theta1 + gamma * L^T (y / nu)
+  virtual void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
+                            double* theta1) = 0;
+  // m = C^-T C^-1 theta1, using the inverted diagonal blocks of C
+  virtual void trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1,
+                     double* mvec) = 0;
+  virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
+  // X_ij <- (i >= j) ? (a_i m_j + X_ij) / nu_i : 0
+  virtual void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) = 0;
+  // g = <Kbt, dK/dtheta> over the real N x N part (Kbt = Kbar^T; dK symmetric), then one Adam step on
+  // the unconstrained hypers.  ustate per member: [u_var, u_ls, m_var, m_ls, v_var, v_ls, t, pad]
+  virtual void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt,
+                         double* ustate, double lr) = 0;
+  virtual void gemv_n(int nb, int n, Mat A, const double* x, double* y) = 0;    // y = A x
+  virtual void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) = 0;  // dst = K0 + diag(nu)
+  // compact copy-out of the real N x N part: mode 0 as is, 1 symmetric from the lower triangle,
+  // 2 lower triangle with zeros above
+  virtual void extract(int nb, int N, Mat src, double* dst, int mode) = 0;
+  virtual void extract_vec(int nb, int N, int Np, const double* src, double* dst) = 0;
+  virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii
+  virtual void hyp_out(int nb, const double* ustate, double* hyp) = 0;  // softplus(u) -> (variance, lengthscale)
+};
+
+}  // namespace bayens

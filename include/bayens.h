@@ -1,0 +1,140 @@
+/*
+ * bayens.h - C ABI of libbayens (MI355X / gfx950), the drop-in boundary for the
+ * GP-fit -> ensemble-weighting -> weighted-posterior hot path of mattramos/bayesian_ensembling.
+ *
+ * The reference has no FFI: its boundary is a duck-typed Python plug-in protocol
+ * (SURVEY.md 8(b)).  Each entry point below names the reference interface whose arithmetic it
+ * replaces; the Python classes in bayesian_ensembling_amd/ keep the reference signatures and call
+ * these through ctypes.  Plain pointers and sizes only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *   - all matrices row-major, fp64 (the reference precision: ensembles/__init__.py:10)
+ *   - every function returns 0 on success, >0 = hipError_t / ncclResult_t passthrough,
+ *     <0 = domain error (BAYENS_E_*); bayens_last_error(ctx) holds the message
+ *   - `loc` says where the caller's buffers live: BAYENS_HOST (the library stages them through
+ *     HBM) or BAYENS_DEVICE (pointers from bayens_malloc, already resident in HBM)
+ *   - one ctx per (process, device); calls on one ctx are not re-entrant
+ */
+#ifndef BAYENS_H
+#define BAYENS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bayens_ctx bayens_ctx;
+
+enum { BAYENS_HOST = 0, BAYENS_DEVICE = 1 };
+/* kernel ids: 0 is the only kernel the reference instantiates (models.py:186) */
+enum { BAYENS_MATERN32 = 0, BAYENS_MATERN52 = 1, BAYENS_RBF = 2 };
+enum {
+  BAYENS_E_ARG = -1,      /* bad argument */
+  BAYENS_E_NOTPD = -2,    /* a Cholesky pivot was not positive; info[] holds member-wise pivots */
+  BAYENS_E_NOGPU = -3,    /* no HIP device / kernel image not loadable */
+  BAYENS_E_COMM = -4,     /* RCCL not initialised or not loadable */
+  BAYENS_E_ALLOC = -5
+};
+
+/* ---- context, memory and timing plumbing -------------------------------------------------- */
+int bayens_ctx_create(int device, bayens_ctx** out);
+int bayens_ctx_destroy(bayens_ctx* ctx);
+const char* bayens_last_error(bayens_ctx* ctx);
+const char* bayens_version(void);
+int bayens_device_info(bayens_ctx* ctx, char* name, int name_len, int* compute_units, size_t* hbm_bytes);
+int bayens_malloc(bayens_ctx* ctx, size_t bytes, void** dptr);
+int bayens_free(bayens_ctx* ctx, void* dptr);
+int bayens_memcpy_h2d(bayens_ctx* ctx, void* dst, const void* src, size_t bytes);
+int bayens_memcpy_d2h(bayens_ctx* ctx, void* dst, const void* src, size_t bytes);
+int bayens_sync(bayens_ctx* ctx);
+/* HIP-event timer on the ctx stream (the stream every kernel of this library is launched on) */
+int bayens_timer_start(bayens_ctx* ctx);
+int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
+/* per-kernel-family accounting (HIP events around every launch of the family; off by default).
+ * family 0 = the batched fp64 MFMA GEMM.  Returns summed device ms, algorithmic flop, launches. */
+int bayens_profile_enable(bayens_ctx* ctx, int on);
+int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/* GPDTW1D.fit after the DTW-barycentre stage, for B independent members at once
+ * (reference: ensembles/models.py:179-220 called from ModelCollection.fit, ensembles/data.py:385-395;
+ *  third-party arithmetic restated in SURVEY.md Appendix A), followed by
+ * Distribution.__post_init__ -> distrax MultivariateNormalFullCovariance (ensembles/data.py:38-39):
+ *   X       [B][N][R]   realisation_set.T per member (models.py:182)
+ *   y_mean  [B][N]      DBA target (models.py:176-178; boundary input)
+ *   y_var   [B][N]      np.var(realisation_set, axis=0) (models.py:179)
+ *   n_iters             n_optim_nits; gamma 0.5 (models.py:191); lr 0.01 (models.py:192); jitter 1e-6
+ * outputs (any may be NULL except mu/cov):
+ *   mu [B][N], cov [B][N][N] (predict_f full_cov + diag(y_var), models.py:217-220),
+ *   cov_chol [B][N][N] lower Cholesky of cov, logdet [B] = sum(log(diag(chol))),
+ *   hyp [B][2] final (variance, lengthscale), info [B] 0 or 1-based failing pivot.
+ *   loss_trace must be NULL in this version (models.py:211-215 only feeds a progress bar). */
+int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
+                        const double* X, const double* y_mean, const double* y_var,
+                        int kernel, int n_iters, double gamma, double lr, double jitter,
+                        double* mu, double* cov, double* cov_chol, double* logdet,
+                        double* hyp, double* loss_trace, int* info);
+
+/* Distribution.__post_init__ for a caller-supplied full covariance (ensembles/data.py:38-39):
+ * chol [B][N][N] lower, logdet [B]. */
+int bayens_mvn_factor_batch(bayens_ctx* ctx, int loc, int B, int N, const double* cov,
+                            double* chol, double* logdet, int* info);
+
+/* _dist.variance() of a full-covariance posterior = diag(cov)  (ensemble_scheme.py:64-65, weights.py:311) */
+int bayens_extract_diag(bayens_ctx* ctx, int loc, int B, int N, const double* cov, double* var);
+
+/* LogLikelihoodWeight._compute inner loops, MVN branch (ensembles/weights.py:88-104):
+ * ll_mean[b][t] = mean_r log N(obs[r][t] * 1_N ; mu_b, cov_b)   obs [R_obs][N] */
+int bayens_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
+                       const double* mu, const double* cov_chol, const double* logdet,
+                       const double* obs, double* ll_mean);
+
+/* same, dx.Normal branch (ensembles/weights.py:95-96): elementwise log N(obs; mu, scale) */
+int bayens_normal_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
+                              const double* mu, const double* scale, const double* obs, double* ll_mean);
+
+/* standardise + normalise over the model axis (ensembles/weights.py:107,118-123):
+ * w_raw = exp(c_std * ll_mean), w = w_raw / sum_m w_raw.  scheme 0 = exp.  w_raw may be NULL. */
+int bayens_weights_normalise(bayens_ctx* ctx, int loc, int M, int P, const double* ll_mean,
+                             double c_std, int scheme, double* w, double* w_raw);
+
+/* ModelSimilarityWeight mode='temporal' (ensembles/weights.py:302-325,331 with
+ * ensembles/wasserstein.py:21-47 on 1x1 dx.Normal(mean, scale=variance)). mean,var,w [M][P]. */
+int bayens_w2_temporal(bayens_ctx* ctx, int loc, int M, int P, const double* mean,
+                       const double* var, double* w);
+
+/* Barycentre._compute (ensembles/ensemble_scheme.py:52-78) + gaussian_barycentre
+ * (ensembles/wasserstein.py:61-100).  w, mean, var [M][P]; mu_out, var_out [P] (var_out = sigma*^2). */
+int bayens_barycentre(bayens_ctx* ctx, int loc, int M, int P, const double* w, const double* mean,
+                      const double* var, double tol, double init_var,
+                      double* mu_out, double* var_out, int* n_not_converged);
+
+/* WeightedModelMean._compute (ensembles/ensemble_scheme.py:136-160).
+ * data [M][R_max][P] (rows r >= R[m] ignored), R [M], w [M][P]. */
+int bayens_weighted_model_mean(bayens_ctx* ctx, int loc, int M, int R_max, const int* R, int P,
+                               const double* data, const double* w, double* mu_out, double* var_out);
+
+/* ---- multi-GPU: RCCL all-gather of per-member rows ------------------------ */
+int bayens_comm_unique_id(bayens_ctx* ctx, void* id128);            /* 128-byte ncclUniqueId, rank 0 */
+int bayens_comm_init(bayens_ctx* ctx, int rank, int nranks, const void* id128);
+int bayens_comm_destroy(bayens_ctx* ctx);
+/* local [M_loc][P] device rows -> all [nranks*M_loc][P] device rows (ncclAllGather on the ctx stream) */
+int bayens_allgather_rows(bayens_ctx* ctx, const double* local_dev, double* all_dev, int M_loc, int P);
+
+/* ---- diagnostic entry points used by the GPU unit tests (device primitives, batched) ------- */
+/* C = alpha * op(A) op(B) + beta * C on host buffers; flags as in csrc/prims.h */
+int bayens_test_gemm(bayens_ctx* ctx, int nb, int m, int n, int k, double alpha,
+                     const double* A, int lda, const double* B, int ldb, double beta,
+                     double* C, int ldc, int flags, double diag_add);
+/* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
+int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
+/* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
+int bayens_test_trsm(bayens_ctx* ctx, int nb, int m, int n, const double* L, double* Bm, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYENS_H */

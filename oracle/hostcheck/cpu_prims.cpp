@@ -1,0 +1,335 @@
+// cpu_prims.cpp - TEST INFRASTRUCTURE ONLY (lives under oracle/, never linked into the product).
+//
+// A deliberately naive CPU implementation of the device-primitive interface (csrc/prims.h) so that the
+// host-side sequencing in csrc/driver.cpp (recursive Cholesky / triangular solves, the natgrad + Adam
+// iteration, the prediction epilogue) can be validated against the NumPy oracle in a container without a
+// GPU.  The semantics written here are the specification each HIP kernel is tested against on the GPU.
+//
+// Build: oracle/hostcheck/build.sh  ->  oracle/_build/libhostcheck.so
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../bayesian_ensembling_amd/csrc/driver.h"
+
+using namespace bayens;
+
+namespace {
+
+inline double softplus(double u) { return u > 30 ? u : std::log1p(std::exp(u)); }
+
+struct CpuPrims : Prims {
+  void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
+            double diag_add) override {
+    const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
+    std::vector<double> out((size_t)m * n);
+    for (int b = 0; b < nb; ++b) {
+      const double* a = A.p + b * A.stride;
+      const double* bb = B.p + b * B.stride;
+      double* c = C.p + b * C.stride;
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+          if ((flags & GEMM_TRI_OUT) && (j / LEAF) > (i / LEAF)) { out[(size_t)i * n + j] = NAN; continue; }
+          int k0 = 0;
+          if (flags & GEMM_KTRIM_TN_LOWER) {   // same trimming the device kernel applies per 128-tile
+            int r0 = (i / 128) * 128, c0 = (j / 128) * 128;
+            k0 = r0 > c0 ? r0 : c0;
+          }
+          double s = 0;
+          for (int kk = k0; kk < k; ++kk) {
+            double av = ta ? a[(size_t)kk * A.ld + i] : a[(size_t)i * A.ld + kk];
+            double bv = tb ? bb[(size_t)j * B.ld + kk] : bb[(size_t)kk * B.ld + j];
+            s += av * bv;
+          }
+          double v = alpha * s + (beta != 0.0 ? beta * c[(size_t)i * C.ld + j] : 0.0);
+          if (i == j) v += diag_add;
+          if (flags & GEMM_EPI_PHI) { if (i < j) v = 0; else if (i == j) v *= 0.5; }
+          out[(size_t)i * n + j] = v;
+        }
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+          if ((flags & GEMM_TRI_OUT) && (j / LEAF) > (i / LEAF)) continue;
+          c[(size_t)i * C.ld + j] = out[(size_t)i * n + j];
+        }
+    }
+  }
+
+  void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override {
+    for (int b = 0; b < nb; ++b) {
+      double* a = Ablk.p + b * Ablk.stride;
+      const int ld = Ablk.ld;
+      for (int j = 0; j < LEAF; ++j) {
+        double d = a[(size_t)j * ld + j];
+        if (!(d > 0.0)) { if (info[b] == 0) info[b] = pivot_base + j + 1; d = 1.0; }
+        d = std::sqrt(d);
+        a[(size_t)j * ld + j] = d;
+        for (int i = j + 1; i < LEAF; ++i) a[(size_t)i * ld + j] /= d;
+        for (int i = j + 1; i < LEAF; ++i)
+          for (int kk = j + 1; kk <= i; ++kk) a[(size_t)i * ld + kk] -= a[(size_t)i * ld + j] * a[(size_t)kk * ld + j];
+      }
+      for (int i = 0; i < LEAF; ++i)
+        for (int j = i + 1; j < LEAF; ++j) a[(size_t)i * ld + j] = 0.0;
+      double* iv = inv + b * inv_stride;
+      for (int c = 0; c < LEAF; ++c)
+        for (int i = 0; i < LEAF; ++i) {
+          if (i < c) { iv[i * LEAF + c] = 0.0; continue; }
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int kk = c; kk < i; ++kk) s -= a[(size_t)i * ld + kk] * iv[kk * LEAF + c];
+          iv[i * LEAF + c] = s / a[(size_t)i * ld + i];
+        }
+    }
+  }
+
+  void copy(int nb, int n, Mat src, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        std::memcpy(dst.p + b * dst.stride + (size_t)i * dst.ld, src.p + b * src.stride + (size_t)i * src.ld, n * sizeof(double));
+  }
+  void tri_copy(int nb, int n, Mat src, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          dst.p[b * dst.stride + (size_t)i * dst.ld + j] = j <= i ? src.p[b * src.stride + (size_t)i * src.ld + j] : 0.0;
+  }
+  void transpose_lower(int nb, int n, Mat W, Mat Wt) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          Wt.p[b * Wt.stride + (size_t)i * Wt.ld + j] = j >= i ? W.p[b * W.stride + (size_t)j * W.ld + i] : 0.0;
+  }
+  void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
+                  const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) override {
+    const double u0 = std::log(std::exp(1.0) - 1.0);
+    for (int b = 0; b < nb; ++b) {
+      for (int i = 0; i < Np; ++i) {
+        for (int j = 0; j < Np; ++j) Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j] = i == j ? 1.0 : 0.0;
+        theta1[(size_t)b * Np + i] = 0; mvec[(size_t)b * Np + i] = 0;
+        y_pad[(size_t)b * Np + i] = i < N ? y_in[(size_t)b * N + i] : 0.0;
+        nu_pad[(size_t)b * Np + i] = i < N ? nu_in[(size_t)b * N + i] : 1.0;
+      }
+      double* u = ustate + b * 8;
+      u[0] = u[1] = u0; for (int q = 2; q < 8; ++q) u[q] = 0;
+      info[b] = 0;
+    }
+  }
+  static void kern(int kernel, double var, double ls, double r2, double& K, double& dKdl) {
+    const double S3 = std::sqrt(3.0), S5 = std::sqrt(5.0);
+    if (kernel == 2) { double r2c = r2 > 0 ? r2 : 0; K = var * std::exp(-0.5 * r2c); dKdl = K * r2c / ls; return; }
+    bool clamp = r2 <= 1e-36;
+    double r = std::sqrt(r2 > 1e-36 ? r2 : 1e-36);
+    if (kernel == 0) { double e = std::exp(-S3 * r); K = var * (1 + S3 * r) * e; dKdl = 3 * var * r * r * e / ls; }
+    else { double e = std::exp(-S5 * r); K = var * (1 + S5 * r + 5.0 / 3.0 * r * r) * e; dKdl = 5.0 / 3.0 * var * r * r * (1 + S5 * r) * e / ls; }
+    if (clamp) dKdl = 0;
+  }
+  static double r2_of(const double* X, int R, int i, int j, double ls) {
+    double g = 0, si = 0, sj = 0;
+    for (int d = 0; d < R; ++d) {
+      double xi = X[(size_t)i * R + d] / ls, xj = X[(size_t)j * R + d] / ls;
+      g += xi * xj; si += xi * xi; sj += xj * xj;
+    }
+    return (-2.0 * g + si) + sj;
+  }
+  void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
+            Mat K0, Mat Lb) override {
+    for (int b = 0; b < nb; ++b) {
+      double var = softplus(ustate[b * 8 + 0]), ls = softplus(ustate[b * 8 + 1]);
+      const double* Xb = X + (size_t)b * N * R;
+      for (int i = 0; i < Np; ++i)
+        for (int j = 0; j < Np; ++j) {
+          double K, d;
+          if (i < N && j < N) kern(kernel, var, ls, r2_of(Xb, R, i, j, ls), K, d);
+          else K = i == j ? 1.0 : 0.0;
+          K0.p[b * K0.stride + (size_t)i * K0.ld + j] = K;
+          Lb.p[b * Lb.stride + (size_t)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+        }
+    }
+  }
+  void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i) {
+        double s = 1.0 / std::sqrt(nu[(size_t)b * n + i]);
+        for (int j = 0; j < n; ++j) dst.p[b * dst.stride + (size_t)i * dst.ld + j] = src.p[b * src.stride + (size_t)i * src.ld + j] * s;
+      }
+  }
+  void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma, double* theta1) override {
+    for (int b = 0; b < nb; ++b)
+      for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int i = j; i < n; ++i) s += L.p[b * L.stride + (size_t)i * L.ld + j] * (y[(size_t)b * n + i] / nu[(size_t)b * n + i]);
+        theta1[(size_t)b * n + j] = (1 - gamma) * theta1[(size_t)b * n + j] + gamma * s;
+      }
+  }
+  void trsv2(int nb, int n, Mat C, const double*, long, const double* theta1, double* mvec) override {
+    std::vector<double> z(n);
+    for (int b = 0; b < nb; ++b) {
+      const double* c = C.p + b * C.stride;
+      for (int i = 0; i < n; ++i) {
+        double s = theta1[(size_t)b * n + i];
+        for (int k = 0; k < i; ++k) s -= c[(size_t)i * C.ld + k] * z[k];
+        z[i] = s / c[(size_t)i * C.ld + i];
+      }
+      for (int i = n - 1; i >= 0; --i) {
+        double s = z[i];
+        for (int k = i + 1; k < n; ++k) s -= c[(size_t)k * C.ld + i] * mvec[(size_t)b * n + k];
+        mvec[(size_t)b * n + i] = s / c[(size_t)i * C.ld + i];
+      }
+    }
+  }
+  void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k <= i; ++k) s += L.p[b * L.stride + (size_t)i * L.ld + k] * mvec[(size_t)b * n + k];
+        a[(size_t)b * n + i] = s - y[(size_t)b * n + i];
+      }
+  }
+  void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          double& x = X.p[b * X.stride + (size_t)i * X.ld + j];
+          x = j <= i ? (a[(size_t)b * n + i] * mvec[(size_t)b * n + j] + x) / nu[(size_t)b * n + i] : 0.0;
+        }
+  }
+  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) override {
+    (void)Np;
+    for (int b = 0; b < nb; ++b) {
+      double* u = ustate + b * 8;
+      double var = softplus(u[0]), ls = softplus(u[1]);
+      const double* Xb = X + (size_t)b * N * R;
+      double gv = 0, gl = 0;
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+          double K, d;
+          kern(kernel, var, ls, r2_of(Xb, R, i, j, ls), K, d);
+          double kb = Kbt.p[b * Kbt.stride + (size_t)i * Kbt.ld + j];
+          gv += kb * K; gl += kb * d;
+        }
+      gv /= var;
+      double g[2] = {gv * (1 - std::exp(-var)), gl * (1 - std::exp(-ls))};
+      double t = u[6] + 1; u[6] = t;
+      double lr_t = lr * std::sqrt(1 - std::pow(0.999, t)) / (1 - std::pow(0.9, t));
+      for (int q = 0; q < 2; ++q) {
+        u[2 + q] = 0.9 * u[2 + q] + 0.1 * g[q];
+        u[4 + q] = 0.999 * u[4 + q] + 0.001 * g[q] * g[q];
+        u[q] -= lr_t * u[2 + q] / (std::sqrt(u[4 + q]) + 1e-7);
+      }
+    }
+  }
+  void gemv_n(int nb, int n, Mat A, const double* x, double* y) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s += A.p[b * A.stride + (size_t)i * A.ld + k] * x[(size_t)b * n + k];
+        y[(size_t)b * n + i] = s;
+      }
+  }
+  void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          dst.p[b * dst.stride + (size_t)i * dst.ld + j] = K0.p[b * K0.stride + (size_t)i * K0.ld + j] + (i == j ? nu[(size_t)b * n + i] : 0.0);
+  }
+  void extract(int nb, int N, Mat src, double* dst, int mode) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+          const double* s = src.p + b * src.stride;
+          double v;
+          if (mode == 0) v = s[(size_t)i * src.ld + j];
+          else if (mode == 1) v = j <= i ? s[(size_t)i * src.ld + j] : s[(size_t)j * src.ld + i];
+          else v = j <= i ? s[(size_t)i * src.ld + j] : 0.0;
+          dst[((size_t)b * N + i) * N + j] = v;
+        }
+  }
+  void extract_vec(int nb, int N, int Np, const double* src, double* dst) override {
+    for (int b = 0; b < nb; ++b) std::memcpy(dst + (size_t)b * N, src + (size_t)b * Np, N * sizeof(double));
+  }
+  void logdet(int nb, int N, Mat Lc, double* out) override {
+    for (int b = 0; b < nb; ++b) {
+      double s = 0;
+      for (int i = 0; i < N; ++i) s += std::log(Lc.p[b * Lc.stride + (size_t)i * Lc.ld + i]);
+      out[b] = s;
+    }
+  }
+  void hyp_out(int nb, const double* ustate, double* hyp) override {
+    for (int b = 0; b < nb; ++b) { hyp[b * 2] = softplus(ustate[b * 8]); hyp[b * 2 + 1] = softplus(ustate[b * 8 + 1]); }
+  }
+};
+
+struct HostWs {
+  FitWorkspace ws;
+  std::vector<std::vector<double>> bufs;
+  std::vector<int> info;
+  double* alloc(size_t n) { bufs.emplace_back(n, 0.0); return bufs.back().data(); }
+  HostWs(int nb, int Np) {
+    ws.nb = nb; ws.Np = Np;
+    auto mat = [&]() { return Mat{alloc((size_t)nb * Np * Np), Np, (long)Np * Np}; };
+    ws.K0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T1 = mat(); ws.T2 = mat();
+    ws.invL = alloc((size_t)nb * Np * LEAF); ws.invC = alloc((size_t)nb * Np * LEAF);
+    ws.theta1 = alloc((size_t)nb * Np); ws.mvec = alloc((size_t)nb * Np); ws.avec = alloc((size_t)nb * Np);
+    ws.y = alloc((size_t)nb * Np); ws.nu = alloc((size_t)nb * Np); ws.muvec = alloc((size_t)nb * Np);
+    ws.ustate = alloc((size_t)nb * 8);
+    info.assign(nb, 0); ws.info = info.data();
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int hostcheck_gp_fit(int B, int N, int R, const double* X, const double* y_mean, const double* y_var,
+                     int kernel, int n_iters, double gamma, double lr, double jitter, double* mu,
+                     double* cov, double* chol, double* logdet, double* hyp, int* info) {
+  CpuPrims P;
+  HostWs h(B, pad_to_leaf(N));
+  FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+  gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp);
+  for (int b = 0; b < B; ++b) info[b] = h.info[b];
+  return 0;
+}
+
+// blocked Cholesky / solves on their own (n % 64 == 0)
+int hostcheck_potrf(int nb, int n, double* A, int* info) {
+  CpuPrims P;
+  std::vector<double> inv((size_t)nb * n * LEAF);
+  for (int b = 0; b < nb; ++b) info[b] = 0;
+  Mat Am{A, n, (long)n * n};
+  // callers pass the full symmetric matrix; the blocked factorisation needs zeros above the diagonal blocks
+  std::vector<double> tmp((size_t)nb * n * n);
+  Mat T{tmp.data(), n, (long)n * n};
+  P.tri_copy(nb, n, Am, T);
+  potrf(P, nb, n, T, inv.data(), (long)n * LEAF, info);
+  std::memcpy(A, tmp.data(), tmp.size() * sizeof(double));
+  return 0;
+}
+
+int hostcheck_trsm(int nb, int m, int n, const double* L, double* Bm, int mode, int rhs_lower) {
+  CpuPrims P;
+  std::vector<double> Lc(L, L + (size_t)nb * n * n), inv((size_t)nb * n * LEAF);
+  std::vector<int> info(nb, 0);
+  Mat Lm{Lc.data(), n, (long)n * n};
+  // re-derive the inverted diagonal blocks from the given factor: factor L L^T blockwise is overkill;
+  // invert each diagonal block directly.
+  for (int b = 0; b < nb; ++b)
+    for (int lf = 0; lf < n / LEAF; ++lf) {
+      const double* a = Lc.data() + (size_t)b * n * n + (size_t)lf * LEAF * n + lf * LEAF;
+      double* iv = inv.data() + (size_t)b * n * LEAF + (size_t)lf * LEAF * LEAF;
+      for (int c = 0; c < LEAF; ++c)
+        for (int i = 0; i < LEAF; ++i) {
+          if (i < c) { iv[i * LEAF + c] = 0; continue; }
+          double s = i == c ? 1.0 : 0.0;
+          for (int kk = c; kk < i; ++kk) s -= a[(size_t)i * n + kk] * iv[kk * LEAF + c];
+          iv[i * LEAF + c] = s / a[(size_t)i * n + i];
+        }
+    }
+  Mat B{Bm, n, (long)m * n};
+  if (mode == 0) trsm_rlt(P, nb, m, n, Lm, inv.data(), (long)n * LEAF, B);
+  else trsm_rln(P, nb, m, n, Lm, inv.data(), (long)n * LEAF, B, rhs_lower != 0);
+  return 0;
+}
+
+double hostcheck_fit_flops(int N, int R, int T) { return fit_flops(N, R, T); }
+}
