@@ -1,0 +1,368 @@
+"""ctypes binding of libbayens.so (include/bayens.h).  The library is the product: there is no CPU
+fallback - if it cannot be loaded, or no MI355X is visible, every hot-path call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbayens.so")
+HEADER = os.path.join(HERE, "..", "include", "bayens.h")
+
+HOST, DEVICE = 0, 1
+MATERN32, MATERN52, RBF = 0, 1, 2
+KERNEL_IDS = {"matern32": MATERN32, "matern52": MATERN52, "rbf": RBF}
+
+GEMM_TA, GEMM_TB, GEMM_TRI_OUT, GEMM_KTRIM_TN_LOWER, GEMM_EPI_PHI = 1, 2, 4, 8, 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+
+class BayensError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbayens error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name include/bayens.h declares (used by the CPU test that checks the exports)."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bayens_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BayensError(-3, f"{LIB_PATH} is missing: build it with `python -m bayesian_ensembling_amd.build` "
+                              "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.bayens_version.restype = C.c_char_p
+    lib.bayens_last_error.restype = C.c_char_p
+    lib.bayens_last_error.argtypes = [_vp]
+    lib.bayens_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+    lib.bayens_ctx_destroy.argtypes = [_vp]
+    lib.bayens_device_info.argtypes = [_vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_size_t)]
+    lib.bayens_malloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+    lib.bayens_free.argtypes = [_vp, _vp]
+    lib.bayens_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    lib.bayens_memcpy_d2h.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    lib.bayens_sync.argtypes = [_vp]
+    lib.bayens_timer_start.argtypes = [_vp]
+    lib.bayens_timer_stop.argtypes = [_vp, _dp]
+    lib.bayens_profile_enable.argtypes = [_vp, C.c_int]
+    lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
+    lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                        C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+    lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+    lib.bayens_weights_normalise.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]
+    lib.bayens_w2_temporal.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
+    lib.bayens_barycentre.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_double,
+                                      _vp, _vp, _ip]
+    lib.bayens_weighted_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    lib.bayens_comm_unique_id.argtypes = [_vp, _vp]
+    lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
+    lib.bayens_comm_destroy.argtypes = [_vp]
+    lib.bayens_allgather_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
+    lib.bayens_test_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp,
+                                     C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
+    lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceBuffer):
+        return a.ptr
+    if isinstance(a, int):
+        return a
+    return a.ctypes.data
+
+
+class DeviceBuffer:
+    """A block of HBM owned by a Context (bayens_malloc / bayens_free)."""
+
+    def __init__(self, ctx, nbytes, shape=None, dtype=np.float64):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.shape = shape
+        self.dtype = np.dtype(dtype)
+        p = _vp()
+        ctx._check(ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.bayens_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape=None):
+        shape = shape if shape is not None else self.shape
+        out = np.empty(shape, dtype=self.dtype)
+        self.ctx._check(self.ctx.lib.bayens_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def offset(self, nbytes):
+        return self.ptr + int(nbytes)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.bayens_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One libbayens context = one HIP device + stream.  Raises BayensError when no GPU is usable."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.bayens_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise BayensError(rc, "bayens_ctx_create failed (no usable HIP device: the hot path needs an MI355X; "
+                                  "there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bayens_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        hbm = C.c_size_t()
+        self._check(self.lib.bayens_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def empty(self, shape, dtype=np.float64):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return DeviceBuffer(self, max(n, 8), tuple(shape), dtype)
+
+    def to_device(self, arr, dtype=np.float64):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        return self.empty(arr.shape, dtype).upload(arr)
+
+    def sync(self):
+        self._check(self.lib.bayens_sync(self.h))
+
+    def timer_start(self):
+        self._check(self.lib.bayens_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        self._check(self.lib.bayens_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.bayens_profile_enable(self.h, 1 if on else 0))
+
+    def profile_get(self, family=0):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+        self._check(self.lib.bayens_profile_get(self.h, family, C.byref(ms), C.byref(fl), C.byref(n)))
+        return {"ms": ms.value, "flop": fl.value, "launches": n.value}
+
+    # -- hot path (host arrays in, host arrays out) --------------------------------------------------
+    def gp_fit_batch(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6,
+                     want_chol=True):
+        X = _f64(X)
+        B, N, R = X.shape
+        y_mean = _f64(y_mean).reshape(B, N)
+        y_var = _f64(y_var).reshape(B, N)
+        mu = np.empty((B, N))
+        cov = np.empty((B, N, N))
+        chol = np.empty((B, N, N)) if want_chol else None
+        logdet = np.empty(B) if want_chol else None
+        hyp = np.empty((B, 2))
+        info = np.zeros(B, dtype=np.int32)
+        rc = self.lib.bayens_gp_fit_batch(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+                                          int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
+                                          _ptr(logdet), _ptr(hyp), None, _ptr(info))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
+        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info}
+
+    def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
+                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
+        info = np.zeros(B, dtype=np.int32)
+        rc = self.lib.bayens_gp_fit_batch(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+                                          int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
+                                          _ptr(logdet), _ptr(hyp), None, _ptr(info))
+        self._check(rc)
+        return info
+
+    def mvn_factor_batch(self, cov):
+        cov = _f64(cov)
+        B, N, _ = cov.shape
+        chol = np.empty((B, N, N))
+        logdet = np.empty(B)
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.bayens_mvn_factor_batch(self.h, HOST, B, N, _ptr(cov), _ptr(chol), _ptr(logdet),
+                                                     _ptr(info)))
+        return chol, logdet
+
+    def extract_diag(self, cov):
+        cov = _f64(cov)
+        B, N, _ = cov.shape
+        var = np.empty((B, N))
+        self._check(self.lib.bayens_extract_diag(self.h, HOST, B, N, _ptr(cov), _ptr(var)))
+        return var
+
+    def loglik_rows(self, mu, chol, logdet, obs, loc=HOST, out=None):
+        if loc == HOST:
+            mu, chol, logdet, obs = _f64(mu), _f64(chol), _f64(logdet), _f64(obs)
+            B, N = mu.shape
+            R_obs = obs.shape[0]
+            out = np.empty((B, N))
+            self._check(self.lib.bayens_loglik_rows(self.h, HOST, B, N, R_obs, _ptr(mu), _ptr(chol), _ptr(logdet),
+                                                    _ptr(obs), _ptr(out)))
+            return out
+        raise ValueError("use loglik_rows_dev for resident buffers")
+
+    def loglik_rows_dev(self, B, N, R_obs, mu, chol, logdet, obs, ll_mean):
+        self._check(self.lib.bayens_loglik_rows(self.h, DEVICE, B, N, R_obs, _ptr(mu), _ptr(chol), _ptr(logdet),
+                                                _ptr(obs), _ptr(ll_mean)))
+
+    def normal_loglik_rows(self, mu, scale, obs):
+        mu, scale, obs = _f64(mu), _f64(scale), _f64(obs)
+        B, N = mu.shape
+        out = np.empty((B, N))
+        self._check(self.lib.bayens_normal_loglik_rows(self.h, HOST, B, N, obs.shape[0], _ptr(mu), _ptr(scale),
+                                                       _ptr(obs), _ptr(out)))
+        return out
+
+    def weights_normalise(self, ll_mean, c_std=1.0, return_raw=False):
+        ll_mean = _f64(ll_mean)
+        M, P = ll_mean.shape
+        w = np.empty((M, P))
+        raw = np.empty((M, P)) if return_raw else None
+        self._check(self.lib.bayens_weights_normalise(self.h, HOST, M, P, _ptr(ll_mean), float(c_std), 0, _ptr(w),
+                                                      _ptr(raw)))
+        return (w, raw) if return_raw else w
+
+    def weights_normalise_dev(self, M, P, ll_mean, c_std, w, w_raw=None):
+        self._check(self.lib.bayens_weights_normalise(self.h, DEVICE, M, P, _ptr(ll_mean), float(c_std), 0, _ptr(w),
+                                                      _ptr(w_raw)))
+
+    def w2_temporal(self, mean, var):
+        mean, var = _f64(mean), _f64(var)
+        M, P = mean.shape
+        w = np.empty((M, P))
+        self._check(self.lib.bayens_w2_temporal(self.h, HOST, M, P, _ptr(mean), _ptr(var), _ptr(w)))
+        return w
+
+    def barycentre(self, w, mean, var, tol=1e-6, init_var=1.0):
+        w, mean, var = _f64(w), _f64(mean), _f64(var)
+        M, P = mean.shape
+        w = np.ascontiguousarray(w.reshape(M, -1))
+        mu = np.empty(P)
+        v = np.empty(P)
+        bad = C.c_int(0)
+        self._check(self.lib.bayens_barycentre(self.h, HOST, M, P, _ptr(w), _ptr(mean), _ptr(var), tol, init_var,
+                                               _ptr(mu), _ptr(v), C.byref(bad)))
+        return mu, v, bad.value
+
+    def barycentre_dev(self, M, P, w, mean, var, mu_out, var_out, tol=1e-6, init_var=1.0):
+        bad = C.c_int(0)
+        self._check(self.lib.bayens_barycentre(self.h, DEVICE, M, P, _ptr(w), _ptr(mean), _ptr(var), tol, init_var,
+                                               _ptr(mu_out), _ptr(var_out), C.byref(bad)))
+        return bad.value
+
+    def extract_diag_dev(self, B, N, cov, var):
+        self._check(self.lib.bayens_extract_diag(self.h, DEVICE, B, N, _ptr(cov), _ptr(var)))
+
+    def weighted_model_mean(self, data, R, w):
+        data, w = _f64(data), _f64(w)
+        M, R_max, P = data.shape
+        R = np.ascontiguousarray(R, dtype=np.int32)
+        mu = np.empty(P)
+        v = np.empty(P)
+        self._check(self.lib.bayens_weighted_model_mean(self.h, HOST, M, R_max, _ptr(R), P, _ptr(data), _ptr(w),
+                                                        _ptr(mu), _ptr(v)))
+        return mu, v
+
+    # -- RCCL ------------------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.bayens_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._check(self.lib.bayens_comm_init(self.h, rank, nranks, buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.bayens_comm_destroy(self.h))
+
+    def allgather_rows(self, local, all_, M_loc, P):
+        self._check(self.lib.bayens_allgather_rows(self.h, _ptr(local), _ptr(all_), M_loc, P))
+
+    # -- diagnostics -----------------------------------------------------------------------------------
+    def test_gemm(self, A, B, Cm, alpha=1.0, beta=0.0, flags=0, diag_add=0.0):
+        A, B = _f64(A), _f64(B)
+        Cm = np.array(Cm, dtype=np.float64, order="C", copy=True)
+        nb, m, n = Cm.shape
+        k = A.shape[1] if (flags & GEMM_TA) else A.shape[2]
+        self._check(self.lib.bayens_test_gemm(self.h, nb, m, n, k, alpha, _ptr(A), A.shape[2], _ptr(B), B.shape[2],
+                                              beta, _ptr(Cm), Cm.shape[2], flags, diag_add))
+        return Cm
+
+    def test_potrf(self, A):
+        A = np.array(A, dtype=np.float64, order="C", copy=True)
+        nb, n, _ = A.shape
+        info = np.zeros(nb, dtype=np.int32)
+        self._check(self.lib.bayens_test_potrf(self.h, nb, n, _ptr(A), _ptr(info)))
+        return A, info
+
+    def test_trsm(self, L, Bm, mode):
+        L = _f64(L)
+        Bm = np.array(Bm, dtype=np.float64, order="C", copy=True)
+        nb, m, n = Bm.shape
+        self._check(self.lib.bayens_test_trsm(self.h, nb, m, n, _ptr(L), _ptr(Bm), mode))
+        return Bm
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the device LOCAL_RANK selects (one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

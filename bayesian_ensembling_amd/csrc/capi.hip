@@ -1,0 +1,567 @@
+// capi.hip - the extern "C" boundary of libbayens (include/bayens.h): context, HBM plumbing, the hot-path
+// entry points and the RCCL all-gather.  No torch types, no exceptions across the boundary.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bayens.h"
+#include "driver.h"
+#include "hip_prims.h"
+
+using namespace bayens;
+
+// ---- minimal RCCL surface, resolved with dlopen so that the library loads on hosts without RCCL ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef ncclResult_t (*pfn_ncclGetUniqueId)(ncclUniqueId*);
+typedef ncclResult_t (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+typedef ncclResult_t (*pfn_ncclCommDestroy)(ncclComm_t);
+typedef ncclResult_t (*pfn_ncclAllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, ncclComm_t, hipStream_t);
+typedef const char* (*pfn_ncclGetErrorString)(ncclResult_t);
+constexpr int NCCL_FLOAT64 = 8;
+
+struct RcclApi {
+  void* handle = nullptr;
+  pfn_ncclGetUniqueId GetUniqueId = nullptr;
+  pfn_ncclCommInitRank CommInitRank = nullptr;
+  pfn_ncclCommDestroy CommDestroy = nullptr;
+  pfn_ncclAllGather AllGather = nullptr;
+  pfn_ncclGetErrorString GetErrorString = nullptr;
+  bool load(std::string& err) {
+    if (handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (handle) break;
+    }
+    if (!handle) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
+    GetUniqueId = (pfn_ncclGetUniqueId)dlsym(handle, "ncclGetUniqueId");
+    CommInitRank = (pfn_ncclCommInitRank)dlsym(handle, "ncclCommInitRank");
+    CommDestroy = (pfn_ncclCommDestroy)dlsym(handle, "ncclCommDestroy");
+    AllGather = (pfn_ncclAllGather)dlsym(handle, "ncclAllGather");
+    GetErrorString = (pfn_ncclGetErrorString)dlsym(handle, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather) { err = "librccl: missing symbols"; return false; }
+    return true;
+  }
+};
+
+struct bayens_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  HipPrims* prims = nullptr;
+  std::string err;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // fit workspace (grown on demand)
+  FitWorkspace ws;
+  std::vector<void*> ws_allocs;
+  // generic device scratch for host-staged calls
+  std::vector<void*> temps;
+  RcclApi rccl;
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+namespace {
+
+int fail(bayens_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+template <typename F>
+int guarded(bayens_ctx* c, F&& f) {
+  if (!c) return BAYENS_E_ARG;
+  try {
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, (int)e, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return f();
+  } catch (const HipError& e) {
+    return fail(c, e.code > 0 ? e.code : BAYENS_E_ARG, e.what);
+  } catch (const std::exception& e) {
+    return fail(c, BAYENS_E_ALLOC, e.what());
+  }
+}
+
+void free_ws(bayens_ctx* c) {
+  for (void* p : c->ws_allocs) (void)hipFree(p);
+  c->ws_allocs.clear();
+  c->ws = FitWorkspace();
+}
+
+void ensure_ws(bayens_ctx* c, int nb, int Np) {
+  if (c->ws.nb >= nb && c->ws.Np == Np) { return; }
+  free_ws(c);
+  auto dalloc = [&](size_t bytes) {
+    void* p = nullptr;
+    BAYENS_HIP(hipMalloc(&p, bytes));
+    c->ws_allocs.push_back(p);
+    return p;
+  };
+  FitWorkspace& w = c->ws;
+  w.nb = nb; w.Np = Np;
+  const size_t msz = (size_t)nb * Np * Np * sizeof(double);
+  auto mat = [&]() { return Mat{(double*)dalloc(msz), Np, (long)Np * Np}; };
+  w.K0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T1 = mat(); w.T2 = mat();
+  const size_t isz = (size_t)nb * Np * LEAF * sizeof(double);
+  w.invL = (double*)dalloc(isz); w.invC = (double*)dalloc(isz);
+  const size_t vsz = (size_t)nb * Np * sizeof(double);
+  w.theta1 = (double*)dalloc(vsz); w.mvec = (double*)dalloc(vsz); w.avec = (double*)dalloc(vsz);
+  w.y = (double*)dalloc(vsz); w.nu = (double*)dalloc(vsz); w.muvec = (double*)dalloc(vsz);
+  w.ustate = (double*)dalloc((size_t)nb * 8 * sizeof(double));
+  w.info = (int*)dalloc((size_t)nb * sizeof(int));
+}
+
+// a workspace view for a batch smaller than the allocated one
+FitWorkspace ws_view(bayens_ctx* c, int nb) {
+  FitWorkspace v = c->ws;
+  v.nb = nb;
+  return v;
+}
+
+// host staging helpers ------------------------------------------------------------------------
+struct Stage {
+  bayens_ctx* c;
+  int loc;
+  std::vector<void*> owned;
+  struct Out { void* host; void* dev; size_t bytes; };
+  std::vector<Out> outs;
+  Stage(bayens_ctx* c_, int loc_) : c(c_), loc(loc_) {}
+  ~Stage() { for (void* p : owned) (void)hipFree(p); }
+  template <typename T>
+  const T* in(const T* p, size_t count) {
+    if (!p || loc == BAYENS_DEVICE) return p;
+    void* d = nullptr;
+    BAYENS_HIP(hipMalloc(&d, count * sizeof(T)));
+    owned.push_back(d);
+    BAYENS_HIP(hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return (const T*)d;
+  }
+  template <typename T>
+  T* out(T* p, size_t count) {
+    if (!p || loc == BAYENS_DEVICE) return p;
+    void* d = nullptr;
+    BAYENS_HIP(hipMalloc(&d, count * sizeof(T)));
+    owned.push_back(d);
+    outs.push_back(Out{p, d, count * sizeof(T)});
+    return (T*)d;
+  }
+  template <typename T>
+  T* scratch(size_t count) {
+    void* d = nullptr;
+    BAYENS_HIP(hipMalloc(&d, count * sizeof(T)));
+    owned.push_back(d);
+    return (T*)d;
+  }
+  void finish() {
+    for (auto& o : outs) BAYENS_HIP(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* bayens_version(void) { return "bayens 0.1 (gfx950, fp64 MFMA)"; }
+
+int bayens_ctx_create(int device, bayens_ctx** out) {
+  if (!out) return BAYENS_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return BAYENS_E_NOGPU;
+  if (device < 0 || device >= ndev) return BAYENS_E_ARG;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return (int)e;
+  bayens_ctx* c = new bayens_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  (void)hipEventCreate(&c->t0);
+  (void)hipEventCreate(&c->t1);
+  c->prims = new HipPrims(c->stream);
+  *out = c;
+  return 0;
+}
+
+int bayens_ctx_destroy(bayens_ctx* c) {
+  if (!c) return BAYENS_E_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm && c->rccl.CommDestroy) c->rccl.CommDestroy(c->comm);
+  free_ws(c);
+  delete c->prims;
+  if (c->t0) (void)hipEventDestroy(c->t0);
+  if (c->t1) (void)hipEventDestroy(c->t1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+const char* bayens_last_error(bayens_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bayens_device_info(bayens_ctx* c, char* name, int name_len, int* cus, size_t* hbm) {
+  return guarded(c, [&]() {
+    hipDeviceProp_t p;
+    BAYENS_HIP(hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+    if (cus) *cus = p.multiProcessorCount;
+    if (hbm) *hbm = p.totalGlobalMem;
+    return 0;
+  });
+}
+
+int bayens_malloc(bayens_ctx* c, size_t bytes, void** dptr) {
+  return guarded(c, [&]() { BAYENS_HIP(hipMalloc(dptr, bytes)); return 0; });
+}
+int bayens_free(bayens_ctx* c, void* dptr) {
+  return guarded(c, [&]() { BAYENS_HIP(hipFree(dptr)); return 0; });
+}
+int bayens_memcpy_h2d(bayens_ctx* c, void* dst, const void* src, size_t bytes) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  });
+}
+int bayens_memcpy_d2h(bayens_ctx* c, void* dst, const void* src, size_t bytes) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  });
+}
+int bayens_sync(bayens_ctx* c) {
+  return guarded(c, [&]() { BAYENS_HIP(hipStreamSynchronize(c->stream)); return 0; });
+}
+int bayens_timer_start(bayens_ctx* c) {
+  return guarded(c, [&]() { BAYENS_HIP(hipEventRecord(c->t0, c->stream)); return 0; });
+}
+int bayens_timer_stop(bayens_ctx* c, double* ms) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+    BAYENS_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    BAYENS_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    if (ms) *ms = f;
+    return 0;
+  });
+}
+int bayens_profile_enable(bayens_ctx* c, int on) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    KernelProfile& p = c->prims->prof;
+    for (auto& e : p.events) { p.pool.push_back(e.first); p.pool.push_back(e.second); }
+    p.events.clear();
+    p.flop = 0; p.launches = 0;
+    p.enabled = on != 0;
+    return 0;
+  });
+}
+int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long* launches) {
+  return guarded(c, [&]() {
+    if (family != 0) return fail(c, BAYENS_E_ARG, "unknown kernel family");
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    KernelProfile& p = c->prims->prof;
+    double tot = 0;
+    for (auto& e : p.events) {
+      float f = 0;
+      BAYENS_HIP(hipEventElapsedTime(&f, e.first, e.second));
+      tot += f;
+    }
+    if (ms) *ms = tot;
+    if (flop) *flop = p.flop;
+    if (launches) *launches = p.launches;
+    return 0;
+  });
+}
+
+int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
+                        const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
+                        double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
+                        double* loss_trace, int* info) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
+    if (loss_trace) return fail(c, BAYENS_E_ARG, "gp_fit_batch: loss_trace is not produced by this version (pass NULL)");
+    const int Np = pad_to_leaf(N);
+    if ((size_t)2 * Np * sizeof(double) > 128 * 1024) return fail(c, BAYENS_E_ARG, "gp_fit_batch: N too large");
+    ensure_ws(c, B, Np);
+    Stage st(c, loc);
+    const double* dX = st.in(X, (size_t)B * N * R);
+    const double* dy = st.in(y_mean, (size_t)B * N);
+    const double* dnu = st.in(y_var, (size_t)B * N);
+    double* dmu = st.out(mu, (size_t)B * N);
+    double* dcov = st.out(cov, (size_t)B * N * N);
+    double* dchol = st.out(cov_chol, (size_t)B * N * N);
+    double* dld = st.out(logdet, (size_t)B);
+    double* dhyp = st.out(hyp, (size_t)B * 2);
+    FitWorkspace w = ws_view(c, B);
+    FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+    gp_fit(*c->prims, w, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp);
+    std::vector<int> hinfo(B, 0);
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), w.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
+    return 0;
+  });
+}
+
+int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* cov, double* chol, double* logdet,
+                            int* info) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || !cov) return fail(c, BAYENS_E_ARG, "mvn_factor_batch: bad argument");
+    const int Np = pad_to_leaf(N);
+    ensure_ws(c, B, Np);
+    Stage st(c, loc);
+    const double* dcov = st.in(cov, (size_t)B * N * N);
+    double* dchol = st.out(chol, (size_t)B * N * N);
+    double* dld = st.out(logdet, (size_t)B);
+    FitWorkspace w = ws_view(c, B);
+    BAYENS_HIP(hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), c->stream));
+    c->prims->pad_in(B, N, Np, dcov, w.T1);
+    mvn_factor(*c->prims, w, N, dchol, dld);
+    std::vector<int> hinfo(B, 0);
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), w.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, "mvn_factor_batch: covariance not positive definite (see info[])");
+    return 0;
+  });
+}
+
+int bayens_extract_diag(bayens_ctx* c, int loc, int B, int N, const double* cov, double* var) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || !cov || !var) return fail(c, BAYENS_E_ARG, "extract_diag: bad argument");
+    Stage st(c, loc);
+    const double* dcov = st.in(cov, (size_t)B * N * N);
+    double* dvar = st.out(var, (size_t)B * N);
+    c->prims->extract_diag(B, N, dcov, dvar);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* mu, const double* cov_chol,
+                       const double* logdet, const double* obs, double* ll_mean) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R_obs <= 0 || !mu || !cov_chol || !logdet || !obs || !ll_mean)
+      return fail(c, BAYENS_E_ARG, "loglik_rows: bad argument");
+    Stage st(c, loc);
+    const double* dmu = st.in(mu, (size_t)B * N);
+    const double* dch = st.in(cov_chol, (size_t)B * N * N);
+    const double* dld = st.in(logdet, (size_t)B);
+    const double* dobs = st.in(obs, (size_t)R_obs * N);
+    double* dll = st.out(ll_mean, (size_t)B * N);
+    double* ac = st.scratch<double>((size_t)B * 2 * N);
+    c->prims->loglik_rows(B, N, R_obs, dmu, dch, dld, dobs, dll, ac);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_normal_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* mu,
+                              const double* scale, const double* obs, double* ll_mean) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R_obs <= 0 || !mu || !scale || !obs || !ll_mean)
+      return fail(c, BAYENS_E_ARG, "normal_loglik_rows: bad argument");
+    Stage st(c, loc);
+    const double* dmu = st.in(mu, (size_t)B * N);
+    const double* dsc = st.in(scale, (size_t)B * N);
+    const double* dobs = st.in(obs, (size_t)R_obs * N);
+    double* dll = st.out(ll_mean, (size_t)B * N);
+    c->prims->normal_loglik_rows(B, N, R_obs, dmu, dsc, dobs, dll);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_weights_normalise(bayens_ctx* c, int loc, int M, int P, const double* ll_mean, double c_std, int scheme,
+                             double* w, double* w_raw) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || !ll_mean || !w) return fail(c, BAYENS_E_ARG, "weights_normalise: bad argument");
+    if (scheme != 0) return fail(c, BAYENS_E_ARG, "weights_normalise: only scheme 0 (exp) runs on the device");
+    Stage st(c, loc);
+    const double* dll = st.in(ll_mean, (size_t)M * P);
+    double* dw = st.out(w, (size_t)M * P);
+    double* draw = st.out(w_raw, (size_t)M * P);
+    c->prims->weights_normalise(M, P, dll, c_std, dw, draw);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_w2_temporal(bayens_ctx* c, int loc, int M, int P, const double* mean, const double* var, double* w) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || !mean || !var || !w) return fail(c, BAYENS_E_ARG, "w2_temporal: bad argument");
+    Stage st(c, loc);
+    const double* dm = st.in(mean, (size_t)M * P);
+    const double* dv = st.in(var, (size_t)M * P);
+    double* dw = st.out(w, (size_t)M * P);
+    c->prims->w2_temporal(M, P, dm, dv, dw);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_barycentre(bayens_ctx* c, int loc, int M, int P, const double* w, const double* mean, const double* var,
+                      double tol, double init_var, double* mu_out, double* var_out, int* n_not_converged) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || !w || !mean || !var || !mu_out || !var_out)
+      return fail(c, BAYENS_E_ARG, "barycentre: bad argument");
+    Stage st(c, loc);
+    const double* dw = st.in(w, (size_t)M * P);
+    const double* dm = st.in(mean, (size_t)M * P);
+    const double* dv = st.in(var, (size_t)M * P);
+    double* dmu = st.out(mu_out, (size_t)P);
+    double* dvar = st.out(var_out, (size_t)P);
+    int* dbad = st.scratch<int>(1);
+    c->prims->barycentre(M, P, dw, dm, dv, tol, init_var, dmu, dvar, dbad);
+    int hbad = 0;
+    BAYENS_HIP(hipMemcpyAsync(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    if (n_not_converged) *n_not_converged = hbad;
+    return 0;
+  });
+}
+
+int bayens_weighted_model_mean(bayens_ctx* c, int loc, int M, int R_max, const int* R, int P, const double* data,
+                               const double* w, double* mu_out, double* var_out) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || R_max <= 0 || !R || !data || !w || !mu_out || !var_out)
+      return fail(c, BAYENS_E_ARG, "weighted_model_mean: bad argument");
+    Stage st(c, loc);
+    const int* dR = st.in(R, (size_t)M);
+    const double* dd = st.in(data, (size_t)M * R_max * P);
+    const double* dw = st.in(w, (size_t)M * P);
+    double* dmu = st.out(mu_out, (size_t)P);
+    double* dvar = st.out(var_out, (size_t)P);
+    c->prims->weighted_model_mean(M, R_max, dR, P, dd, dw, dmu, dvar);
+    st.finish();
+    return 0;
+  });
+}
+
+// ---- RCCL ---------------------------------------------------------------------------------------
+int bayens_comm_unique_id(bayens_ctx* c, void* id128) {
+  return guarded(c, [&]() {
+    if (!id128) return fail(c, BAYENS_E_ARG, "comm_unique_id: null buffer");
+    std::string err;
+    if (!c->rccl.load(err)) return fail(c, BAYENS_E_COMM, err);
+    ncclUniqueId id;
+    ncclResult_t r = c->rccl.GetUniqueId(&id);
+    if (r != 0) return fail(c, BAYENS_E_COMM, "ncclGetUniqueId failed");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+  });
+}
+
+int bayens_comm_init(bayens_ctx* c, int rank, int nranks, const void* id128) {
+  return guarded(c, [&]() {
+    if (!id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(c, BAYENS_E_ARG, "comm_init: bad argument");
+    std::string err;
+    if (!c->rccl.load(err)) return fail(c, BAYENS_E_COMM, err);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = c->rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0) {
+      c->comm = nullptr;
+      return fail(c, BAYENS_E_COMM, std::string("ncclCommInitRank: ") +
+                                        (c->rccl.GetErrorString ? c->rccl.GetErrorString(r) : "error"));
+    }
+    c->rank = rank; c->nranks = nranks;
+    return 0;
+  });
+}
+
+int bayens_comm_destroy(bayens_ctx* c) {
+  return guarded(c, [&]() {
+    if (c->comm) { c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    return 0;
+  });
+}
+
+int bayens_allgather_rows(bayens_ctx* c, const double* local_dev, double* all_dev, int M_loc, int P) {
+  return guarded(c, [&]() {
+    if (!c->comm) return fail(c, BAYENS_E_COMM, "allgather_rows: communicator not initialised");
+    if (!local_dev || !all_dev || M_loc <= 0 || P <= 0) return fail(c, BAYENS_E_ARG, "allgather_rows: bad argument");
+    ncclResult_t r = c->rccl.AllGather(local_dev, all_dev, (size_t)M_loc * P, NCCL_FLOAT64, c->comm, c->stream);
+    if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllGather failed");
+    return 0;
+  });
+}
+
+// ---- diagnostics for the GPU unit tests ----------------------------------------------------------
+int bayens_test_gemm(bayens_ctx* c, int nb, int m, int n, int k, double alpha, const double* A, int lda,
+                     const double* B, int ldb, double beta, double* C, int ldc, int flags, double diag_add) {
+  return guarded(c, [&]() {
+    const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
+    const size_t an = (size_t)(ta ? k : m) * lda, bn = (size_t)(tb ? n : k) * ldb, cn = (size_t)m * ldc;
+    Stage st(c, BAYENS_HOST);
+    const double* dA = st.in(A, an * nb);
+    const double* dB = st.in(B, bn * nb);
+    double* dC = st.scratch<double>(cn * nb);
+    BAYENS_HIP(hipMemcpyAsync(dC, C, cn * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->prims->gemm(nb, m, n, k, alpha, Mat{const_cast<double*>(dA), lda, (long)an},
+                   Mat{const_cast<double*>(dB), ldb, (long)bn}, beta, Mat{dC, ldc, (long)cn}, flags, diag_add);
+    BAYENS_HIP(hipMemcpyAsync(C, dC, cn * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_test_potrf(bayens_ctx* c, int nb, int n, double* A, int* info) {
+  return guarded(c, [&]() {
+    if (n % LEAF) return fail(c, BAYENS_E_ARG, "test_potrf: n must be a multiple of 64");
+    Stage st(c, BAYENS_HOST);
+    const size_t an = (size_t)nb * n * n;
+    double* dA = st.scratch<double>(an);
+    double* dT = st.scratch<double>(an);
+    double* inv = st.scratch<double>((size_t)nb * n * LEAF);
+    int* dinfo = st.scratch<int>(nb);
+    BAYENS_HIP(hipMemcpyAsync(dA, A, an * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipMemsetAsync(dinfo, 0, nb * sizeof(int), c->stream));
+    Mat Am{dA, n, (long)n * n}, Tm{dT, n, (long)n * n};
+    c->prims->tri_copy(nb, n, Am, Tm);
+    potrf(*c->prims, nb, n, Tm, inv, (long)n * LEAF, dinfo);
+    BAYENS_HIP(hipMemcpyAsync(A, dT, an * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipMemcpyAsync(info, dinfo, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_test_trsm(bayens_ctx* c, int nb, int m, int n, const double* L, double* Bm, int mode) {
+  return guarded(c, [&]() {
+    if ((n % LEAF) || (m % LEAF)) return fail(c, BAYENS_E_ARG, "test_trsm: m, n must be multiples of 64");
+    // The solves need the inverted diagonal blocks: refactor L L^T (cheap at test sizes) to obtain them.
+    Stage st(c, BAYENS_HOST);
+    const size_t ln = (size_t)nb * n * n, bn = (size_t)nb * m * n;
+    const double* dL = st.in(L, ln);
+    double* dA = st.scratch<double>(ln);
+    double* dB = st.scratch<double>(bn);
+    double* inv = st.scratch<double>((size_t)nb * n * LEAF);
+    int* dinfo = st.scratch<int>(nb);
+    BAYENS_HIP(hipMemsetAsync(dinfo, 0, nb * sizeof(int), c->stream));
+    BAYENS_HIP(hipMemcpyAsync(dB, Bm, bn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    Mat Lm{const_cast<double*>(dL), n, (long)n * n}, Am{dA, n, (long)n * n}, Bv{dB, n, (long)m * n};
+    c->prims->gemm(nb, n, n, n, 1.0, Lm, Lm, 0.0, Am, GEMM_TB | GEMM_TRI_OUT, 0.0);   // A = L L^T (lower blocks)
+    c->prims->tri_copy(nb, n, Am, Am);
+    potrf(*c->prims, nb, n, Am, inv, (long)n * LEAF, dinfo);
+    if (mode == 0) trsm_rlt(*c->prims, nb, m, n, Am, inv, (long)n * LEAF, Bv);
+    else trsm_rln(*c->prims, nb, m, n, Am, inv, (long)n * LEAF, Bv, mode == 2);
+    BAYENS_HIP(hipMemcpyAsync(Bm, dB, bn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    return 0;
+  });
+}
+
+}  // extern "C"

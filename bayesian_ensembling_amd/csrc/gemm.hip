@@ -1,0 +1,224 @@
+// gemm.hip - batched fp64 GEMM on the gfx950 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// This is the one heavy primitive of the GP fit: the blocked Cholesky factorisations, the triangular
+// solves and the symmetric rank-N updates of SURVEY.md Appendix A are all sequenced (driver.cpp) as calls
+// of this kernel, so its rate bounds the fit (compute-bound on the fp64 matrix pipe).
+//
+// Tiling (CDNA4: 64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
+//   workgroup = 256 threads = 4 waves, output tile 128 x 128, each wave a 64 x 64 sub-tile
+//   = 4 x 4 MFMA tiles of 16 x 16 (16 accumulators x 4 f64 = 128 VGPR);
+//   K is consumed in steps of 16: both operand tiles are staged through LDS in a k-major image
+//   [16][128+2] (the +2 double pad keeps the transposing ds_write at 2-way conflicts), double-buffered,
+//   with the global loads of step s+1 in flight while step s runs 64 MFMAs per wave;
+//   66.6 KB LDS and <=256 VGPR per workgroup => two workgroups per CU.
+//   All dimensions are multiples of 64; waves whose 64 x 64 sub-tile lies outside the matrix (or, with
+//   GEMM_TRI_OUT, strictly above the block diagonal) skip their MFMAs and stores (wave-uniform).
+//   Block ids are dealt so that each XCD (own L2) walks a contiguous range of tiles of few members.
+#include "hip_prims.h"
+
+namespace bayens {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 2;
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  long sA, sB, sC;
+  int lda, ldb, ldc;
+  int m, n, k;
+  double alpha, beta, diag_add;
+  int flags;
+  int tiles_m, tiles_n, total;
+};
+
+// Stage one 128 x 16 operand tile into registers.  TR=true: memory is [row][k] (k contiguous) -> each
+// thread takes 4 x (2 consecutive k) of rows r, r+32, r+64, r+96; TR=false: memory is [k][row] -> each
+// thread takes 4 x (2 consecutive rows) of k-rows kr, kr+4, kr+8, kr+12.
+template <bool TR>
+__device__ __forceinline__ void stage_load(const double* base, int ld, int row0, int nrows,
+                                           int k0, int tid, v2d (&reg)[4]) {
+  if (TR) {
+    const int kp = tid & 7, r = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int rr = row0 + r + 32 * p;
+      rr = rr < nrows ? rr : nrows - 1;
+      reg[p] = *reinterpret_cast<const v2d*>(base + (long)rr * ld + k0 + 2 * kp);
+    }
+  } else {
+    const int c2 = tid & 63, kr = tid >> 6;
+    int cc = row0 + 2 * c2;
+    cc = cc < nrows - 1 ? cc : nrows - 2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      reg[p] = *reinterpret_cast<const v2d*>(base + (long)(k0 + kr + 4 * p) * ld + cc);
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ void stage_store(double (*tile)[LDT], int tid, const v2d (&reg)[4]) {
+  if (TR) {
+    const int kp = tid & 7, r = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      tile[2 * kp][r + 32 * p] = reg[p].x;
+      tile[2 * kp + 1][r + 32 * p] = reg[p].y;
+    }
+  } else {
+    const int c2 = tid & 63, kr = tid >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<v2d*>(&tile[kr + 4 * p][2 * c2]) = reg[p];
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[2][BK][LDT];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK][LDT];
+
+  // XCD-aware dealing: consecutive hardware block ids go round-robin over the 8 XCDs; give every XCD a
+  // contiguous chunk of the (member, tile) space so that its L2 sees few members' panels.
+  int bid = blockIdx.x;
+  if ((g.total & 7) == 0) bid = (bid & 7) * (g.total >> 3) + (bid >> 3);
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int batch = bid / tiles;
+  const int t = bid - batch * tiles;
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+  if ((g.flags & GEMM_TRI_OUT) && col0 > row0) return;   // whole tile above the block diagonal
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const double* A = g.A + batch * g.sA;
+  const double* B = g.B + batch * g.sB;
+  double* C = g.C + batch * g.sC;
+
+  bool active = (row0 + wm * 64 < g.m) && (col0 + wn * 64 < g.n);
+  if ((g.flags & GEMM_TRI_OUT) && (col0 + wn * 64 > row0 + wm * 64)) active = false;
+
+  int kbeg = 0;
+  if (g.flags & GEMM_KTRIM_TN_LOWER) kbeg = row0 > col0 ? row0 : col0;
+  const int nk = (g.k - kbeg) / BK;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  v2d ra[4], rb[4];
+  if (nk > 0) {
+    stage_load<!TA>(A, g.lda, row0, g.m, kbeg, tid, ra);
+    stage_load<TB>(B, g.ldb, col0, g.n, kbeg, tid, rb);
+    stage_store<!TA>(As[0], tid, ra);
+    stage_store<TB>(Bs[0], tid, rb);
+  }
+  __syncthreads();
+
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) {
+      stage_load<!TA>(A, g.lda, row0, g.m, kbeg + (s + 1) * BK, tid, ra);
+      stage_load<TB>(B, g.ldb, col0, g.n, kbeg + (s + 1) * BK, tid, rb);
+    }
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = As[buf][kk * 4 + lk][wm * 64 + i * 16 + lr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kk * 4 + lk][wn * 64 + j * 16 + lr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nk) {
+      stage_store<!TA>(As[buf ^ 1], tid, ra);
+      stage_store<TB>(Bs[buf ^ 1], tid, rb);
+    }
+    __syncthreads();
+  }
+
+  if (!active) return;
+  // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile
+  const bool phi = g.flags & GEMM_EPI_PHI;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + wn * 64 + j * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wm * 64 + i * 16 + lk + 4 * r;
+        double* cp = C + (long)row * g.ldc + col;
+        double v = g.alpha * acc[i][j][r];
+        if (g.beta != 0.0) v += g.beta * (*cp);
+        if (row == col) v += g.diag_add;
+        if (phi) v = row < col ? 0.0 : (row == col ? 0.5 * v : v);
+        *cp = v;
+      }
+    }
+}
+
+double algorithmic_flop(int nb, int m, int n, int k, int flags) {
+  double f = 2.0 * m * (double)n * k * nb;
+  if ((flags & GEMM_TRI_OUT) && (flags & GEMM_KTRIM_TN_LOWER)) return f / 6.0;
+  if (flags & GEMM_TRI_OUT) return f / 2.0;
+  return f;
+}
+
+}  // namespace
+
+void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
+                    double diag_add) {
+  if (nb <= 0 || m <= 0 || n <= 0) return;
+  GemmArgs g;
+  g.A = A.p; g.B = B.p; g.C = C.p;
+  g.sA = A.stride; g.sB = B.stride; g.sC = C.stride;
+  g.lda = A.ld; g.ldb = B.ld; g.ldc = C.ld;
+  g.m = m; g.n = n; g.k = k;
+  g.alpha = alpha; g.beta = beta; g.diag_add = diag_add;
+  g.flags = flags;
+  g.tiles_m = (m + BM - 1) / BM;
+  g.tiles_n = (n + BN - 1) / BN;
+  g.total = g.tiles_m * g.tiles_n * nb;
+  if ((m % 64) || (n % 64) || (k % 64) || (A.ld & 1) || (B.ld & 1))
+    throw HipError{-1, "gemm: dimensions must be multiples of 64 and leading dimensions even"};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof.enabled) {
+    auto take = [&]() {
+      hipEvent_t e;
+      if (!prof.pool.empty()) { e = prof.pool.back(); prof.pool.pop_back(); }
+      else BAYENS_HIP(hipEventCreate(&e));
+      return e;
+    };
+    e0 = take(); e1 = take();
+    BAYENS_HIP(hipEventRecord(e0, stream));
+  }
+  const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
+  dim3 grid(g.total), block(256);
+  if (!ta && tb) hipLaunchKernelGGL((gemm_f64_mfma<false, true>), grid, block, 0, stream, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_mfma<true, false>), grid, block, 0, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_mfma<false, false>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f64_mfma<true, true>), grid, block, 0, stream, g);
+  BAYENS_HIP(hipGetLastError());
+  if (prof.enabled) {
+    BAYENS_HIP(hipEventRecord(e1, stream));
+    prof.events.emplace_back(e0, e1);
+    prof.flop += algorithmic_flop(nb, m, n, k, flags);
+    prof.launches += 1;
+  }
+}
+
+}  // namespace bayens

@@ -1,0 +1,89 @@
+// hip_prims.h - the gfx950 implementation of the primitive interface (kernels in gemm.hip / kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "prims.h"
+
+namespace bayens {
+
+struct HipError {
+  int code;
+  std::string what;
+};
+
+#define BAYENS_HIP(expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      throw ::bayens::HipError{(int)e__, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
+  } while (0)
+
+struct KernelProfile {
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // per GEMM launch
+  std::vector<hipEvent_t> pool;
+  double flop = 0;
+  long launches = 0;
+};
+
+struct HipPrims : Prims {
+  hipStream_t stream = nullptr;
+  KernelProfile prof;
+  // scratch owned by the primitives (scaled inputs for the kernel matrix, gradient partial sums)
+  double* xs = nullptr;       // [nb][Np][R4]
+  double* ssq = nullptr;      // [nb][Np]
+  double* gpart = nullptr;    // [nb][tiles][2]
+  size_t xs_cap = 0, ssq_cap = 0, gpart_cap = 0;
+
+  explicit HipPrims(hipStream_t s) : stream(s) {}
+  ~HipPrims() override;
+  void ensure_scratch(int nb, int Np, int R4);
+
+  void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
+            double diag_add) override;
+  void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
+  void copy(int nb, int n, Mat src, Mat dst) override;
+  void tri_copy(int nb, int n, Mat src, Mat dst) override;
+  void transpose_lower(int nb, int n, Mat W, Mat Wt) override;
+  void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
+                  const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) override;
+  void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
+            Mat K0, Mat Lb) override;
+  void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
+  void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
+                    double* theta1) override;
+  void trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1,
+             double* mvec) override;
+  void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
+  void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override;
+  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
+                 double lr) override;
+  void gemv_n(int nb, int n, Mat A, const double* x, double* y) override;
+  void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) override;
+  void extract(int nb, int N, Mat src, double* dst, int mode) override;
+  void extract_vec(int nb, int N, int Np, const double* src, double* dst) override;
+  void logdet(int nb, int N, Mat Lc, double* out) override;
+  void hyp_out(int nb, const double* ustate, double* hyp) override;
+
+  // not part of the driver interface: pad a compact [nb][N][N] matrix into a padded Mat (identity pad)
+  void pad_in(int nb, int N, int Np, const double* src, Mat dst);
+
+  // weights / weighted-posterior kernels (compact layouts, see include/bayens.h)
+  void loglik_rows(int B, int N, int R_obs, const double* mu, const double* chol, const double* logdet,
+                   const double* obs, double* ll_mean, double* scratch_ac /*[B][2][N]*/);
+  void normal_loglik_rows(int B, int N, int R_obs, const double* mu, const double* scale,
+                          const double* obs, double* ll_mean);
+  void weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw);
+  void w2_temporal(int M, int P, const double* mean, const double* var, double* w);
+  void barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,
+                  double init_var, double* mu_out, double* var_out, int* n_bad);
+  void weighted_model_mean(int M, int R_max, const int* R, int P, const double* data, const double* w,
+                           double* mu_out, double* var_out);
+  void extract_diag(int B, int N, const double* cov, double* var);
+};
+
+}  // namespace bayens

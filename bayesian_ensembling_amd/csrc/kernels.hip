@@ -1,0 +1,836 @@
+// kernels.hip - every device kernel of the hot path except the batched GEMM (gemm.hip).
+//
+// Reference arithmetic (file:line into /root/reference/ensembles) is cited at each kernel; formulas are
+// written out in SURVEY.md Appendix A.  These kernels are O(N^2) per member and HBM/latency-bound: they
+// are laid out for coalesced 512-byte wave accesses along the contiguous (column / time) axis.
+#include <cmath>
+
+#include "hip_prims.h"
+
+namespace bayens {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr double SQRT3 = 1.7320508075688772;
+constexpr double SQRT5 = 2.23606797749979;
+constexpr double LOG2PI = 1.8378770664093453;
+
+__device__ __forceinline__ double softplus_d(double u) { return u > 30.0 ? u : log1p(exp(u)); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;   // valid in lane 0
+}
+
+// K(r2) and dK/dlengthscale for the three stationary kernels (GPflow 2.1.5 forms; Matern-3/2 is the only
+// one the reference instantiates, models.py:186).
+__device__ __forceinline__ void kern_eval(int kernel, double var, double ls, double r2, double& K, double& dK) {
+  if (kernel == 2) {
+    double r2c = r2 > 0.0 ? r2 : 0.0;
+    K = var * exp(-0.5 * r2c);
+    dK = K * r2c / ls;
+    return;
+  }
+  const bool clamp = r2 <= 1e-36;
+  const double r = sqrt(r2 > 1e-36 ? r2 : 1e-36);
+  if (kernel == 0) {
+    double e = exp(-SQRT3 * r);
+    K = var * (1.0 + SQRT3 * r) * e;
+    dK = 3.0 * var * r * r * e / ls;
+  } else {
+    double e = exp(-SQRT5 * r);
+    K = var * (1.0 + SQRT5 * r + (5.0 / 3.0) * r * r) * e;
+    dK = (5.0 / 3.0) * var * r * r * (1.0 + SQRT5 * r) * e / ls;
+  }
+  if (clamp) dK = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise / layout kernels (2-D grid of 64x64 tiles, batch in z)
+// ------------------------------------------------------------------------------------------------
+__global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
+  // mode 0 full copy, 1 tril copy (zeros above)
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = src.p + b * src.stride;
+  double* d = dst.p + b * dst.stride;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    double v = (mode == 1 && j > i) ? 0.0 : s[(long)i * src.ld + j];
+    d[(long)i * dst.ld + j] = v;
+  }
+}
+
+__global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
+  __shared__ double tile[64][65];
+  const int b = blockIdx.z;
+  const int bi = blockIdx.y, bj = blockIdx.x;   // output tile (bi, bj) = input tile (bj, bi)^T
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const double* w = W.p + b * W.stride;
+  double* wt = Wt.p + b * Wt.stride;
+  if (bj < bi) {   // strictly below the diagonal of the output: zeros
+    for (int q = 0; q < 16; ++q) wt[(long)(bi * 64 + r0 + 4 * q) * Wt.ld + bj * 64 + c] = 0.0;
+    return;
+  }
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    const int gi = bj * 64 + r, gj = bi * 64 + c;   // input element (gi, gj), lower part only
+    tile[r][c] = gj <= gi ? w[(long)gi * W.ld + gj] : 0.0;
+  }
+  __syncthreads();
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    wt[(long)(bi * 64 + r) * Wt.ld + bj * 64 + c] = tile[c][r];
+  }
+}
+
+__global__ void fill_identity_kernel(int n, Mat A) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  double* a = A.p + b * A.stride;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    a[(long)i * A.ld + j] = i == j ? 1.0 : 0.0;
+  }
+}
+
+__global__ void init_vec_kernel(int nb, int N, int Np, double* theta1, double* mvec, double* ustate,
+                                const double* y_in, const double* nu_in, double* y_pad, double* nu_pad,
+                                int* info) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Np) {
+    theta1[(long)b * Np + i] = 0.0;
+    mvec[(long)b * Np + i] = 0.0;
+    y_pad[(long)b * Np + i] = i < N ? y_in[(long)b * N + i] : 0.0;
+    nu_pad[(long)b * Np + i] = i < N ? nu_in[(long)b * N + i] : 1.0;
+  }
+  if (i < 8) ustate[b * 8 + i] = i < 2 ? 0.5413248546129181 /* log(e-1): softplus -> 1.0 */ : 0.0;
+  if (i == 0) info[b] = 0;
+}
+
+__global__ void scale_rows_kernel(int n, Mat src, const double* nu, Mat dst) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = src.p + b * src.stride;
+  double* d = dst.p + b * dst.stride;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    d[(long)i * dst.ld + j] = s[(long)i * src.ld + j] * (1.0 / sqrt(nu[(long)b * n + i]));
+  }
+}
+
+__global__ void form_lbar_kernel(int n, Mat X, const double* a, const double* mvec, const double* nu) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  double* x = X.p + b * X.stride;
+  const double mj = mvec[(long)b * n + j];
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    double* p = x + (long)i * X.ld + j;
+    *p = j <= i ? (a[(long)b * n + i] * mj + *p) / nu[(long)b * n + i] : 0.0;
+  }
+}
+
+__global__ void cov_init_kernel(int n, Mat K0, const double* nu, Mat dst) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = K0.p + b * K0.stride;
+  double* d = dst.p + b * dst.stride;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    d[(long)i * dst.ld + j] = s[(long)i * K0.ld + j] + (i == j ? nu[(long)b * n + i] : 0.0);
+  }
+}
+
+__global__ void extract_kernel(int N, Mat src, double* dst, int mode) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = src.p + b * src.stride;
+  double* d = dst + (long)b * N * N;
+  if (j >= N) return;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    if (i >= N) break;
+    double v;
+    if (mode == 0) v = s[(long)i * src.ld + j];
+    else if (mode == 1) v = j <= i ? s[(long)i * src.ld + j] : s[(long)j * src.ld + i];
+    else v = j <= i ? s[(long)i * src.ld + j] : 0.0;
+    d[(long)i * N + j] = v;
+  }
+}
+
+__global__ void pad_in_kernel(int N, int Np, const double* src, Mat dst) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = src + (long)b * N * N;
+  double* d = dst.p + b * dst.stride;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    double v = (i < N && j < N) ? s[(long)i * N + j] : (i == j ? 1.0 : 0.0);
+    d[(long)i * dst.ld + j] = v;
+  }
+}
+
+__global__ void extract_vec_kernel(int N, int Np, const double* src, double* dst) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) dst[(long)b * N + i] = src[(long)b * Np + i];
+}
+
+__global__ void logdet_kernel(int N, Mat Lc, double* out) {
+  __shared__ double part[4];
+  const int b = blockIdx.x;
+  const double* l = Lc.p + b * Lc.stride;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) s += log(l[(long)i * Lc.ld + i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void hyp_out_kernel(int nb, const double* ustate, double* hyp) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) {
+    hyp[b * 2] = softplus_d(ustate[b * 8]);
+    hyp[b * 2 + 1] = softplus_d(ustate[b * 8 + 1]);
+  }
+}
+
+__global__ void extract_diag_kernel(int N, const double* cov, double* var) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) var[(long)b * N + i] = cov[((long)b * N + i) * N + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel matrix (GPflow Matern32.K as used at models.py:186-189,198,217): r2 = -2 X~X~^T + s_i + s_j with
+// the X~X~^T contraction on the fp64 matrix cores; the epilogue (sqrt/exp) runs on the 4 results per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ void xprep_kernel(int N, int Np, int R, int R4, const double* X, const double* ustate,
+                             double* xs, double* ssq) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Np) return;
+  const double ls = softplus_d(ustate[b * 8 + 1]);
+  double s = 0.0;
+  for (int d = 0; d < R4; ++d) {
+    double v = (i < N && d < R) ? X[((long)b * N + i) * R + d] / ls : 0.0;
+    xs[((long)b * Np + i) * R4 + d] = v;
+    s += v * v;
+  }
+  ssq[(long)b * Np + i] = s;
+}
+
+// one workgroup = one 64x64 output tile; wave w owns rows 16w..16w+15, four 16x16 MFMA tiles across.
+// GRAD=false: write K0 and Lb.  GRAD=true: accumulate <Kbt, K0> and <Kbt, dK/dl> over the real part.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
+                                                   const double* ustate, int kernel, double jitter, Mat K0,
+                                                   Mat Lb, Mat Kbt, double* gpart) {
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int i0 = blockIdx.y * 64 + wave * 16, j0 = blockIdx.x * 64;
+  const double var = softplus_d(ustate[b * 8]), ls = softplus_d(ustate[b * 8 + 1]);
+  const double* xb = xs + (long)b * Np * R4;
+  const double* sb = ssq + (long)b * Np;
+  double gv = 0.0, gl = 0.0;
+  for (int jt = 0; jt < 4; ++jt) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < R4; kk += 4) {
+      const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
+      const double bb = xb[(long)(j0 + jt * 16 + lr) * R4 + kk + lk];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    }
+    const int j = j0 + jt * 16 + lr;
+    const double sj = sb[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + lk + 4 * r;
+      const double r2 = (-2.0 * acc[r] + sb[i]) + sj;
+      double K, dK;
+      kern_eval(kernel, var, ls, r2, K, dK);
+      if (GRAD) {
+        if (i < N && j < N) {
+          const double kb = Kbt.p[b * Kbt.stride + (long)i * Kbt.ld + j];
+          gv += kb * K;
+          gl += kb * dK;
+        }
+      } else {
+        if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
+        K0.p[b * K0.stride + (long)i * K0.ld + j] = K;
+        Lb.p[b * Lb.stride + (long)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+      }
+    }
+  }
+  if (GRAD) {
+    __shared__ double red[2][4];
+    gv = wave_sum(gv);
+    gl = wave_sum(gl);
+    if (lane == 0) { red[0][wave] = gv; red[1][wave] = gl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long t = (long)blockIdx.y * gridDim.x + blockIdx.x;
+      const long nt = (long)gridDim.x * gridDim.y;
+      gpart[((long)b * nt + t) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      gpart[((long)b * nt + t) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+  }
+}
+
+// deterministic reduction of the tile partials + TF-2.8 Keras Adam on the two unconstrained hypers
+// (models.py:192,210)
+__global__ void adam_kernel(int ntiles, const double* gpart, double* ustate, double lr) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x;
+  double gv = 0.0, gl = 0.0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+    gv += gpart[((long)b * ntiles + t) * 2];
+    gl += gpart[((long)b * ntiles + t) * 2 + 1];
+  }
+  red[0][threadIdx.x] = gv;
+  red[1][threadIdx.x] = gl;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double* u = ustate + b * 8;
+    const double var = softplus_d(u[0]), ls = softplus_d(u[1]);
+    double g[2];
+    g[0] = (red[0][0] / var) * (1.0 - exp(-var));   // softplus'(u) = 1 - exp(-softplus(u))
+    g[1] = red[1][0] * (1.0 - exp(-ls));
+    const double t = u[6] + 1.0;
+    u[6] = t;
+    const double lr_t = lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t));
+    for (int q = 0; q < 2; ++q) {
+      u[2 + q] = 0.9 * u[2 + q] + 0.1 * g[q];
+      u[4 + q] = 0.999 * u[4 + q] + 0.001 * g[q] * g[q];
+      u[q] -= lr_t * u[2 + q] / (sqrt(u[4 + q]) + 1e-7);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64x64 diagonal block: Cholesky in LDS + inverse of the factor (one workgroup per member)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
+                                                         int* info) {
+  __shared__ double S[64][65];
+  __shared__ double Iv[64][65];
+  __shared__ double part[4][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* a = Ablk.p + b * Ablk.stride;
+  const int c = tid & 63, r0 = tid >> 6;
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    S[r][c] = c <= r ? a[(long)r * Ablk.ld + c] : 0.0;
+  }
+  __syncthreads();
+  // right-looking unblocked factorisation; thread (i = tid/4, kq = tid%4) updates row i, columns k = kq (mod 4)
+  const int ui = tid >> 2, kq = tid & 3;
+  for (int j = 0; j < 64; ++j) {
+    if (tid == 0) {
+      double d = S[j][j];
+      if (!(d > 0.0)) {
+        if (info[b] == 0) info[b] = pivot_base + j + 1;
+        d = 1.0;
+      }
+      S[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    if (tid > j && tid < 64) S[tid][j] /= S[j][j];
+    __syncthreads();
+    if (ui > j) {
+      const double lij = S[ui][j];
+      for (int k = j + 1 + kq; k <= ui; k += 4) S[ui][k] -= lij * S[k][j];
+    }
+    __syncthreads();
+  }
+  // inverse M = L^-1 by rows: M[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] M[k][c]) / L[i][i]
+  // thread (c = tid&63, q = tid>>6) sums k = q (mod 4); the four partials are combined through LDS.
+  for (int q = 0; q < 16; ++q) Iv[r0 + 4 * q][c] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) {
+    double s = 0.0;
+    if (c < i)
+      for (int k = c + r0; k < i; k += 4) s += S[i][k] * Iv[k][c];
+    part[r0][c] = s;
+    __syncthreads();
+    if (r0 == 0 && c <= i) {
+      const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+      Iv[i][c] = ((c == i ? 1.0 : 0.0) - tot) / S[i][i];
+    }
+    __syncthreads();
+  }
+  double* iv = inv + b * inv_stride;
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    a[(long)r * Ablk.ld + c] = S[r][c];     // lower factor, zeros above the diagonal
+    iv[r * 64 + c] = Iv[r][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// matrix-vector kernels
+// ------------------------------------------------------------------------------------------------
+// theta1 = (1-gamma) theta1 + gamma L^T (y/nu): one workgroup per 64 columns; lanes = columns (512-byte
+// coalesced row segments), the 4 waves split the rows i >= j0 (L is lower triangular).
+__global__ __launch_bounds__(256) void theta_update_kernel(int n, Mat L, const double* y, const double* nu,
+                                                           double gamma, double* theta1) {
+  __shared__ double part[4][64];
+  const int b = blockIdx.y, j0 = blockIdx.x * 64;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* l = L.p + b * L.stride;
+  double s = 0.0;
+  for (int i = j0 + w; i < n; i += 4)
+    s += l[(long)i * L.ld + j0 + c] * (y[(long)b * n + i] / nu[(long)b * n + i]);
+  part[w][c] = s;
+  __syncthreads();
+  if (w == 0) {
+    const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    double* t = theta1 + (long)b * n + j0 + c;
+    *t = (1.0 - gamma) * (*t) + gamma * tot;
+  }
+}
+
+// out_i = sum_{k < klim(i)} A_ik x_k - (sub ? sub_i : 0); one wave per row, lanes stride k.
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const double* x, const double* sub,
+                                                        double* out, int lower) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const double* a = A.p + b * A.stride + (long)i * A.ld;
+  const int klim = lower ? i + 1 : n;
+  double s = 0.0;
+  for (int k = lane; k < klim; k += 64) s += a[k] * x[(long)b * n + k];
+  s = wave_sum(s);
+  if (lane == 0) out[(long)b * n + i] = s - (sub ? sub[(long)b * n + i] : 0.0);
+}
+
+// m = C^-T C^-1 theta1 with the inverted 64x64 diagonal blocks of C: one workgroup per member, blocked
+// forward then backward substitution (z and m live in dynamic LDS).
+__global__ __launch_bounds__(256) void trsv2_kernel(int n, Mat C, const double* invC, long inv_stride,
+                                                    const double* theta1, double* mvec) {
+  extern __shared__ double lds[];
+  double* z = lds;            // [n]
+  double* mm = lds + n;       // [n]
+  __shared__ double rblk[64];
+  __shared__ double part[4][64];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* c = C.p + b * C.stride;
+  const double* iv = invC + b * inv_stride;
+  const int nl = n / 64;
+  // forward: C z = theta1
+  for (int jb = 0; jb < nl; ++jb) {
+    const int base = jb * 64;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = base + w * 16 + rr;
+      double s = 0.0;
+      for (int k = lane; k < base; k += 64) s += c[(long)row * C.ld + k] * z[k];
+      s = wave_sum(s);
+      if (lane == 0) rblk[w * 16 + rr] = theta1[(long)b * n + row] - s;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 16; ++rr) {
+      const int rl = w * 16 + rr;
+      double s = iv[(long)jb * 4096 + rl * 64 + lane] * rblk[lane];   // inverse is lower: zeros for lane > rl
+      s = wave_sum(s);
+      if (lane == 0) z[base + rl] = s;
+    }
+    __syncthreads();
+  }
+  // backward: C^T m = z
+  for (int jb = nl - 1; jb >= 0; --jb) {
+    const int base = jb * 64;
+    double s = 0.0;
+    for (int k = base + 64 + w; k < n; k += 4) s += c[(long)k * C.ld + base + lane] * mm[k];
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0) rblk[lane] = z[base + lane] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    __syncthreads();
+    // m_blk = inv^T r : m[cidx] = sum_k inv[k][cidx] r[k]
+    double t = 0.0;
+    for (int k = w; k < 64; k += 4) t += iv[(long)jb * 4096 + k * 64 + lane] * rblk[k];
+    part[w][lane] = t;
+    __syncthreads();
+    if (w == 0) mm[base + lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += 256) mvec[(long)b * n + i] = mm[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LogLikelihoodWeight (weights.py:88-104): the MVN is evaluated at the constant vector x_t * 1_N,
+// log N = -1/2 || x_t a - c ||^2 - logdet - N/2 log 2pi with a = Lc^-1 1, c = Lc^-1 mu.
+// ------------------------------------------------------------------------------------------------
+// forward substitution with the two right-hand sides (1, mu) on a compact [N][N] lower factor, any N;
+// one workgroup per member: 64-row blocks, GEMV part by all 4 waves, the 64x64 diagonal solve by wave 0.
+__global__ __launch_bounds__(256) void trsv_fwd2_kernel(int N, const double* chol, const double* mu, double* ac) {
+  extern __shared__ double lds[];
+  double* xa = lds;            // [Npad]
+  double* xc = lds + ((N + 63) / 64) * 64;
+  __shared__ double D[64][65];
+  __shared__ double ra[64], rc[64];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* l = chol + (long)b * N * N;
+  const int nl = (N + 63) / 64;
+  for (int jb = 0; jb < nl; ++jb) {
+    const int base = jb * 64;
+    const int rows = N - base < 64 ? N - base : 64;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int rl = w * 16 + rr, row = base + rl;
+      double sa = 0.0, sc = 0.0;
+      if (rl < rows) {
+        for (int k = lane; k < base; k += 64) {
+          const double v = l[(long)row * N + k];
+          sa += v * xa[k];
+          sc += v * xc[k];
+        }
+      }
+      sa = wave_sum(sa);
+      sc = wave_sum(sc);
+      if (lane == 0) {
+        ra[rl] = rl < rows ? 1.0 - sa : 0.0;
+        rc[rl] = rl < rows ? mu[(long)b * N + row] - sc : 0.0;
+      }
+      // diagonal block into LDS (identity outside the matrix)
+      {
+        double v = 0.0;
+        if (rl < rows && base + lane < N && lane <= rl) v = l[(long)row * N + base + lane];
+        if (rl >= rows && lane == rl) v = 1.0;
+        D[rl][lane] = v;
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+      double va = ra[lane], vc = rc[lane];
+      for (int k = 0; k < 64; ++k) {
+        const double dk = D[k][k];
+        const double xak = __shfl(va, k, 64) / dk, xck = __shfl(vc, k, 64) / dk;
+        if (lane == k) { va = xak; vc = xck; }
+        else if (lane > k) { const double lv = D[lane][k]; va -= lv * xak; vc -= lv * xck; }
+      }
+      xa[base + lane] = va;
+      xc[base + lane] = vc;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < N; i += 256) {
+    ac[((long)b * 2) * N + i] = xa[i];
+    ac[((long)b * 2 + 1) * N + i] = xc[i];
+  }
+}
+
+constexpr int MAX_ROBS = 4;
+// thread per (member, t): q_r = sum_i (x_rt a_i - c_i)^2 for every observation realisation (chunks of 4)
+__global__ __launch_bounds__(256) void loglik_rows_kernel(int N, int R_obs, const double* ac, const double* logdet,
+                                                          const double* obs, double* ll_mean) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const double* a = ac + ((long)b * 2) * N;
+  const double* c = ac + ((long)b * 2 + 1) * N;
+  const double cst = -logdet[b] - 0.5 * N * LOG2PI;
+  double acc_ll = 0.0;
+  for (int r0 = 0; r0 < R_obs; r0 += MAX_ROBS) {
+    const int nr = R_obs - r0 < MAX_ROBS ? R_obs - r0 : MAX_ROBS;
+    double x[MAX_ROBS], q[MAX_ROBS];
+#pragma unroll
+    for (int r = 0; r < MAX_ROBS; ++r) {
+      x[r] = (r < nr && t < N) ? obs[(long)(r0 + r) * N + t] : 0.0;
+      q[r] = 0.0;
+    }
+    for (int i = 0; i < N; ++i) {
+      const double ai = a[i], ci = c[i];
+#pragma unroll
+      for (int r = 0; r < MAX_ROBS; ++r) {
+        if (r < nr) {
+          const double zz = x[r] * ai - ci;
+          q[r] += zz * zz;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < MAX_ROBS; ++r)
+      if (r < nr) acc_ll += -0.5 * q[r] + cst;
+  }
+  if (t < N) ll_mean[(long)b * N + t] = acc_ll / R_obs;
+}
+
+// dx.Normal branch (weights.py:95-96): elementwise log N(x; mu, scale), mean over realisations
+__global__ void normal_loglik_kernel(int N, int R_obs, const double* mu, const double* scale, const double* obs,
+                                     double* ll_mean) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const double m = mu[(long)b * N + t], s = scale[(long)b * N + t];
+  double acc = 0.0;
+  for (int r = 0; r < R_obs; ++r) {
+    const double z = (obs[(long)r * N + t] - m) / s;
+    acc += -0.5 * z * z - log(s) - 0.5 * LOG2PI;
+  }
+  ll_mean[(long)b * N + t] = acc / R_obs;
+}
+
+// weights.py:107,118-123: w_raw = exp(c ll), w = w_raw / sum_m w_raw; thread per point, coalesced over points
+__global__ void normalise_kernel(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double sum = 0.0;
+  for (int m = 0; m < M; ++m) sum += exp(c_std * ll_mean[(long)m * P + t]);
+  for (int m = 0; m < M; ++m) {
+    const double raw = exp(c_std * ll_mean[(long)m * P + t]);
+    w[(long)m * P + t] = raw / sum;
+    if (w_raw) w_raw[(long)m * P + t] = raw;
+  }
+}
+
+// weights.py:302-325,331 with wasserstein.py:21-47 on 1x1 Normal(mean, scale=variance):
+// D[i,j,t] = |mu_it - mu_jt| + (v_it - v_jt)^2 ; w[i,t] = mean_j D / sum_i mean_j D
+__global__ void w2_temporal_kernel(int M, int P, const double* mean, const double* var, double* w) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double tot = 0.0;
+  for (int i = 0; i < M; ++i) {
+    const double mi = mean[(long)i * P + t], vi = var[(long)i * P + t];
+    double d = 0.0;
+    for (int j = 0; j < M; ++j) {
+      const double dv = vi - var[(long)j * P + t];
+      d += fabs(mi - mean[(long)j * P + t]) + dv * dv;
+    }
+    d /= M;
+    w[(long)i * P + t] = d;
+    tot += d;
+  }
+  for (int i = 0; i < M; ++i) w[(long)i * P + t] /= tot;
+}
+
+// ensemble_scheme.py:52-78 + wasserstein.py:61-100 (signed convergence test, <= 201 sweeps)
+__global__ void barycentre_kernel(int M, int P, const double* w, const double* mean, const double* var,
+                                  double tol, double init_var, double* mu_out, double* var_out, int* n_bad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double v = init_var;
+  int n_iters = 0;
+  while (true) {
+    double cand = 0.0;
+    const double sv = sqrt(v);
+    for (int m = 0; m < M; ++m) cand += w[(long)m * P + t] * sv * sqrt(var[(long)m * P + t]);
+    if (cand - v < tol) { v = cand; break; }
+    v = cand;
+    ++n_iters;
+    if (n_iters > 200) { atomicAdd(n_bad, 1); break; }
+  }
+  double mu = 0.0;
+  for (int m = 0; m < M; ++m) mu += w[(long)m * P + t] * mean[(long)m * P + t];
+  mu_out[t] = mu;
+  const double sig = sqrt(v);
+  var_out[t] = sig * sig;    // Barycentre passes bary_stds ** 2 (ensemble_scheme.py:76)
+}
+
+// ensemble_scheme.py:136-160: mean and (std ** 2) across realisations (ddof = 0), weighted
+__global__ void weighted_model_mean_kernel(int M, int R_max, const int* R, int P, const double* data,
+                                           const double* w, double* mu_out, double* var_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double wm = 0.0, wv = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const int Rm = R[m];
+    const double* d = data + (long)m * R_max * P;
+    double s = 0.0;
+    for (int r = 0; r < Rm; ++r) s += d[(long)r * P + t];
+    const double mean = s / Rm;
+    double q = 0.0;
+    for (int r = 0; r < Rm; ++r) { const double e = d[(long)r * P + t] - mean; q += e * e; }
+    const double sd = sqrt(q / Rm);
+    const double wt = w[(long)m * P + t];
+    wv += (sd * sd) * (wt * wt);
+    wm += mean * wt;
+  }
+  mu_out[t] = wm;
+  var_out[t] = wv;
+}
+
+inline dim3 tile_grid(int n, int nb) { return dim3(n / 64, n / 64, nb); }
+inline dim3 tile_grid_up(int n, int nb) { return dim3((n + 63) / 64, (n + 63) / 64, nb); }
+
+}  // namespace
+
+#define LAUNCH_CHECK() BAYENS_HIP(hipGetLastError())
+
+HipPrims::~HipPrims() {
+  if (xs) (void)hipFree(xs);
+  if (ssq) (void)hipFree(ssq);
+  if (gpart) (void)hipFree(gpart);
+  for (auto& e : prof.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : prof.pool) (void)hipEventDestroy(e);
+}
+
+void HipPrims::ensure_scratch(int nb, int Np, int R4) {
+  size_t need_xs = (size_t)nb * Np * R4 * sizeof(double);
+  size_t need_s = (size_t)nb * Np * sizeof(double);
+  size_t need_g = (size_t)nb * (Np / 64) * (Np / 64) * 2 * sizeof(double);
+  if (need_xs > xs_cap) { if (xs) BAYENS_HIP(hipFree(xs)); BAYENS_HIP(hipMalloc(&xs, need_xs)); xs_cap = need_xs; }
+  if (need_s > ssq_cap) { if (ssq) BAYENS_HIP(hipFree(ssq)); BAYENS_HIP(hipMalloc(&ssq, need_s)); ssq_cap = need_s; }
+  if (need_g > gpart_cap) { if (gpart) BAYENS_HIP(hipFree(gpart)); BAYENS_HIP(hipMalloc(&gpart, need_g)); gpart_cap = need_g; }
+}
+
+void HipPrims::potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+  hipLaunchKernelGGL(potrf_leaf_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info);
+  LAUNCH_CHECK();
+}
+void HipPrims::copy(int nb, int n, Mat src, Mat dst) {
+  hipLaunchKernelGGL(copy_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, dst, 0);
+  LAUNCH_CHECK();
+}
+void HipPrims::tri_copy(int nb, int n, Mat src, Mat dst) {
+  hipLaunchKernelGGL(copy_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, dst, 1);
+  LAUNCH_CHECK();
+}
+void HipPrims::transpose_lower(int nb, int n, Mat W, Mat Wt) {
+  hipLaunchKernelGGL(transpose_lower_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, W, Wt);
+  LAUNCH_CHECK();
+}
+void HipPrims::init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
+                          const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) {
+  hipLaunchKernelGGL(fill_identity_kernel, tile_grid(Np, nb), dim3(256), 0, stream, Np, Lam);
+  hipLaunchKernelGGL(init_vec_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, nb, N, Np, theta1, mvec,
+                     ustate, y_in, nu_in, y_pad, nu_pad, info);
+  LAUNCH_CHECK();
+}
+void HipPrims::kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
+                    Mat K0, Mat Lb) {
+  const int R4 = ((R + 3) / 4) * 4;
+  ensure_scratch(nb, Np, R4);
+  hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq);
+  hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
+                     kernel, jitter, K0, Lb, Mat{nullptr, 0, 0}, (double*)nullptr);
+  LAUNCH_CHECK();
+}
+void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) {
+  hipLaunchKernelGGL(scale_rows_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, nu, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma, double* theta1) {
+  hipLaunchKernelGGL(theta_update_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, y, nu, gamma, theta1);
+  LAUNCH_CHECK();
+}
+void HipPrims::trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1, double* mvec) {
+  size_t lds = (size_t)2 * n * sizeof(double);
+  if (lds > 128 * 1024) throw HipError{-1, "trsv2: N too large for the LDS-resident substitution"};
+  if (lds > 48 * 1024)
+    BAYENS_HIP(hipFuncSetAttribute((const void*)trsv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(trsv2_kernel, dim3(nb), dim3(256), lds, stream, n, C, invC, inv_stride, theta1, mvec);
+  LAUNCH_CHECK();
+}
+void HipPrims::resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) {
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
+  LAUNCH_CHECK();
+}
+void HipPrims::form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) {
+  hipLaunchKernelGGL(form_lbar_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, X, a, mvec, nu);
+  LAUNCH_CHECK();
+}
+void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) {
+  const int R4 = ((R + 3) / 4) * 4;
+  ensure_scratch(nb, Np, R4);
+  // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
+  hipLaunchKernelGGL((kmat_kernel<true>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate, kernel,
+                     0.0, Mat{nullptr, 0, 0}, Mat{nullptr, 0, 0}, Kbt, gpart);
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
+  LAUNCH_CHECK();
+}
+void HipPrims::gemv_n(int nb, int n, Mat A, const double* x, double* y) {
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, x, (const double*)nullptr, y, 0);
+  LAUNCH_CHECK();
+}
+void HipPrims::cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) {
+  hipLaunchKernelGGL(cov_init_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, K0, nu, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::extract(int nb, int N, Mat src, double* dst, int mode) {
+  hipLaunchKernelGGL(extract_kernel, tile_grid_up(N, nb), dim3(256), 0, stream, N, src, dst, mode);
+  LAUNCH_CHECK();
+}
+void HipPrims::extract_vec(int nb, int N, int Np, const double* src, double* dst) {
+  hipLaunchKernelGGL(extract_vec_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::logdet(int nb, int N, Mat Lc, double* out) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(nb), dim3(256), 0, stream, N, Lc, out);
+  LAUNCH_CHECK();
+}
+void HipPrims::hyp_out(int nb, const double* ustate, double* hyp) {
+  hipLaunchKernelGGL(hyp_out_kernel, dim3((nb + 63) / 64), dim3(64), 0, stream, nb, ustate, hyp);
+  LAUNCH_CHECK();
+}
+void HipPrims::pad_in(int nb, int N, int Np, const double* src, Mat dst) {
+  hipLaunchKernelGGL(pad_in_kernel, tile_grid(Np, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+
+void HipPrims::loglik_rows(int B, int N, int R_obs, const double* mu, const double* chol, const double* logdet,
+                           const double* obs, double* ll_mean, double* scratch_ac) {
+  const int Npad = ((N + 63) / 64) * 64;
+  size_t lds = (size_t)2 * Npad * sizeof(double);
+  if (lds > 96 * 1024) throw HipError{-1, "loglik_rows: N too large for the LDS-resident substitution"};
+  if (lds > 16 * 1024)
+    BAYENS_HIP(hipFuncSetAttribute((const void*)trsv_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(trsv_fwd2_kernel, dim3(B), dim3(256), lds, stream, N, chol, mu, scratch_ac);
+  hipLaunchKernelGGL(loglik_rows_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, scratch_ac, logdet,
+                     obs, ll_mean);
+  LAUNCH_CHECK();
+}
+void HipPrims::normal_loglik_rows(int B, int N, int R_obs, const double* mu, const double* scale, const double* obs,
+                                  double* ll_mean) {
+  hipLaunchKernelGGL(normal_loglik_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, mu, scale, obs,
+                     ll_mean);
+  LAUNCH_CHECK();
+}
+void HipPrims::weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw) {
+  hipLaunchKernelGGL(normalise_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, ll_mean, c_std, w, w_raw);
+  LAUNCH_CHECK();
+}
+void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, double* w) {
+  hipLaunchKernelGGL(w2_temporal_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, mean, var, w);
+  LAUNCH_CHECK();
+}
+void HipPrims::barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,
+                          double init_var, double* mu_out, double* var_out, int* n_bad) {
+  BAYENS_HIP(hipMemsetAsync(n_bad, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(barycentre_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, w, mean, var, tol,
+                     init_var, mu_out, var_out, n_bad);
+  LAUNCH_CHECK();
+}
+void HipPrims::weighted_model_mean(int M, int R_max, const int* R, int P, const double* data, const double* w,
+                                   double* mu_out, double* var_out) {
+  hipLaunchKernelGGL(weighted_model_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, R_max, R, P, data, w,
+                     mu_out, var_out);
+  LAUNCH_CHECK();
+}
+void HipPrims::extract_diag(int B, int N, const double* cov, double* var) {
+  hipLaunchKernelGGL(extract_diag_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, cov, var);
+  LAUNCH_CHECK();
+}
+
+}  // namespace bayens
