@@ -77,6 +77,11 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   const long is = ws.inv_stride();
   P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info);
 
+  if (fp.n_iters == 0) {   // q(v) stays at its initial N(0, I): C = chol(I)
+    P.tri_copy(nb, Np, ws.Lam, ws.Cb);
+    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);
+  }
+
   for (int it = 0; it < fp.n_iters; ++it) {
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
@@ -96,7 +101,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
     P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))
     P.gemm(nb, Np, Np, Np, 1.0, ws.Lb, ws.T1, 0.0, ws.T2,
-           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI, 0.0);   // Phi(L^T Lbar)
+           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI | GEMM_ZERO_SKIPPED, 0.0);   // Phi(L^T Lbar): a clean
+    // lower-triangular right-hand side (the solve below reads whole row panels of it)
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
     P.transpose_lower(nb, Np, ws.T2, ws.T1);                          // W^T
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1, false);        // Kbar^T = W^T L^-1

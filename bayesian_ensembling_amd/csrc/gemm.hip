@@ -91,10 +91,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   const int t = bid - batch * tiles;
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
-  if ((g.flags & GEMM_TRI_OUT) && col0 > row0) return;   // whole tile above the block diagonal
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  if ((g.flags & GEMM_TRI_OUT) && (g.flags & GEMM_ZERO_SKIPPED)) {
+    // 64x64 blocks strictly above the block diagonal are not computed but must read as zeros later
+    const int r64 = row0 + wm * 64, c64 = col0 + wn * 64;
+    if (c64 > r64 && r64 < g.m && c64 < g.n) {
+      double* Cz = g.C + batch * g.sC + (long)r64 * g.ldc + c64;
+      for (int e = lane; e < 64 * 64; e += 64) Cz[(long)(e >> 6) * g.ldc + (e & 63)] = 0.0;
+    }
+  }
+  if ((g.flags & GEMM_TRI_OUT) && col0 > row0) return;   // whole tile above the block diagonal
   const double* A = g.A + batch * g.sA;
   const double* B = g.B + batch * g.sB;
   double* C = g.C + batch * g.sC;

@@ -31,6 +31,7 @@ enum : int {
   GEMM_TRI_OUT = 4,        // C square: skip 64x64 blocks strictly above the diagonal (not written)
   GEMM_KTRIM_TN_LOWER = 8, // with TA, !TB: A and B are lower triangular => k starts at max(i0, j0)
   GEMM_EPI_PHI = 16,       // epilogue: zero where i<j, halve where i==j   (Cholesky-backward Phi)
+  GEMM_ZERO_SKIPPED = 32,  // with TRI_OUT: the skipped 64x64 blocks are written with zeros instead of left alone
 };
 
 struct Prims {

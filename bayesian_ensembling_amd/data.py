@@ -1,0 +1,248 @@
+"""Containers of the plug-in API: Distribution, ProcessModel, ModelCollection.
+
+Same names, fields, properties and error behaviour as the reference (ensembles/data.py:18-143, 146-352,
+355-562) minus plotting; `ModelCollection.fit` additionally batches all members into one device call when
+the emulator offers `fit_collection` (members are independent: data.py:391 loops over them serially).
+"""
+from __future__ import annotations
+
+import pickle
+import typing as tp
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import distributions as dx
+from .labelled import DataArray
+
+
+@dataclass
+class Distribution:
+    """ensembles/data.py:18-143.  `dist_type(mu, covariance)` is called positionally (data.py:39)."""
+    mu: np.ndarray
+    covariance: np.ndarray
+    dim_array: DataArray
+    dist_type: tp.Any
+    _factor: tp.Any = field(default=None, repr=False)   # (chol, logdet) handed over by the GPU fit
+
+    def __post_init__(self):
+        if self.dist_type is dx.MultivariateNormalFullCovariance and self._factor is not None:
+            self._dist = self.dist_type(self.mu, self.covariance, _chol=self._factor[0], _logdet=self._factor[1])
+        else:
+            self._dist = self.dist_type(self.mu, self.covariance)
+
+    def reshape(self, vals, name=False):
+        """data.py:41-55"""
+        reshaped_vals = np.asarray(vals).reshape(self.dim_array.shape)
+        reshaped_array = self.dim_array.copy(data=reshaped_vals)
+        if name:
+            reshaped_array = reshaped_array.rename(name)
+        return reshaped_array
+
+    @property
+    def mean(self):
+        return self.reshape(self._dist.mean(), name="Distribution mean")
+
+    @property
+    def variance(self):
+        return self.reshape(self._dist.variance(), name="Distribution variance")
+
+    def sample(self):
+        samples = np.asarray(self._dist.sample(seed=np.random.randint(0, 110000)))
+        return self.reshape(samples, name="Distribution sample")
+
+
+@dataclass
+class ProcessModel:
+    """ensembles/data.py:146-352: the simulation output of one process model, dims (realisation, time, ...)."""
+    model_data: DataArray
+    model_name: str
+    idx: int = 0
+    _distribution = None
+
+    def __post_init__(self):
+        self.model_data = DataArray.from_any(self.model_data)
+        self.model_mean = self.model_data.mean()
+        self.model_std = self.model_data.std()
+        self.climatology = None
+        assert isinstance(self.model_data, DataArray), "Input must be a DataArray"
+        assert self.model_data.dims[0] == "realisation"
+        assert np.any(~np.isnan(self.model_data.values)), "Input data must not contain NaN"
+
+    @property
+    def max_val(self):
+        return self.model_data.max()
+
+    @property
+    def min_val(self):
+        return self.model_data.min()
+
+    @property
+    def n_observations(self) -> int:
+        raise NotImplementedError
+
+    @property
+    def n_realisations(self) -> int:
+        return self.model_data.shape[0]
+
+    @property
+    def time(self):
+        return self.model_data.time
+
+    def calculate_anomaly(self, climatology_dates=("1961-01-01", "1990-12-31"), climatology=False,
+                          resample_freq=None):
+        """data.py:225-261: anomaly w.r.t. a monthly climatology; optional annual ('Y') resampling."""
+        da = self.model_data.copy(deep=True)
+        t = np.asarray(da.coords["time"]).astype("datetime64[D]")
+        month = t.astype("datetime64[M]").astype(int) % 12
+        tax = da.dims.index("time")
+        if np.any(climatology) == False:  # noqa: E712  (same test as the reference)
+            t0, t1 = np.datetime64(climatology_dates[0]), np.datetime64(climatology_dates[1])
+            sel = (t >= t0) & (t <= t1)
+            vals = np.moveaxis(da.values, tax, 0)
+            clim = np.stack([vals[sel & (month == m)].mean(axis=0) for m in range(12)])   # (12, real, ...)
+            clim = clim.mean(axis=1)                                                      # mean over realisation
+        else:
+            clim = np.asarray(getattr(climatology, "values", climatology))
+            assert clim.shape[0] == 12, "Climatology is the incorrect length (must be 12)"
+        vals = np.moveaxis(da.values, tax, 0).astype(np.float64)      # (time, real, ...)
+        anom = vals - clim[month][:, None, ...]
+        tcoord = da.coords["time"]
+        if resample_freq:
+            if resample_freq not in ("Y", "A", "YE"):
+                raise NotImplementedError("only annual resampling is implemented")
+            years = t.astype("datetime64[Y]")
+            uy = np.unique(years)
+            anom = np.stack([anom[years == y].mean(axis=0) for y in uy])
+            tcoord = (uy + 1).astype("datetime64[D]") - np.timedelta64(1, "D")   # year-end stamps like xarray
+        anom = np.moveaxis(anom, 0, tax)
+        coords = dict(da.coords)
+        coords["time"] = tcoord
+        out = DataArray(anom, da.dims, coords, da.name)
+        anomaly_model = ProcessModel(out, self.model_name + " anomaly")
+        anomaly_model.climatology = DataArray(clim, ("month",) + tuple(d for d in da.dims if d not in ("time", "realisation")),
+                                              {"month": np.arange(1, 13)})
+        return anomaly_model
+
+    @property
+    def mean_across_realisations(self):
+        return self.model_data.mean("realisation")
+
+    @property
+    def std_across_realisations(self):
+        return self.model_data.std("realisation")
+
+    @property
+    def ndim(self):
+        return self.model_data.ndim
+
+    @property
+    def distribution(self) -> Distribution:
+        return self._distribution
+
+    @distribution.setter
+    def distribution(self, dist: Distribution):
+        self._distribution = dist
+
+    def __len__(self) -> int:
+        return self.n_realisations
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        try:
+            if self.idx >= self.n_realisations:
+                raise IndexError
+            out = self.model_data.isel(realisation=self.idx)
+            self.idx += 1
+        except IndexError:
+            self.idx = 0
+            raise StopIteration
+        return out
+
+
+@dataclass
+class ModelCollection:
+    """ensembles/data.py:355-562."""
+    models: tp.List[ProcessModel]
+    idx: int = 0
+
+    def __post_init__(self):
+        self.check_time_axes()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        try:
+            out = self.models[self.idx]
+            self.idx += 1
+        except IndexError:
+            self.idx = 0
+            raise StopIteration
+        return out
+
+    def fit(self, model, **kwargs):
+        """data.py:385-395.  Emulators exposing `fit_collection` fit every member in one batched GPU call."""
+        for process_model in self.models:
+            if process_model.distribution != None:  # noqa: E711
+                warnings.warn("Removing the model's previously learnt distribution")
+        if hasattr(model, "fit_collection"):
+            dists = model.fit_collection(self.models, **kwargs)
+            for process_model, dist in zip(self.models, dists):
+                process_model.distribution = dist
+            return
+        for process_model in self.models:
+            dist = model.fit(process_model, **kwargs)
+            process_model.distribution = dist
+
+    def save(self, path: str):
+        with open(path, "wb") as f:
+            pickle.dump(self, f)
+
+    @property
+    def time(self):
+        return self.models[0].time
+
+    @property
+    def max_val(self):
+        return np.max([model.max_val.values for model in self.models])
+
+    @property
+    def min_val(self):
+        return np.min([model.min_val.values for model in self.models])
+
+    @property
+    def number_of_models(self):
+        return len(self.models)
+
+    @property
+    def model_names(self):
+        return [model.model_name for model in self.models]
+
+    def __len__(self):
+        return len(self.models)
+
+    def __getitem__(self, item):
+        return self.models[item]
+
+    def distributions(self) -> tp.Dict[str, Distribution]:
+        return {model.model_name: model.distribution for model in self.models}
+
+    def check_time_axes(self):
+        """data.py:542-562"""
+        time_axes_match = True
+        for model1 in self.models:
+            for model2 in self.models:
+                t1, t2 = model1.model_data.coords["time"], model2.model_data.coords["time"]
+                if t1.shape != t2.shape or np.any(t1 != t2):
+                    time_axes_match = False
+        if time_axes_match == False:  # noqa: E712
+            warnings.warn("Time axes of models don't match: applying naive fix. Check models are collocated "
+                          "correctly in time!")
+            new_time = self.time
+            for model in self.models:
+                model.model_data["time"] = new_time
+        return

@@ -1,0 +1,76 @@
+"""Ensembling plug-ins (ensembles/ensemble_scheme.py): Scheme()(process_models, weights, **kw) -> Distribution."""
+from __future__ import annotations
+
+import abc
+import typing as tp
+
+import numpy as np
+
+from . import _lib
+from . import distributions as dx
+from .data import Distribution, ModelCollection
+from .labelled import DataArray, ones_like
+
+
+class AbstractEnsembleScheme:
+    def __init__(self, name: str) -> None:
+        self.name = name
+        self.distributions = None
+
+    @abc.abstractmethod
+    def _compute(self, process_models: ModelCollection, weights) -> Distribution:
+        raise NotImplementedError
+
+    def __call__(self, process_models: ModelCollection, weights, **kwargs) -> tp.Any:
+        return self._compute(process_models=process_models, weights=weights, **kwargs)   # ensemble_scheme.py:33-36
+
+
+def _blank(process_model):
+    return (ones_like(process_model.model_data[0].drop_vars("realisation")) * np.nan).rename("blank")
+
+
+class Barycentre(AbstractEnsembleScheme):
+    def __init__(self, name: str = "Barycentre") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, weights, n_threads=2) -> Distribution:
+        """ensemble_scheme.py:43-81: per point the 1-D Wasserstein barycentre of the members' marginals
+        N(mean_t, variance_t).  Returns MultivariateNormalDiag(mu*, scale_diag = sigma*^2) as the reference does."""
+        del n_threads
+        M = process_models.number_of_models
+        for t_idx, process_model in enumerate(process_models.models):
+            if not process_model.distribution:
+                raise AttributeError(f"No posterior for model {t_idx}. Please run model.fit() first.")
+        n_points = int(process_models[0].model_data.size / process_models[0].model_data.shape[0])
+        w = np.asarray(getattr(weights, "values", weights), dtype=np.float64).reshape(M, -1)
+        if w.shape[1] != n_points:
+            raise ValueError(f"weights have {w.shape[1]} points per model, the posteriors {n_points}")
+        mean = np.stack([np.asarray(pm.distribution._dist.mean()).reshape(-1) for pm in process_models.models])
+        var = np.stack([np.asarray(pm.distribution._dist.variance()).reshape(-1) for pm in process_models.models])
+        mu, v, bad = _lib.default_context().barycentre(w, mean, var)
+        if bad:
+            import warnings
+            warnings.warn(f"Barycentre not converged for {bad} time step(s)")
+        return Distribution(mu=mu, covariance=v, dim_array=_blank(process_models.models[-1]),
+                            dist_type=dx.MultivariateNormalDiag)
+
+
+class WeightedModelMean(AbstractEnsembleScheme):
+    def __init__(self, name: str = "MultiModelMean") -> None:   # (sic) the reference names it "MultiModelMean"
+        super().__init__(name)
+
+    def _compute(self, process_models, weights) -> Distribution:
+        """ensemble_scheme.py:136-160"""
+        models = list(process_models.models)
+        M = len(models)
+        wda = DataArray.from_any(weights)
+        w = np.stack([np.asarray(wda.sel(model=m.model_name).values, dtype=np.float64).reshape(-1) for m in models])
+        R = np.array([m.n_realisations for m in models], dtype=np.int32)
+        P = int(models[0].model_data.size / models[0].n_realisations)
+        if w.shape[1] == 1 and P > 1:
+            w = np.repeat(w, P, axis=1)
+        data = np.zeros((M, int(R.max()), P))
+        for i, m in enumerate(models):
+            data[i, :R[i]] = np.asarray(m.model_data.values, dtype=np.float64).reshape(R[i], -1)
+        mu, v = _lib.default_context().weighted_model_mean(data, R, w)
+        return Distribution(mu=mu, covariance=v, dim_array=_blank(models[0]), dist_type=dx.MultivariateNormalDiag)

@@ -1,0 +1,275 @@
+"""A small labelled N-d array: the subset of xarray.DataArray behaviour the reference's hot-path API
+relies on (named dims, coordinate vectors, reductions by dim name, isel/sel, broadcasting by name).
+
+The reference passes xarray.DataArray objects across its plug-in boundary (ensembles/data.py,
+weights.py:110-123, ensemble_scheme.py:52).  xarray is not available on the target image, so the
+drop-in carries its own container with the same spelling; `from_any` accepts a real xarray.DataArray
+when a caller has one, and `to_xarray` converts back when xarray is importable.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class DataArray:
+    def __init__(self, data, dims=None, coords=None, name=None):
+        self.values = np.asarray(data)
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(self.values.ndim))
+        self.dims = tuple(dims)
+        assert len(self.dims) == self.values.ndim, "dims do not match data rank"
+        self.coords = {}
+        self.scalar_coords = {}
+        for k, v in (coords or {}).items():
+            v = np.asarray(v)
+            if v.ndim == 0 or k not in self.dims:
+                self.scalar_coords[k] = v
+            else:
+                assert v.shape[0] == self.values.shape[self.dims.index(k)], f"coord {k} has the wrong length"
+                self.coords[k] = v
+        self.name = name
+
+    # -- construction helpers ------------------------------------------------------------------------
+    @staticmethod
+    def from_any(obj):
+        if isinstance(obj, DataArray):
+            return obj
+        if hasattr(obj, "dims") and hasattr(obj, "values") and hasattr(obj, "coords"):   # xarray.DataArray
+            coords = {k: np.asarray(obj.coords[k].values) for k in obj.coords}
+            return DataArray(np.asarray(obj.values), tuple(obj.dims), coords, getattr(obj, "name", None))
+        raise TypeError("expected a DataArray (bayesian_ensembling_amd.labelled or xarray)")
+
+    def to_xarray(self):
+        import xarray as xr   # only when the caller has it
+        return xr.DataArray(self.values, dims=self.dims, coords={k: (k, v) for k, v in self.coords.items()},
+                            name=self.name)
+
+    def _new(self, data, dims=None, coords=None, name=None):
+        dims = self.dims if dims is None else tuple(dims)
+        if coords is None:
+            coords = {k: v for k, v in self.coords.items() if k in dims}
+        out = DataArray(data, dims, coords, self.name if name is None else name)
+        out.scalar_coords.update(self.scalar_coords)
+        return out
+
+    # -- basic protocol ------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self.values.shape
+
+    @property
+    def ndim(self):
+        return self.values.ndim
+
+    @property
+    def size(self):
+        return self.values.size
+
+    @property
+    def data(self):
+        return self.values
+
+    @data.setter
+    def data(self, v):
+        v = np.asarray(v)
+        assert v.shape == self.values.shape
+        self.values = v
+
+    def __len__(self):
+        return self.values.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def __repr__(self):
+        return f"<DataArray {self.name or ''} dims={self.dims} shape={self.shape}>"
+
+    def __getattr__(self, item):
+        # coordinate access by attribute (da.time, da.realisation, da.model ...)
+        d = self.__dict__
+        if "coords" in d and item in d["coords"]:
+            return DataArray(d["coords"][item], (item,), {item: d["coords"][item]}, item)
+        if "scalar_coords" in d and item in d["scalar_coords"]:
+            return DataArray(d["scalar_coords"][item], (), {}, item)
+        raise AttributeError(item)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, str):
+            return getattr(self, idx)
+        if isinstance(idx, (int, np.integer)):
+            return self.isel(**{self.dims[0]: int(idx)})
+        if isinstance(idx, slice):
+            return self.isel(**{self.dims[0]: idx})
+        raise TypeError("only integer / slice indexing of the first dimension is supported")
+
+    def __setitem__(self, key, value):
+        if isinstance(key, str):   # da['time'] = new coordinate
+            self.coords[key] = np.asarray(getattr(value, "values", value))
+            return
+        raise TypeError("only coordinate assignment is supported")
+
+    def __iter__(self):
+        for i in range(self.values.shape[0]):
+            yield self[i]
+
+    def copy(self, deep=True, data=None):
+        out = self._new(np.array(self.values, copy=True) if data is None else np.asarray(data),
+                        coords={k: v.copy() for k, v in self.coords.items()})
+        return out
+
+    def rename(self, name):
+        out = self._new(self.values)
+        out.name = name
+        return out
+
+    def assign_coords(self, **kw):
+        out = self._new(self.values)
+        for k, v in kw.items():
+            v = np.asarray(getattr(v, "values", v))
+            if k in out.dims and v.ndim == 1:
+                out.coords[k] = v
+            else:
+                out.scalar_coords[k] = v
+        return out
+
+    def drop_vars(self, names):
+        if isinstance(names, str):
+            names = [names]
+        out = self._new(self.values)
+        for n in names:
+            out.scalar_coords.pop(n, None)
+            if n in out.coords and n not in out.dims:
+                out.coords.pop(n)
+        return out
+
+    drop = drop_vars
+
+    def expand_dims(self, axis=0, **kw):
+        (dim, coord), = kw.items()
+        coord = np.asarray(getattr(coord, "values", coord))
+        data = np.repeat(np.expand_dims(self.values, axis), coord.shape[0], axis=axis)
+        dims = list(self.dims)
+        dims.insert(axis, dim)
+        coords = dict(self.coords)
+        coords[dim] = coord
+        return self._new(data, dims, coords)
+
+    # -- selection -----------------------------------------------------------------------------------
+    def isel(self, **kw):
+        data = self.values
+        dims = list(self.dims)
+        coords = dict(self.coords)
+        scalars = dict(self.scalar_coords)
+        for dim, ix in kw.items():
+            ax = dims.index(dim)
+            if isinstance(ix, (int, np.integer)):
+                data = np.take(data, int(ix), axis=ax)
+                if dim in coords:
+                    scalars[dim] = coords.pop(dim)[int(ix)]
+                dims.pop(ax)
+            else:
+                sl = [slice(None)] * data.ndim
+                sl[ax] = ix
+                data = data[tuple(sl)]
+                if dim in coords:
+                    coords[dim] = coords[dim][ix]
+        out = DataArray(data, dims, coords, self.name)
+        out.scalar_coords = scalars
+        return out
+
+    def sel(self, **kw):
+        ix = {}
+        for dim, val in kw.items():
+            c = self.coords[dim]
+            if isinstance(val, slice):
+                lo = c[0] if val.start is None else np.asarray(val.start).astype(c.dtype)
+                hi = c[-1] if val.stop is None else np.asarray(val.stop).astype(c.dtype)
+                ix[dim] = np.nonzero((c >= lo) & (c <= hi))[0]
+            else:
+                hits = np.nonzero(c == val)[0]
+                if hits.size == 0:
+                    raise KeyError(f"{val!r} not found in coordinate {dim}")
+                ix[dim] = int(hits[0])
+        return self.isel(**ix)
+
+    # -- reductions ----------------------------------------------------------------------------------
+    def _reduce(self, fn, dim=None, **kw):
+        if dim is None:
+            return DataArray(fn(self.values, **kw), (), {}, self.name)
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        axes = tuple(self.dims.index(d) for d in dims)
+        keep = [d for d in self.dims if d not in dims]
+        return self._new(fn(self.values, axis=axes, **kw), keep)
+
+    def sum(self, dim=None):
+        return self._reduce(np.sum, dim)
+
+    def mean(self, dim=None):
+        return self._reduce(np.mean, dim)
+
+    def std(self, dim=None):
+        return self._reduce(np.std, dim)
+
+    def var(self, dim=None):
+        return self._reduce(np.var, dim)
+
+    def max(self, dim=None):
+        return self._reduce(np.max, dim)
+
+    def min(self, dim=None):
+        return self._reduce(np.min, dim)
+
+    # -- arithmetic with broadcasting by dimension name ----------------------------------------------------
+    def _binary(self, other, fn, reflected=False):
+        if isinstance(other, DataArray):
+            dims = list(self.dims) + [d for d in other.dims if d not in self.dims]
+
+            def expand(a):
+                src = [d for d in dims if d in a.dims]
+                v = np.transpose(a.values, [a.dims.index(d) for d in src]) if src else a.values
+                shape = [a.values.shape[a.dims.index(d)] if d in a.dims else 1 for d in dims]
+                return v.reshape(shape)
+
+            x, y = expand(self), expand(other)
+            coords = dict(other.coords)
+            coords.update(self.coords)
+            out = DataArray(fn(y, x) if reflected else fn(x, y), dims, {k: v for k, v in coords.items() if k in dims},
+                            self.name)
+            out.scalar_coords.update(other.scalar_coords)
+            out.scalar_coords.update(self.scalar_coords)
+            return out
+        o = np.asarray(other)
+        return self._new(fn(o, self.values) if reflected else fn(self.values, o))
+
+    def __add__(self, o): return self._binary(o, np.add)
+    def __radd__(self, o): return self._binary(o, np.add, True)
+    def __sub__(self, o): return self._binary(o, np.subtract)
+    def __rsub__(self, o): return self._binary(o, np.subtract, True)
+    def __mul__(self, o): return self._binary(o, np.multiply)
+    def __rmul__(self, o): return self._binary(o, np.multiply, True)
+    def __truediv__(self, o): return self._binary(o, np.divide)
+    def __rtruediv__(self, o): return self._binary(o, np.divide, True)
+    def __pow__(self, o): return self._binary(o, np.power)
+    def __neg__(self): return self._new(-self.values)
+    def __eq__(self, o): return self._binary(o, np.equal)      # noqa: E704
+    def __ne__(self, o): return self._binary(o, np.not_equal)  # noqa: E704
+    __hash__ = None
+
+
+def concat(arrays, dim):
+    """xr.concat along a NEW dimension whose coordinate comes from the scalar coord `dim` of each item
+    (weights.py:110-118 assigns `model=<name>` to every member's row and concatenates over 'model')."""
+    arrays = [DataArray.from_any(a) for a in arrays]
+    first = arrays[0]
+    data = np.stack([a.values for a in arrays], axis=0)
+    coords = dict(first.coords)
+    if all(dim in a.scalar_coords for a in arrays):
+        coords[dim] = np.asarray([a.scalar_coords[dim] for a in arrays])
+    out = DataArray(data, (dim,) + first.dims, coords, first.name)
+    out.scalar_coords = {k: v for k, v in first.scalar_coords.items() if k != dim}
+    return out
+
+
+def ones_like(a):
+    a = DataArray.from_any(a)
+    return a._new(np.ones_like(a.values, dtype=np.float64))

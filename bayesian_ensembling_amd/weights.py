@@ -1,0 +1,122 @@
+"""Weighting plug-ins with the reference's protocol (ensembles/weights.py:15-53): instantiate, then call with
+(process_models, observations=None, **kwargs) -> DataArray with a leading 'model' dimension that sums to one
+over 'model'.  The arithmetic of LogLikelihoodWeight (weights.py:56-131) and ModelSimilarityWeight
+(weights.py:214-333) runs in libbayens kernels."""
+from __future__ import annotations
+
+import abc
+import copy
+
+import numpy as np
+
+from . import _lib
+from . import distributions as dx
+from .data import ModelCollection, ProcessModel
+from .labelled import DataArray, concat
+
+__all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight"]
+
+
+class AbstractWeight:
+    def __init__(self, name: str) -> None:
+        self.name = name
+
+    @abc.abstractmethod
+    def _compute(self, process_models: ModelCollection, observations: ProcessModel):
+        raise NotImplementedError
+
+    def __call__(self, process_models: ModelCollection, observations: ProcessModel = None, **kwargs):
+        """weights.py:27-53"""
+        if observations is not None:
+            assert np.all(process_models.time.values == observations.time.values), \
+                "Time coordinates do not match between models and observations"
+            assert len(process_models.time) == len(observations.time), \
+                "Time coordinates do not match between models and observations"
+        for process_model in process_models.models:
+            assert hasattr(process_model.distribution, "_dist"), "Distribution not defined - fit models first"
+        return self._compute(process_models=process_models, observations=observations, **kwargs)
+
+
+def _row_template(model):
+    # copy.deepcopy(model.model_data.isel(realisation=0)).drop_vars("realisation")      (weights.py:110-112)
+    return copy.deepcopy(model.model_data.isel(realisation=0)).drop_vars("realisation")
+
+
+class LogLikelihoodWeight(AbstractWeight):
+    def __init__(self, name: str = "LogLikelihoodWeight") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, observations, return_lls=False, standardisation_scheme=None,
+                 standardisation_constant=1.0):
+        """weights.py:66-131.  standardisation_scheme: None / 'exp' (the reference default jnp.exp) runs fused on
+        the device; any other callable is applied on the host to the device-computed mean log-likelihood."""
+        ctx = _lib.default_context()
+        models = list(process_models.models)
+        obs = np.ascontiguousarray(np.asarray(observations.model_data.values, dtype=np.float64)
+                                   .reshape(observations.n_realisations, -1))
+        M = len(models)
+        P = obs.shape[1]
+        ll_mean = np.empty((M, P))
+        full = [i for i, m in enumerate(models) if m.distribution.dist_type is not dx.Normal]
+        diag = [i for i, m in enumerate(models) if m.distribution.dist_type is dx.Normal]
+        if full:
+            ds = [models[i].distribution._dist for i in full]
+            if not all(isinstance(d, dx.MultivariateNormalFullCovariance) for d in ds):
+                for i in full:   # MultivariateNormalDiag etc.: generic log_prob with the (N,1) broadcast
+                    d = models[i].distribution._dist
+                    ll_mean[i] = np.mean([d.log_prob(o[:, None]) for o in obs], axis=0)
+            else:
+                mu = np.stack([d.loc for d in ds])
+                chol = np.stack([d._scale_tri for d in ds])
+                logdet = np.array([d._logdet for d in ds])
+                ll_mean[full] = ctx.loglik_rows(mu, chol, logdet, obs)
+        if diag:
+            mu = np.stack([models[i].distribution._dist.loc.reshape(-1) for i in diag])
+            sc = np.stack([models[i].distribution._dist.scale.reshape(-1) for i in diag])
+            ll_mean[diag] = ctx.normal_loglik_rows(mu, sc, obs)
+
+        if standardisation_scheme is None or standardisation_scheme == "exp" or standardisation_scheme is np.exp:
+            w, raw = ctx.weights_normalise(ll_mean, standardisation_constant, return_raw=True)
+        else:
+            raw = np.asarray(standardisation_scheme(standardisation_constant * ll_mean), dtype=np.float64)
+            with np.errstate(all="ignore"):
+                w = raw / raw.sum(axis=0, keepdims=True)
+
+        def to_da(vals, name):
+            rows = []
+            for i, m in enumerate(models):
+                row = _row_template(m)
+                row.data = vals[i].reshape(row.shape)
+                rows.append(row.assign_coords(model=m.model_name))
+            return concat(rows, dim="model").rename(name)
+
+        weights = to_da(w, "Log-likelihood weights")
+        obs_real_shape = observations.model_data.shape[1:]
+        assert weights.shape == (len(process_models),) + obs_real_shape
+        if return_lls:
+            return weights, to_da(raw, "Log-likelihoods")
+        return weights
+
+
+class ModelSimilarityWeight(AbstractWeight):
+    def __init__(self, name: str = "ModelSimilarityWeight") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, mode: str = "single", observations: ProcessModel = None):
+        """weights.py:224-333.  'temporal' runs on the device; `observations` is accepted and ignored as in the
+        reference."""
+        if mode == "temporal":
+            ctx = _lib.default_context()
+            mean = np.stack([np.asarray(m.distribution._dist.mean()).reshape(-1) for m in process_models.models])
+            var = np.stack([np.asarray(m.distribution._dist.variance()).reshape(-1) for m in process_models.models])
+            w = ctx.w2_temporal(mean, var)
+            out = DataArray(w, ("model", "time"),
+                            {"model": np.asarray(process_models.model_names),
+                             "time": process_models[0].model_data.coords["time"]},
+                            "Model similarity weights")
+            return out
+        if mode in ("single", "spatial"):
+            raise NotImplementedError(
+                f"ModelSimilarityWeight(mode='{mode}') is not on the device yet (full-covariance W2 needs a "
+                "batched symmetric eigen-solver; SURVEY 8(e)/7-9).  Use mode='temporal'.")
+        raise ValueError('Mode must be "single", "spatial", or "temporal"')

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py - GP-member-fits/sec + weighted-posterior latency on the 32-member x 2000-timestep synthetic
+ensemble (BASELINE.json configs[1]), one process per GPU.
+
+One "step" = one pass of the hot path over the per-rank batch of synthetic members, inputs already resident
+in HBM: bayens_gp_fit_batch (Matern-3/2 VGP, n_optim_nits natgrad+Adam iterations, full-cov prediction,
+chol/logdet) -> loglik rows -> [RCCL all-gather of the packed (ll, mean, var) rows when N > 1] -> weights
+normalisation -> Wasserstein barycentre.  Members shard embarrassingly: each rank fits its own 32 members
+("weak" scaling); the only collective is the all-gather of [32, 3, 2000] fp64 rows per rank.
+
+Prints ONE JSON line on rank 0.  Run:  python bench.py --gpus 1 --steps 5 --warmup 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet); = 32 FLOP/clk/SIMD x 1024 SIMD x 2.4 GHz
+
+
+def fit_flops(N, R, T):
+    n3, n2r = float(N) ** 3, 2.0 * N * N * R
+    return T * (14.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0
+
+
+def make_inputs(M, N, R, R_obs, seed):
+    """Seeded synthetic ensemble: quadratic trend + AR(1) noise; y_mean = mean over realisations."""
+    from bayesian_ensembling_amd.synthetic import synthetic_ensemble
+    data, obs = synthetic_ensemble(M, N, R=R, R_obs=R_obs, seed=seed)
+    X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
+    return X, data.mean(axis=1), data.var(axis=1), obs
+
+
+def cpu_baseline(N, R, T, members):
+    """The oracle (NumPy/LAPACK restatement of the reference arithmetic, validated against the reference's
+    pickled fits) timed on this box's host cores, on a bounded sample of the same workload."""
+    from threadpoolctl import threadpool_info
+    from oracle import gp_oracle as go
+    data, _ = go.synthetic_ensemble(members, N, R=R, seed=0xB4E5)
+    t0 = time.time()
+    for m in range(members):
+        X, y, nu = go.prologue(data[m])
+        mu, cov, _ = go.gp_fit(X, y, nu, T)
+        go.mvn_factor(cov)
+    dt = time.time() - t0
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    return {"value": members / dt, "unit": "member-fits/s", "cores": int(threads), "kind": "port",
+            "sample": f"{members} member(s) of the same workload (N={N}, R={R}, n_optim_nits={T}), "
+                      f"NumPy/LAPACK oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=32, help="members per GPU")
+    ap.add_argument("--timesteps", type=int, default=2000)
+    ap.add_argument("--realisations", type=int, default=8)
+    ap.add_argument("--nits", type=int, default=2, help="n_optim_nits (2 = the reference's test scale)")
+    ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-members", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from bayesian_ensembling_amd import _lib, parallel
+    ctx = _lib.Context(local_rank)          # raises when libbayens / the GPU is missing: no fallback
+    host = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only (barrier, max, uid)
+        host = parallel.HostGather()
+        parallel.init_rccl(ctx, host)       # data plane: ncclAllGather over xGMI inside libbayens
+
+    M, N, R, T, R_obs = args.members, args.timesteps, args.realisations, args.nits, 3
+    kid = _lib.KERNEL_IDS[args.kernel]
+    X, y, nu, obs = make_inputs(M, N, R, R_obs, seed=0xB4E5 + rank)
+    dX, dy, dnu, dobs = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu), ctx.to_device(obs)
+    dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
+    dld, dhyp = ctx.empty((M,)), ctx.empty((M, 2))
+    Mtot = M * world
+    dll_loc, dvar_loc = ctx.empty((M, N)), ctx.empty((M, N))
+    if world > 1:
+        dll_all, dmean_all, dvar_all = ctx.empty((Mtot, N)), ctx.empty((Mtot, N)), ctx.empty((Mtot, N))
+    else:
+        dll_all, dmean_all, dvar_all = dll_loc, dmu, dvar_loc
+    dw, dbmu, dbvar = ctx.empty((Mtot, N)), ctx.empty((N,)), ctx.empty((N,))
+
+    def fit():
+        return ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, kernel=kid)
+
+    def weighted_posterior():
+        # LogLikelihoodWeight rows + posterior marginals of the local members, exchange of the [M, N] rows over
+        # RCCL (log-likelihoods, means, variances), then normalisation over ALL members and the barycentre
+        ctx.loglik_rows_dev(M, N, R_obs, dmu, dchol, dld, dobs, dll_loc)
+        ctx.extract_diag_dev(M, N, dcov, dvar_loc)
+        if world > 1:
+            ctx.allgather_rows(dll_loc, dll_all, M, N)
+            ctx.allgather_rows(dmu, dmean_all, M, N)
+            ctx.allgather_rows(dvar_loc, dvar_all, M, N)
+        ctx.weights_normalise_dev(Mtot, N, dll_all, 1e-3, dw)
+        return ctx.barycentre_dev(Mtot, N, dw, dmean_all, dvar_all, dbmu, dbvar)
+
+    def step():
+        fit()
+        return weighted_posterior()
+
+    def barrier():
+        ctx.sync()
+        if host:
+            host.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if host:
+        elapsed = host.max_float(elapsed)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = Mtot * args.steps / elapsed
+
+    # ---- untimed diagnostics on rank 0: latencies with HIP events, GEMM roofline, CPU baseline ----
+    extra = {}
+    roof = None
+    cpu = None
+    if rank == 0:
+        ctx.timer_start(); fit(); fit_ms = ctx.timer_stop()
+        ctx.timer_start(); bad = weighted_posterior(); wp_ms = ctx.timer_stop()
+        ctx.profile_enable(True)
+        fit()
+        p = ctx.profile_get(0)
+        ctx.profile_enable(False)
+        gemm_tflops = p["flop"] / (p["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_f64_mfma", "achieved": round(gemm_tflops, 3),
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / F64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_fit_batch": p["launches"],
+                "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
+                "gemm_ms_per_fit_batch": round(p["ms"], 3)}
+        extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
+                 "fit_algorithmic_tflops": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12, 3),
+                 "fit_frac_of_f64_peak": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                 "barycentre_not_converged": int(bad)}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(N, R, T, args.cpu_members)
+    if host:
+        host.barrier()
+        import torch.distributed as dist
+        ctx.comm_destroy()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        out = {
+            "metric": "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step ensemble",
+            "value": round(value, 3), "unit": "member-fits/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{M}-member x {N}-timestep synthetic ensemble per GPU, R={R} realisations, "
+                                   f"{args.kernel} VGP fit (n_optim_nits={T}) + LogLikelihoodWeight(c=1e-3) + Barycentre",
+                       "members_per_gpu": M, "timesteps": N, "realisations": R, "n_optim_nits": T,
+                       "kernel": args.kernel, "obs_realisations": R_obs,
+                       "parallelism": f"member-sharded x{world}, RCCL all-gather of [M,3,N] rows" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

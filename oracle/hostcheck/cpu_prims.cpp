@@ -50,7 +50,10 @@ struct CpuPrims : Prims {
         }
       for (int i = 0; i < m; ++i)
         for (int j = 0; j < n; ++j) {
-          if ((flags & GEMM_TRI_OUT) && (j / LEAF) > (i / LEAF)) continue;
+          if ((flags & GEMM_TRI_OUT) && (j / LEAF) > (i / LEAF)) {
+            if (flags & GEMM_ZERO_SKIPPED) c[(size_t)i * C.ld + j] = 0.0;
+            continue;
+          }
           c[(size_t)i * C.ld + j] = out[(size_t)i * n + j];
         }
     }
@@ -263,7 +266,8 @@ struct HostWs {
   FitWorkspace ws;
   std::vector<std::vector<double>> bufs;
   std::vector<int> info;
-  double* alloc(size_t n) { bufs.emplace_back(n, 0.0); return bufs.back().data(); }
+  // poisoned with NaN: any read of a region the driver never wrote shows up as a NaN in the result
+  double* alloc(size_t n) { bufs.emplace_back(n, std::nan("")); return bufs.back().data(); }
   HostWs(int nb, int Np) {
     ws.nb = nb; ws.Np = Np;
     auto mat = [&]() { return Mat{alloc((size_t)nb * Np * Np), Np, (long)Np * Np}; };

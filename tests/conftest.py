@@ -1,0 +1,52 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """The libbayens context on GPU 0.  GPU tests FAIL (not skip) when the library or the device is missing:
+    a silent fallback would void the parity claims."""
+    from bayesian_ensembling_amd import _lib
+    return _lib.default_context()
+
+
+@pytest.fixture(scope="session")
+def hostcheck():
+    """ctypes handle of the CPU driver-logic checker (oracle/hostcheck, test infrastructure)."""
+    import ctypes
+    so = os.path.join(ROOT, "oracle", "_build", "libhostcheck.so")
+    src = [os.path.join(ROOT, "oracle", "hostcheck", "cpu_prims.cpp"),
+           os.path.join(ROOT, "bayesian_ensembling_amd", "csrc", "driver.cpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call([os.path.join(ROOT, "oracle", "hostcheck", "build.sh")])
+    return ctypes.CDLL(so)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def member_inputs(data):
+    """(M,R,N) realisations -> X (M,N,R), y_mean (M,N) [mean stand-in], y_var (M,N)"""
+    X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
+    return X, data.mean(axis=1), data.var(axis=1)
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_files():
+    return sorted(f for f in os.listdir(GOLDEN) if f.startswith("gpfit_") and f.endswith(".npz"))

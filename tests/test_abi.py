@@ -1,0 +1,50 @@
+"""The C-ABI library loads on a host without a GPU and exports every symbol include/bayens.h declares;
+without a device the product fails loudly (no CPU fallback)."""
+import ctypes
+import os
+
+import pytest
+
+from bayesian_ensembling_amd import _lib
+
+
+def _have_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "libbayens.so is not built (python -m bayesian_ensembling_amd.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _lib.declared_symbols()
+    assert len(names) >= 28
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_string():
+    lib = _lib.load()
+    assert b"gfx950" in lib.bayens_version()
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(_lib.BayensError):
+        _lib.Context(0)
+    import numpy as np
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    _lib._default_ctx = None
+    da = DataArray(np.random.rand(3, 8), ("realisation", "time"),
+                   {"realisation": np.arange(3), "time": np.arange(8)})
+    mc = es.ModelCollection([es.ProcessModel(da, "a"), es.ProcessModel(da, "b")])
+    with pytest.raises(_lib.BayensError):
+        mc.fit(es.GPDTW1D(), n_optim_nits=1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.dirname(_lib.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "gp_oracle" not in txt and "hostcheck" not in txt.replace("oracle/hostcheck", ""), f

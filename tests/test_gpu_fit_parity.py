@@ -1,0 +1,120 @@
+"""The HIP fit vs the oracle on identical seeded inputs, the golden fixtures of the reference's own fits, and
+size-independent properties at BASELINE.json's full size.  Tolerance: 1e-5 relative (fp64), from BASELINE.json;
+the small cases are asserted much tighter."""
+import os
+
+import numpy as np
+import pytest
+from threadpoolctl import threadpool_limits
+
+from bayesian_ensembling_amd import _lib as L
+from conftest import GOLDEN, golden_files, member_inputs, relerr
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+@pytest.mark.parametrize("M,N,R,T,kernel", [
+    (8, 200, 8, 2, 0),      # BASELINE config 1: 8-member x 200-step, test-scale T (tests/test_weights.py:90)
+    (2, 86, 5, 3, 0), (3, 24, 3, 2, 0),   # the reference test's own N=24, R=3
+    (1, 65, 3, 1, 0), (1, 64, 2, 2, 0), (2, 130, 4, 2, 1), (1, 100, 8, 2, 2), (2, 7, 3, 2, 0), (1, 200, 8, 0, 0)])
+def test_fit_matches_oracle(ctx, M, N, R, T, kernel):
+    data, _ = go.synthetic_ensemble(M, N, R=R)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T, kernel=kernel)
+    assert not out["info"].any()
+    tight = 1e-10 if kernel == 0 else 1e-6       # smoother kernels: K + 1e-6 I is far worse conditioned
+    for m in range(M):
+        mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel)
+        Lc, ld = go.mvn_factor(co)
+        assert relerr(out["mu"][m], mo) < tight and relerr(out["cov"][m], co) < tight
+        assert relerr(out["chol"][m], Lc) < tight and abs(out["logdet"][m] - ld) < 1e-6
+        assert relerr(out["hyp"][m], ho) < tight
+        assert np.array_equal(out["cov"][m], out["cov"][m].T)
+
+
+def test_fit_with_api_default_iterations(ctx):
+    # n_optim_nits = 500 is the API default (models.py:167): the optimiser trajectory must stay on the oracle's
+    data, _ = go.synthetic_ensemble(2, 86, R=5, seed=3)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, 500)
+    with threadpool_limits(1):
+        for m in range(2):
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], 500)
+            assert relerr(out["mu"][m], mo) < 1e-7 and relerr(out["cov"][m], co) < 1e-7 and relerr(out["hyp"][m], ho) < 1e-8
+
+
+@pytest.mark.parametrize("fname", golden_files())
+def test_fit_reproduces_the_references_pickled_posteriors(ctx, fname):
+    """experiments/pre_fit_models/*.pkl -> tests/golden: GPDTW1D with n_optim_nits=2500 as the reference ran it."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    X, _, nu = go.prologue(g["data"])
+    out = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], int(g["n_iters"]))
+    assert relerr(out["cov"][0], g["cov_gold"]) < 1e-6
+    assert np.max(np.abs(out["mu"][0] - g["mu_gold"])) < 5e-6
+    assert relerr(out["hyp"][0], g["hyp"]) < 1e-6
+    # Distribution.__post_init__ (distrax): Cholesky + logdet of the reference's covariance
+    chol, logdet = ctx.mvn_factor_batch(g["cov_gold"][None])
+    assert np.max(np.abs(chol[0] - g["chol_gold"])) < 1e-11
+    assert abs(logdet[0] - float(g["logdet_gold"])) < 1e-9
+
+
+def test_fit_is_deterministic_and_independent_of_workspace_history(ctx):
+    # regression: the Cholesky-backward solve once read 64-blocks of a reused workspace that nothing had written
+    data, _ = go.synthetic_ensemble(2, 200, R=8, seed=21)
+    X, y, nu = member_inputs(data)
+    first = ctx.gp_fit_batch(X, y, nu, 3)
+    other, _ = go.synthetic_ensemble(2, 200, R=8, seed=22)
+    ctx.gp_fit_batch(*member_inputs(other), 2)              # dirties every workspace matrix
+    again = ctx.gp_fit_batch(X, y, nu, 3)
+    for k in ("mu", "cov", "chol", "logdet", "hyp"):
+        assert np.array_equal(first[k], again[k]), k
+    mo, co, ho = go.gp_fit(X[0], y[0], nu[0], 3)
+    assert relerr(again["cov"][0], co) < 1e-10 and relerr(again["hyp"][0], ho) < 1e-12
+
+
+def test_ragged_batch_members_do_not_interact(ctx):
+    data, _ = go.synthetic_ensemble(4, 100, R=4, seed=5)
+    X, y, nu = member_inputs(data)
+    all_ = ctx.gp_fit_batch(X, y, nu, 2)
+    one = ctx.gp_fit_batch(X[2:3], y[2:3], nu[2:3], 2)
+    assert np.array_equal(all_["cov"][2], one["cov"][0]) and np.array_equal(all_["mu"][2], one["mu"][0])
+
+
+def test_degenerate_member_is_reported_not_hidden(ctx):
+    # a single realisation has zero variance across realisations: y_var = 0 -> the reference divides by zero too
+    # (TF raises on the Cholesky); here the failing member is flagged through info / BAYENS_E_NOTPD.
+    data, _ = go.synthetic_ensemble(2, 64, R=3, seed=1)
+    X, y, nu = member_inputs(data)
+    nu[1, :] = 0.0
+    with pytest.raises(L.BayensError) as e:
+        ctx.gp_fit_batch(X, y, nu, 1)
+    assert e.value.code == -2 and e.value.info[1] > 0 and e.value.info[0] == 0
+
+
+def test_bad_arguments_are_rejected(ctx):
+    X = np.zeros((1, 8, 2))
+    with pytest.raises(L.BayensError):
+        ctx.gp_fit_batch(X, np.zeros((1, 8)), np.ones((1, 8)), 1, kernel=7)
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 shape (N=2000, R=8; 4 of the 32 members to bound the host-side check)."""
+    M, N, R, T = 4, 2000, 8, 2
+    data, obs = go.synthetic_ensemble(M, N, R=R)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T)
+    assert not out["info"].any()
+    for m in range(M):
+        cov, ch = out["cov"][m], out["chol"][m]
+        assert np.array_equal(cov, cov.T)
+        assert relerr(ch @ ch.T, cov) < 1e-12                       # encode -> decode: chol(cov) chol(cov)^T == cov
+        assert abs(np.sum(np.log(np.diag(ch))) - out["logdet"][m]) < 1e-8
+        assert np.all(np.diag(cov) > nu[m])                          # cov = (PSD) + diag(y_var)
+    # idempotence of the factorisation entry point on its own output
+    ch2, ld2 = ctx.mvn_factor_batch(out["cov"][:1])
+    assert relerr(ch2[0], out["chol"][0]) < 1e-13 and abs(ld2[0] - out["logdet"][0]) < 1e-9
+    # one member against the oracle at full size
+    mo, co, ho = go.gp_fit(X[0], y[0], nu[0], T)
+    assert relerr(out["mu"][0], mo) < REL_TOL and relerr(out["cov"][0], co) < REL_TOL and relerr(out["hyp"][0], ho) < REL_TOL

@@ -1,0 +1,166 @@
+"""Weights + weighted posterior: HIP kernels vs the oracle, reference quirks included, and the plug-in API
+exercised the way the reference's own tests/test_weights.py:71-101 does (type, shape, sum over 'model' == 1)."""
+import numpy as np
+import pytest
+
+import bayesian_ensembling_amd as es
+from bayesian_ensembling_amd import distributions as dx
+from bayesian_ensembling_amd.labelled import DataArray
+from conftest import member_inputs, relerr
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _posteriors(ctx, M, N, R=4, seed=2, T=2):
+    data, obs = go.synthetic_ensemble(M, N, R=R, R_obs=3, seed=seed)
+    X, y, nu = member_inputs(data)
+    return data, obs, ctx.gp_fit_batch(X, y, nu, T)
+
+
+@pytest.mark.parametrize("M,N,R_obs", [(8, 200, 3), (2, 86, 1), (3, 130, 10), (2, 7, 5)])
+def test_loglik_rows_and_weights(ctx, M, N, R_obs):
+    data, _, out = _posteriors(ctx, M, N)
+    _, obs = go.synthetic_ensemble(1, N, R=2, R_obs=R_obs, seed=9)
+    ll = ctx.loglik_rows(out["mu"], out["chol"], out["logdet"], obs)
+    ll_ref = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(out["mu"][m], out["chol"][m], out["logdet"][m], obs))
+                       for m in range(M)])
+    assert relerr(ll, ll_ref) < 1e-12
+    for c in (1e-3, 1e-2):
+        w, raw = ctx.weights_normalise(ll, c, return_raw=True)
+        w_ref, raw_ref = go.loglik_weights(ll_ref, c)
+        assert relerr(w, w_ref) < 1e-12 and relerr(raw, raw_ref) < 1e-12
+        assert np.allclose(w.sum(axis=0), 1.0, rtol=1e-12)
+
+
+def test_exp_underflow_gives_nan_like_the_reference(ctx):
+    ll = np.array([[-4000.0, -10.0], [-3000.0, -12.0]])
+    w = ctx.weights_normalise(ll, 1.0)
+    w_ref, _ = go.loglik_weights(ll, 1.0)
+    assert np.isnan(w[:, 0]).all() and np.array_equal(np.isnan(w), np.isnan(w_ref))
+    assert relerr(w[:, 1], w_ref[:, 1]) < 1e-14
+
+
+def test_normal_branch(ctx):
+    rng = np.random.default_rng(0)
+    mu, scale, obs = rng.standard_normal((3, 50)), rng.uniform(0.1, 2, (3, 50)), rng.standard_normal((4, 50))
+    ll = ctx.normal_loglik_rows(mu, scale, obs)
+    ref = np.stack([go.normal_loglik(mu[m], scale[m], obs).mean(axis=0) for m in range(3)])
+    assert relerr(ll, ref) < 1e-13
+
+
+def test_w2_temporal(ctx):
+    rng = np.random.default_rng(1)
+    mean, var = rng.standard_normal((5, 333)), rng.uniform(0.01, 3, (5, 333))
+    mean[1] = mean[0]                       # a tie: identical marginals, zero distance between the pair
+    var[1] = var[0]
+    assert relerr(ctx.w2_temporal(mean, var), go.w2_weights_temporal(mean, var)) < 1e-13
+
+
+def test_barycentre_both_sides_of_the_signed_test(ctx):
+    rng = np.random.default_rng(3)
+    M, P = 6, 500
+    w = rng.random((M, P))
+    w /= w.sum(axis=0)
+    mean = rng.standard_normal((M, P))
+    var = rng.uniform(0.01, 9.0, (M, P))          # sum w sigma straddles 1: both branches of wasserstein.py:85-91
+    mu, v, bad = ctx.barycentre(w, mean, var)
+    rm, rv, rbad = go.barycentre(w, mean, var)
+    S = (w * np.sqrt(var)).sum(axis=0)
+    assert (S < 1).any() and (S > 1).any() and bad == rbad == 0
+    assert relerr(mu, rm) < 1e-14 and relerr(v, rv) < 1e-13
+    # non-finite weights (the reference's exp underflow) never converge: counted, not hidden
+    w[:, 0] = np.nan
+    _, _, bad = ctx.barycentre(w, mean, var)
+    assert bad == 1
+
+
+def test_weighted_model_mean_with_ragged_realisations(ctx):
+    rng = np.random.default_rng(4)
+    R = np.array([3, 5, 2], dtype=np.int32)
+    P = 40
+    datas = [rng.standard_normal((r, P)) for r in R]
+    w = rng.random((3, P))
+    packed = np.zeros((3, 5, P))
+    for i, d in enumerate(datas):
+        packed[i, :R[i]] = d
+    mu, v = ctx.weighted_model_mean(packed, R, w)
+    rm, rv = go.weighted_model_mean(datas, w)
+    assert relerr(mu, rm) < 1e-14 and relerr(v, rv) < 1e-14
+
+
+# ---- plug-in API, as tests/test_weights.py of the reference drives it ---------------------------------
+def _collection(n_models, obs_n_reals, N=24, R=3, seed=0):
+    rng = np.random.default_rng(seed)
+    time = np.arange("1960-01", "1962-01", dtype="datetime64[M]")[:N]
+
+    def da(n_reals):
+        return DataArray(rng.random((n_reals, N)), ("realisation", "time"),
+                         {"realisation": np.arange(n_reals), "time": time})
+    mc = es.ModelCollection([es.ProcessModel(da(R), f"model{i}") for i in range(n_models)])
+    return mc, es.ProcessModel(da(obs_n_reals), "obs")
+
+
+@pytest.mark.parametrize("obs_n_reals", [1, 2, 5, 10])
+@pytest.mark.parametrize("n_models", [2, 5, 10])
+def test_weightings_api(ctx, n_models, obs_n_reals):
+    mc, obs = _collection(n_models, obs_n_reals)
+    mc.fit(model=es.GPDTW1D(), compile_objective=True, n_optim_nits=2, progress_bar=False)
+    for weighting in [es.LogLikelihoodWeight(), es.ModelSimilarityWeight()]:
+        if weighting.name == "LogLikelihoodWeight":
+            weights = weighting(mc, obs, standardisation_constant=0.001)
+        else:
+            weights = weighting(mc, obs, mode="temporal")
+        assert isinstance(weights, DataArray)
+        assert weights.shape == (n_models,) + obs.model_data.mean("realisation").shape
+        assert np.all(weights.sum("model").values == pytest.approx(1.0, 1e-6))
+    # the whole path against the oracle
+    data = np.stack([m.model_data.values for m in mc.models])
+    X, y, nu = member_inputs(data)
+    w = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=0.001)
+    ll_ref = []
+    for m in range(n_models):
+        mo, co, _ = go.gp_fit(X[m], y[m], nu[m], 2)
+        Lc, ld = go.mvn_factor(co)
+        ll_ref.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, Lc, ld, obs.model_data.values)))
+        assert relerr(mc[m].distribution.mean.values, mo) < 1e-9
+    w_ref, _ = go.loglik_weights(np.stack(ll_ref), 0.001)
+    assert relerr(w.values, w_ref) < 1e-8
+    bary = es.Barycentre()(mc, w)
+    var = np.stack([np.diag(m.distribution.covariance) for m in mc.models])
+    mean = np.stack([m.distribution.mu for m in mc.models])
+    rm, rv, _ = go.barycentre(w_ref, mean, var)
+    assert bary.dist_type is dx.MultivariateNormalDiag
+    assert relerr(bary.mu, rm) < 1e-8 and relerr(bary.covariance, rv) < 1e-8
+    assert relerr(bary._dist.variance(), rv ** 2) < 1e-8      # scale_diag = sigma*^2 quirk (ensemble_scheme.py:75-78)
+    wmm = es.WeightedModelMean()(mc, w)
+    rm2, rv2 = go.weighted_model_mean([m.model_data.values for m in mc.models], w_ref)
+    assert relerr(wmm.mu, rm2) < 1e-8 and relerr(wmm.covariance, rv2) < 1e-8
+
+
+def test_weights_require_fitted_models_and_matching_time(ctx):
+    mc, obs = _collection(2, 2)
+    with pytest.raises(AssertionError):
+        es.LogLikelihoodWeight()(mc, obs)                    # "Distribution not defined - fit models first"
+    mc.fit(es.GPDTW1D(), n_optim_nits=1)
+    with pytest.warns(UserWarning):                           # refitting warns (data.py:392-393)
+        mc.fit(es.GPDTW1D(), n_optim_nits=1)
+    obs.model_data.coords["time"] = obs.model_data.coords["time"] + np.timedelta64(31, "D")
+    with pytest.raises(AssertionError):
+        es.LogLikelihoodWeight()(mc, obs)
+    with pytest.raises(NotImplementedError):
+        es.GPDTW1D().fit(es.ProcessModel(DataArray(np.random.rand(2, 4, 3), ("realisation", "time", "lat")), "3d"))
+
+
+def test_return_lls_and_members_with_different_realisation_counts(ctx):
+    rng = np.random.default_rng(8)
+    time = np.arange(30)
+    def da(r): return DataArray(rng.random((r, 30)), ("realisation", "time"), {"realisation": np.arange(r), "time": time})
+    mc = es.ModelCollection([es.ProcessModel(da(3), "a"), es.ProcessModel(da(6), "b"), es.ProcessModel(da(3), "c")])
+    obs = es.ProcessModel(da(2), "obs")
+    mc.fit(es.GPDTW1D(), n_optim_nits=2)
+    w, lls = es.LogLikelihoodWeight()(mc, obs, return_lls=True, standardisation_constant=1e-3)
+    assert np.allclose((lls / lls.sum("model")).values, w.values)
+    assert list(w.coords["model"]) == ["a", "b", "c"]
+    one = es.GPDTW1D().fit(mc[1], n_optim_nits=2)
+    assert np.array_equal(one.covariance, mc[1].distribution.covariance)

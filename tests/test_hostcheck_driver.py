@@ -1,0 +1,78 @@
+"""CPU check of the host-side sequencing (csrc/driver.cpp): recursive blocked Cholesky / triangular solves,
+the natgrad + Adam iteration and the prediction epilogue, run on naive CPU primitives (oracle/hostcheck)
+and compared with the NumPy oracle.  The HIP primitives themselves are checked on the GPU (test_gpu_*)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import member_inputs, relerr
+from oracle import gp_oracle as go
+
+dp = ctypes.POINTER(ctypes.c_double)
+ip = ctypes.POINTER(ctypes.c_int)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def hc_fit(lib, X, y, nu, T, kernel=0):
+    B, N, R = X.shape
+    mu, cov, chol = np.zeros((B, N)), np.zeros((B, N, N)), np.zeros((B, N, N))
+    ld, hyp, info = np.zeros(B), np.zeros((B, 2)), np.zeros(B, dtype=np.int32)
+    lib.hostcheck_gp_fit(B, N, R, P(X), P(y), P(nu), kernel, T, ctypes.c_double(0.5), ctypes.c_double(0.01),
+                         ctypes.c_double(1e-6), P(mu), P(cov), P(chol), P(ld), P(hyp), info.ctypes.data_as(ip))
+    return mu, cov, chol, ld, hyp, info
+
+
+@pytest.mark.parametrize("M,N,R,T,kernel", [(2, 86, 5, 3, 0), (1, 200, 8, 2, 0), (1, 130, 4, 2, 1), (1, 64, 3, 2, 2),
+                                            (1, 65, 3, 1, 0), (1, 24, 3, 2, 0)])
+def test_driver_matches_oracle(hostcheck, M, N, R, T, kernel):
+    data, _ = go.synthetic_ensemble(M, N, R=R)
+    X, y, nu = member_inputs(data)
+    mu, cov, chol, ld, hyp, info = hc_fit(hostcheck, X, y, nu, T, kernel)
+    assert not info.any()
+    for m in range(M):
+        mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel)
+        Lc, l = go.mvn_factor(co)
+        assert relerr(mu[m], mo) < 1e-9 and relerr(cov[m], co) < 1e-9
+        assert relerr(chol[m], Lc) < 1e-9 and abs(ld[m] - l) < 1e-8 and relerr(hyp[m], ho) < 1e-11
+
+
+def test_blocked_potrf_and_trsm(hostcheck):
+    rng = np.random.default_rng(0)
+    nb, n, m = 2, 192, 128
+    A = rng.standard_normal((nb, n, n))
+    S = A @ np.swapaxes(A, 1, 2) + n * np.eye(n)
+    Lh = S.copy()
+    info = np.zeros(nb, dtype=np.int32)
+    hostcheck.hostcheck_potrf(nb, n, P(Lh), info.ctypes.data_as(ip))
+    ref = np.linalg.cholesky(S)
+    assert relerr(Lh, ref) < 1e-13 and not info.any()
+    B = rng.standard_normal((nb, m, n))
+    for mode, want in [(0, lambda L, Bm: np.linalg.solve(L, Bm.T).T), (1, lambda L, Bm: np.linalg.solve(L.T, Bm.T).T)]:
+        X = B.copy()
+        hostcheck.hostcheck_trsm(nb, m, n, P(ref), P(X), mode, 0)
+        assert relerr(X, np.stack([want(ref[b], B[b]) for b in range(nb)])) < 1e-12
+    Bl = np.tril(rng.standard_normal((nb, n, n)))
+    X = Bl.copy()
+    hostcheck.hostcheck_trsm(nb, n, n, P(ref), P(X), 1, 1)
+    want = np.stack([np.linalg.solve(ref[b].T, Bl[b].T).T for b in range(nb)])
+    assert relerr(np.tril(X), np.tril(want)) < 1e-12
+
+
+def test_not_positive_definite_is_reported(hostcheck):
+    n = 128
+    S = np.eye(n)[None].copy()
+    S[0, 70, 70] = -1.0
+    info = np.zeros(1, dtype=np.int32)
+    hostcheck.hostcheck_potrf(1, n, P(S), info.ctypes.data_as(ip))
+    assert info[0] == 71     # 1-based failing pivot
+
+
+def test_flop_model(hostcheck):
+    hostcheck.hostcheck_fit_flops.restype = ctypes.c_double
+    f = hostcheck.hostcheck_fit_flops(2000, 8, 2)
+    n3 = 2000.0 ** 3
+    assert abs(f - (2 * (14 / 3 * n3 + 2 * 2000 * 2000 * 8) + 13 / 3 * n3 + 2 * 2000 * 2000 * 8 + n3 / 3)) < 1.0

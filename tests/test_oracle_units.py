@@ -1,0 +1,92 @@
+"""Internal consistency of the oracle and the reference quirks it must keep."""
+import math
+
+import numpy as np
+
+from oracle import gp_oracle as go
+
+
+def test_hyper_gradient_matches_finite_differences():
+    data, _ = go.synthetic_ensemble(1, 40, R=4, seed=7)
+    X, y, nu = go.prologue(data[0])
+    st = go.FitState(40)
+    var, ls = 0.8, 1.3
+    K0, dK = go.kernel_matrix(X, var, ls)
+    L = np.linalg.cholesky(K0 + go.JITTER * np.eye(40))
+    go.natgrad_step(st, L, y, nu)
+    g = go.hyper_gradient(st, X, K0, dK, L, y, nu, var)
+
+    def loss(v, l):
+        K, _ = go.kernel_matrix(X, v, l)
+        return go.neg_elbo(st, np.linalg.cholesky(K + go.JITTER * np.eye(40)), y, nu)
+
+    h = 1e-6
+    fd = [(loss(var + h, ls) - loss(var - h, ls)) / (2 * h), (loss(var, ls + h) - loss(var, ls - h)) / (2 * h)]
+    assert np.allclose(g, fd, rtol=2e-5)
+
+
+def test_kernel_forms():
+    X = np.array([[0.0], [1.0], [3.0]])
+    for kern, f in [(go.KERNEL_MATERN32, lambda r: (1 + math.sqrt(3) * r) * math.exp(-math.sqrt(3) * r)),
+                    (go.KERNEL_MATERN52, lambda r: (1 + math.sqrt(5) * r + 5 * r * r / 3) * math.exp(-math.sqrt(5) * r)),
+                    (go.KERNEL_RBF, lambda r: math.exp(-0.5 * r * r))]:
+        K, dK = go.kernel_matrix(X, 2.0, 0.5, kern)
+        assert abs(K[0, 1] - 2.0 * f(2.0)) < 1e-14 and abs(K[0, 2] - 2.0 * f(6.0)) < 1e-14
+        h = 1e-6
+        Kp, _ = go.kernel_matrix(X, 2.0, 0.5 + h, kern)
+        Km, _ = go.kernel_matrix(X, 2.0, 0.5 - h, kern)
+        assert np.allclose(dK, (Kp - Km) / (2 * h), atol=1e-7)
+
+
+def test_barycentre_signed_convergence_quirk():
+    # S = sum w sigma <= 1  ->  one step, v = S (NOT S^2); S > 1 -> converges up to S^2   (wasserstein.py:85-91)
+    mu, sig, ok = go.gaussian_barycentre([0.0, 1.0], [0.5, 0.7], [0.5, 0.5])
+    assert ok and abs(sig ** 2 - 0.6) < 1e-15 and abs(mu - 0.5) < 1e-15
+    mu, sig, ok = go.gaussian_barycentre([0.0, 1.0], [2.0, 3.0], [0.5, 0.5])
+    assert ok and abs(sig ** 2 - 6.25) < 1e-4
+
+
+def test_loglik_weights_underflow_is_nan_like_the_reference():
+    ll = np.array([[-4000.0, -10.0], [-3000.0, -12.0]])
+    w, raw = go.loglik_weights(ll, 1.0)
+    assert np.isnan(w[:, 0]).all() and np.isfinite(w[:, 1]).all()
+    w, _ = go.loglik_weights(ll, 1e-3)
+    assert np.allclose(w.sum(axis=0), 1.0)
+
+
+def test_w2_temporal_equals_w2_of_1x1_gaussians():
+    rng = np.random.default_rng(1)
+    mean, var = rng.standard_normal((3, 4)), rng.uniform(0.1, 2.0, (3, 4))
+    w = go.w2_weights_temporal(mean, var)
+    D = np.zeros((3, 3, 4))
+    for i in range(3):
+        for j in range(3):
+            for t in range(4):
+                # dx.Normal(mean, scale=variance).variance() == variance**2
+                D[i, j, t] = go.gaussian_w2(mean[i, t:t + 1], np.diag([var[i, t] ** 2]),
+                                            mean[j, t:t + 1], np.diag([var[j, t] ** 2]))
+    v = D.mean(axis=1)
+    assert np.allclose(w, v / v.sum(axis=0, keepdims=True), atol=1e-12)
+
+
+def test_constvec_loglik_matches_dense_mvn():
+    rng = np.random.default_rng(2)
+    N = 6
+    A = rng.standard_normal((N, N))
+    cov = A @ A.T + N * np.eye(N)
+    mu = rng.standard_normal(N)
+    Lc, ld = go.mvn_factor(cov)
+    obs = rng.standard_normal((2, N))
+    ll = go.mvn_constvec_loglik(mu, Lc, ld, obs)
+    for r in range(2):
+        for t in range(N):
+            x = np.full(N, obs[r, t])
+            ref = -0.5 * (x - mu) @ np.linalg.solve(cov, x - mu) - 0.5 * np.linalg.slogdet(cov)[1] - 0.5 * N * go.LOG2PI
+            assert abs(ll[r, t] - ref) < 1e-10
+
+
+def test_synthetic_generator_is_deterministic():
+    d1, o1 = go.synthetic_ensemble(2, 16, R=3, R_obs=2)
+    d2, o2 = go.synthetic_ensemble(2, 16, R=3, R_obs=2)
+    assert np.array_equal(d1, d2) and np.array_equal(o1, o2)
+    assert abs(d1[0, 0, 0] - (-0.13108637)) < 1.0   # sanity: finite, O(0.1) noise around the signal
