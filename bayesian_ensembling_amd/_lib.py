@@ -61,6 +61,7 @@ def load():
     lib.bayens_timer_start.argtypes = [_vp]
     lib.bayens_timer_stop.argtypes = [_vp, _dp]
     lib.bayens_profile_enable.argtypes = [_vp, C.c_int]
+    lib.bayens_set_groups.argtypes = [_vp, C.c_int]
     lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -186,6 +187,10 @@ class Context:
         ms = C.c_double()
         self._check(self.lib.bayens_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+    def set_groups(self, n):
+        """Member groups (HIP streams) a fit batch is split over; 1 serialises every kernel."""
+        self._check(self.lib.bayens_set_groups(self.h, int(n)))
 
     def profile_enable(self, on=True):
         self._check(self.lib.bayens_profile_enable(self.h, 1 if on else 0))

@@ -3,8 +3,10 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bayens.h"
@@ -58,8 +60,11 @@ struct bayens_ctx {
   // fit workspace (grown on demand)
   FitWorkspace ws;
   std::vector<void*> ws_allocs;
-  // generic device scratch for host-staged calls
-  std::vector<void*> temps;
+  // member groups: the batch of a fit is split over `gstreams` HIP streams (one host thread each) so that the
+  // low-parallelism steps of one group (64x64 diagonal blocks, narrow panels) overlap the big GEMMs of the others
+  std::vector<hipStream_t> gstreams;
+  std::vector<HipPrims*> gprims;
+  int ngroups = 1;
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -105,7 +110,8 @@ void ensure_ws(bayens_ctx* c, int nb, int Np) {
   w.nb = nb; w.Np = Np;
   const size_t msz = (size_t)nb * Np * Np * sizeof(double);
   auto mat = [&]() { return Mat{(double*)dalloc(msz), Np, (long)Np * Np}; };
-  w.K0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T1 = mat(); w.T2 = mat();
+  w.K0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T2 = mat();
+  w.T1 = Mat{(double*)dalloc((size_t)nb * (Np + LEAF) * Np * sizeof(double)), Np, (long)(Np + LEAF) * Np};
   const size_t isz = (size_t)nb * Np * LEAF * sizeof(double);
   w.invL = (double*)dalloc(isz); w.invC = (double*)dalloc(isz);
   const size_t vsz = (size_t)nb * Np * sizeof(double);
@@ -115,11 +121,46 @@ void ensure_ws(bayens_ctx* c, int nb, int Np) {
   w.info = (int*)dalloc((size_t)nb * sizeof(int));
 }
 
-// a workspace view for a batch smaller than the allocated one
-FitWorkspace ws_view(bayens_ctx* c, int nb) {
+// a workspace view for members [b0, b0 + nb) of the allocated batch
+FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) {
   FitWorkspace v = c->ws;
   v.nb = nb;
+  for (Mat* m : {&v.K0, &v.Lb, &v.Lam, &v.Cb, &v.T1, &v.T2}) m->p += (long)b0 * m->stride;
+  const long is = v.inv_stride();
+  v.invL += b0 * is; v.invC += b0 * is;
+  for (double** p : {&v.theta1, &v.mvec, &v.avec, &v.y, &v.nu, &v.muvec}) *p += (long)b0 * v.Np;
+  v.ustate += (long)b0 * 8;
+  v.info += b0;
   return v;
+}
+
+// Runs the fit of B resident members split into groups, one HIP stream + host thread per group.
+void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
+                   double* dmu, double* dcov, double* dchol, double* dld, double* dhyp) {
+  const int N = fp.N, R = fp.R;
+  const int G = std::max(1, std::min(std::min(c->ngroups, (int)c->gstreams.size()), B));
+  BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
+  std::vector<std::thread> th;
+  std::vector<HipError> errs(G, HipError{0, ""});
+  for (int g = 0; g < G; ++g) {
+    const int b0 = (int)((long)B * g / G), b1 = (int)((long)B * (g + 1) / G);
+    if (b1 <= b0) continue;
+    th.emplace_back([=, &errs]() {
+      try {
+        BAYENS_HIP(hipSetDevice(c->device));
+        FitWorkspace w = ws_view(c, b0, b1 - b0);
+        gp_fit(*c->gprims[g], w, fp, dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
+               dmu + (size_t)b0 * N, dcov + (size_t)b0 * N * N, dchol ? dchol + (size_t)b0 * N * N : nullptr,
+               dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr);
+        BAYENS_HIP(hipStreamSynchronize(c->gstreams[g]));
+      } catch (const HipError& e) {
+        errs[g] = e;
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e.code != 0) throw e;
 }
 
 // host staging helpers ------------------------------------------------------------------------
@@ -184,6 +225,14 @@ int bayens_ctx_create(int device, bayens_ctx** out) {
   (void)hipEventCreate(&c->t0);
   (void)hipEventCreate(&c->t1);
   c->prims = new HipPrims(c->stream);
+  if (const char* env = getenv("BAYENS_STREAMS")) c->ngroups = std::max(1, std::min(16, atoi(env)));
+  for (int g = 0; g < 16; ++g) {
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { bayens_ctx_destroy(c); return (int)e; }
+    c->gstreams.push_back(s);
+    c->gprims.push_back(new HipPrims(s));
+  }
   *out = c;
   return 0;
 }
@@ -194,6 +243,8 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && c->rccl.CommDestroy) c->rccl.CommDestroy(c->comm);
   free_ws(c);
+  for (auto* p : c->gprims) delete p;
+  for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   delete c->prims;
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
@@ -253,31 +304,48 @@ int bayens_timer_stop(bayens_ctx* c, double* ms) {
 }
 int bayens_profile_enable(bayens_ctx* c, int on) {
   return guarded(c, [&]() {
-    BAYENS_HIP(hipStreamSynchronize(c->stream));
-    KernelProfile& p = c->prims->prof;
-    for (auto& e : p.events) { p.pool.push_back(e.first); p.pool.push_back(e.second); }
-    p.events.clear();
-    p.flop = 0; p.launches = 0;
-    p.enabled = on != 0;
+    BAYENS_HIP(hipDeviceSynchronize());
+    std::vector<HipPrims*> all = c->gprims;
+    all.push_back(c->prims);
+    for (HipPrims* hp : all) {
+      KernelProfile& p = hp->prof;
+      for (auto& e : p.events) { p.pool.push_back(e.first); p.pool.push_back(e.second); }
+      p.events.clear();
+      p.flop = 0; p.launches = 0;
+      p.enabled = on != 0;
+    }
     return 0;
   });
 }
 int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long* launches) {
   return guarded(c, [&]() {
     if (family != 0) return fail(c, BAYENS_E_ARG, "unknown kernel family");
-    BAYENS_HIP(hipStreamSynchronize(c->stream));
-    KernelProfile& p = c->prims->prof;
-    double tot = 0;
-    for (auto& e : p.events) {
-      float f = 0;
-      BAYENS_HIP(hipEventElapsedTime(&f, e.first, e.second));
-      tot += f;
+    BAYENS_HIP(hipDeviceSynchronize());
+    std::vector<HipPrims*> all = c->gprims;
+    all.push_back(c->prims);
+    double tot = 0, fl = 0;
+    long n = 0;
+    for (HipPrims* hp : all) {
+      KernelProfile& p = hp->prof;
+      for (auto& e : p.events) {
+        float f = 0;
+        BAYENS_HIP(hipEventElapsedTime(&f, e.first, e.second));
+        tot += f;
+      }
+      fl += p.flop;
+      n += p.launches;
     }
     if (ms) *ms = tot;
-    if (flop) *flop = p.flop;
-    if (launches) *launches = p.launches;
+    if (flop) *flop = fl;
+    if (launches) *launches = n;
     return 0;
   });
+}
+
+int bayens_set_groups(bayens_ctx* c, int n_groups) {
+  if (!c || n_groups < 1 || n_groups > 16) return BAYENS_E_ARG;
+  c->ngroups = n_groups;
+  return 0;
 }
 
 int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
@@ -290,7 +358,6 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
     if (loss_trace) return fail(c, BAYENS_E_ARG, "gp_fit_batch: loss_trace is not produced by this version (pass NULL)");
     const int Np = pad_to_leaf(N);
-    if ((size_t)2 * Np * sizeof(double) > 128 * 1024) return fail(c, BAYENS_E_ARG, "gp_fit_batch: N too large");
     ensure_ws(c, B, Np);
     Stage st(c, loc);
     const double* dX = st.in(X, (size_t)B * N * R);
@@ -301,11 +368,10 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     double* dchol = st.out(cov_chol, (size_t)B * N * N);
     double* dld = st.out(logdet, (size_t)B);
     double* dhyp = st.out(hyp, (size_t)B * 2);
-    FitWorkspace w = ws_view(c, B);
     FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
-    gp_fit(*c->prims, w, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp);
+    fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp);
     std::vector<int> hinfo(B, 0);
-    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), w.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();
     int bad = 0;
     for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
@@ -324,7 +390,7 @@ int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* 
     const double* dcov = st.in(cov, (size_t)B * N * N);
     double* dchol = st.out(chol, (size_t)B * N * N);
     double* dld = st.out(logdet, (size_t)B);
-    FitWorkspace w = ws_view(c, B);
+    FitWorkspace w = ws_view(c, 0, B);
     BAYENS_HIP(hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), c->stream));
     c->prims->pad_in(B, N, Np, dcov, w.T1);
     mvn_factor(*c->prims, w, N, dchol, dld);

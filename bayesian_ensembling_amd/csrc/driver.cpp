@@ -93,11 +93,13 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     P.theta_update(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, ws.theta1);
     P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
-    P.trsv2(nb, Np, ws.Cb, ws.invC, is, ws.theta1, ws.mvec);          // m = Lam^-1 theta1
-    // Adam step on the hypers with (m, S) fixed: Cholesky-backward of the data term  (models.py:210)
+    // [L; theta1^T] C^-T C^-1 = [L S; m^T]: the variational mean m = Lam^-1 theta1 rides through the two
+    // solves that produce L S for the Adam step (models.py:210) as one extra row block of the right-hand side
     P.copy(nb, Np, ws.Lb, ws.T1);
-    trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);               // L C^-T
-    trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1, false);        // L C^-T C^-1 = L S
+    P.aug_set(nb, Np, ws.T1.sub(Np, 0), ws.theta1);
+    trsm_rlt(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1);        // [L; theta1^T] C^-T
+    trsm_rln(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1, false); // ... C^-1
+    P.aug_get(nb, Np, ws.T1.sub(Np, 0), ws.mvec);                     // m
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
     P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))
     P.gemm(nb, Np, Np, Np, 1.0, ws.Lb, ws.T1, 0.0, ws.T2,

@@ -18,7 +18,7 @@ inline int pad_to_leaf(int n) { return ((n + LEAF - 1) / LEAF) * LEAF; }
 // Device workspace for a batch of nb members of padded size Np (all pointers device pointers).
 struct FitWorkspace {
   int nb = 0, Np = 0;
-  Mat K0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each
+  Mat K0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each; T1 carries LEAF extra rows ([nb][Np+64][Np])
   double* invL = nullptr;          // [nb][Np/64][64][64]
   double* invC = nullptr;
   double* theta1 = nullptr;        // [nb][Np]

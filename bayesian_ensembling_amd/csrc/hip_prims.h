@@ -56,8 +56,8 @@ struct HipPrims : Prims {
   void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
   void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
                     double* theta1) override;
-  void trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1,
-             double* mvec) override;
+  void aug_set(int nb, int n, Mat rows, const double* vec) override;
+  void aug_get(int nb, int n, Mat rows, double* vec) override;
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
   void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override;
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,

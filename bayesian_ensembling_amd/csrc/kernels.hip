@@ -426,57 +426,20 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const doub
   if (lane == 0) out[(long)b * n + i] = s - (sub ? sub[(long)b * n + i] : 0.0);
 }
 
-// m = C^-T C^-1 theta1 with the inverted 64x64 diagonal blocks of C: one workgroup per member, blocked
-// forward then backward substitution (z and m live in dynamic LDS).
-__global__ __launch_bounds__(256) void trsv2_kernel(int n, Mat C, const double* invC, long inv_stride,
-                                                    const double* theta1, double* mvec) {
-  extern __shared__ double lds[];
-  double* z = lds;            // [n]
-  double* mm = lds + n;       // [n]
-  __shared__ double rblk[64];
-  __shared__ double part[4][64];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double* c = C.p + b * C.stride;
-  const double* iv = invC + b * inv_stride;
-  const int nl = n / 64;
-  // forward: C z = theta1
-  for (int jb = 0; jb < nl; ++jb) {
-    const int base = jb * 64;
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = base + w * 16 + rr;
-      double s = 0.0;
-      for (int k = lane; k < base; k += 64) s += c[(long)row * C.ld + k] * z[k];
-      s = wave_sum(s);
-      if (lane == 0) rblk[w * 16 + rr] = theta1[(long)b * n + row] - s;
-    }
-    __syncthreads();
-    for (int rr = 0; rr < 16; ++rr) {
-      const int rl = w * 16 + rr;
-      double s = iv[(long)jb * 4096 + rl * 64 + lane] * rblk[lane];   // inverse is lower: zeros for lane > rl
-      s = wave_sum(s);
-      if (lane == 0) z[base + rl] = s;
-    }
-    __syncthreads();
-  }
-  // backward: C^T m = z
-  for (int jb = nl - 1; jb >= 0; --jb) {
-    const int base = jb * 64;
-    double s = 0.0;
-    for (int k = base + 64 + w; k < n; k += 4) s += c[(long)k * C.ld + base + lane] * mm[k];
-    part[w][lane] = s;
-    __syncthreads();
-    if (w == 0) rblk[lane] = z[base + lane] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    __syncthreads();
-    // m_blk = inv^T r : m[cidx] = sum_k inv[k][cidx] r[k]
-    double t = 0.0;
-    for (int k = w; k < 64; k += 4) t += iv[(long)jb * 4096 + k * 64 + lane] * rblk[k];
-    part[w][lane] = t;
-    __syncthreads();
-    if (w == 0) mm[base + lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    __syncthreads();
-  }
-  for (int i = threadIdx.x; i < n; i += 256) mvec[(long)b * n + i] = mm[i];
+// the 64-row block appended to a right-hand side (prims.h aug_set / aug_get)
+__global__ void aug_set_kernel(int n, Mat rows, const double* vec) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double* r = rows.p + b * rows.stride;
+  r[j] = vec[(long)b * n + j];
+  for (int q = 1; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
+}
+
+__global__ void aug_get_kernel(int n, Mat rows, double* vec) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) vec[(long)b * n + j] = rows.p[b * rows.stride + j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,12 +698,12 @@ void HipPrims::theta_update(int nb, int n, Mat L, const double* y, const double*
   hipLaunchKernelGGL(theta_update_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, y, nu, gamma, theta1);
   LAUNCH_CHECK();
 }
-void HipPrims::trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1, double* mvec) {
-  size_t lds = (size_t)2 * n * sizeof(double);
-  if (lds > 128 * 1024) throw HipError{-1, "trsv2: N too large for the LDS-resident substitution"};
-  if (lds > 48 * 1024)
-    BAYENS_HIP(hipFuncSetAttribute((const void*)trsv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(trsv2_kernel, dim3(nb), dim3(256), lds, stream, n, C, invC, inv_stride, theta1, mvec);
+void HipPrims::aug_set(int nb, int n, Mat rows, const double* vec) {
+  hipLaunchKernelGGL(aug_set_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
+  LAUNCH_CHECK();
+}
+void HipPrims::aug_get(int nb, int n, Mat rows, double* vec) {
+  hipLaunchKernelGGL(aug_get_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
   LAUNCH_CHECK();
 }
 void HipPrims::resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) {

@@ -65,9 +65,10 @@ struct Prims {
   // theta1 = (1-gamma) theta1 + gamma * L^T (y / nu)
   virtual void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
                             double* theta1) = 0;
-  // m = C^-T C^-1 theta1, using the inverted diagonal blocks of C
-  virtual void trsv2(int nb, int n, Mat C, const double* invC, long inv_stride, const double* theta1,
-                     double* mvec) = 0;
+  // a 64-row block appended below an n x n right-hand side: row 0 carries a vector through the same
+  // triangular solves (x^T C^-T C^-1 = (C^-T C^-1 x)^T), rows 1..63 are zero
+  virtual void aug_set(int nb, int n, Mat rows, const double* vec) = 0;   // rows[0][:] = vec, others 0
+  virtual void aug_get(int nb, int n, Mat rows, double* vec) = 0;         // vec = rows[0][:]
   virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
   // X_ij <- (i >= j) ? (a_i m_j + X_ij) / nu_i : 0
   virtual void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) = 0;

@@ -57,6 +57,12 @@ int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
 int bayens_profile_enable(bayens_ctx* ctx, int on);
 int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
 
+/* Number of member groups (HIP streams + host threads) a fit batch is split over; 1 = one stream, kernels
+ * run strictly one after the other (what the per-kernel roofline measurement uses).  Default 1
+ * (env BAYENS_STREAMS at context creation), at most 16.  Measured on MI355X at 32 x 2000: 2 groups tie
+ * with 1, 4 and 8 groups are slower (profiles/r01_groups_sweep.txt), so the default stays 1. */
+int bayens_set_groups(bayens_ctx* ctx, int n_groups);
+
 /* ---- the hot path ------------------------------------------------------------------------- */
 
 /* GPDTW1D.fit after the DTW-barycentre stage, for B independent members at once

@@ -164,21 +164,14 @@ struct CpuPrims : Prims {
         theta1[(size_t)b * n + j] = (1 - gamma) * theta1[(size_t)b * n + j] + gamma * s;
       }
   }
-  void trsv2(int nb, int n, Mat C, const double*, long, const double* theta1, double* mvec) override {
-    std::vector<double> z(n);
-    for (int b = 0; b < nb; ++b) {
-      const double* c = C.p + b * C.stride;
-      for (int i = 0; i < n; ++i) {
-        double s = theta1[(size_t)b * n + i];
-        for (int k = 0; k < i; ++k) s -= c[(size_t)i * C.ld + k] * z[k];
-        z[i] = s / c[(size_t)i * C.ld + i];
-      }
-      for (int i = n - 1; i >= 0; --i) {
-        double s = z[i];
-        for (int k = i + 1; k < n; ++k) s -= c[(size_t)k * C.ld + i] * mvec[(size_t)b * n + k];
-        mvec[(size_t)b * n + i] = s / c[(size_t)i * C.ld + i];
-      }
-    }
+  void aug_set(int nb, int n, Mat rows, const double* vec) override {
+    for (int b = 0; b < nb; ++b)
+      for (int r = 0; r < LEAF; ++r)
+        for (int j = 0; j < n; ++j) rows.p[b * rows.stride + (size_t)r * rows.ld + j] = r == 0 ? vec[(size_t)b * n + j] : 0.0;
+  }
+  void aug_get(int nb, int n, Mat rows, double* vec) override {
+    for (int b = 0; b < nb; ++b)
+      for (int j = 0; j < n; ++j) vec[(size_t)b * n + j] = rows.p[b * rows.stride + j];
   }
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override {
     for (int b = 0; b < nb; ++b)
@@ -271,7 +264,8 @@ struct HostWs {
   HostWs(int nb, int Np) {
     ws.nb = nb; ws.Np = Np;
     auto mat = [&]() { return Mat{alloc((size_t)nb * Np * Np), Np, (long)Np * Np}; };
-    ws.K0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T1 = mat(); ws.T2 = mat();
+    ws.K0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T2 = mat();
+    ws.T1 = Mat{alloc((size_t)nb * (Np + LEAF) * Np), Np, (long)(Np + LEAF) * Np};
     ws.invL = alloc((size_t)nb * Np * LEAF); ws.invC = alloc((size_t)nb * Np * LEAF);
     ws.theta1 = alloc((size_t)nb * Np); ws.mvec = alloc((size_t)nb * Np); ws.avec = alloc((size_t)nb * Np);
     ws.y = alloc((size_t)nb * Np); ws.nu = alloc((size_t)nb * Np); ws.muvec = alloc((size_t)nb * Np);
