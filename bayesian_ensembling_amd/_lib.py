@@ -64,8 +64,9 @@ def load():
     lib.bayens_set_groups.argtypes = [_vp, C.c_int]
     lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
-                                        C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
-    lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+                                        C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
@@ -212,34 +213,52 @@ class Context:
         chol = np.empty((B, N, N)) if want_chol else None
         logdet = np.empty(B) if want_chol else None
         hyp = np.empty((B, 2))
+        basis = np.empty((B, 2, N)) if want_chol else None
         info = np.zeros(B, dtype=np.int32)
         rc = self.lib.bayens_gp_fit_batch(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
-                                          _ptr(logdet), _ptr(hyp), None, _ptr(info))
+                                          _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
         if rc != 0:
             err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
             err.info = info
             raise err
-        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info}
+        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis}
 
     def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
-                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
+                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None):
         info = np.zeros(B, dtype=np.int32)
         rc = self.lib.bayens_gp_fit_batch(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
-                                          _ptr(logdet), _ptr(hyp), None, _ptr(info))
+                                          _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
         self._check(rc)
         return info
 
-    def mvn_factor_batch(self, cov):
+    def mvn_factor_batch(self, cov, mu=None):
+        """chol, logdet (and, with mu, the log-likelihood basis) of caller-supplied covariances."""
         cov = _f64(cov)
         B, N, _ = cov.shape
         chol = np.empty((B, N, N))
         logdet = np.empty(B)
         info = np.zeros(B, dtype=np.int32)
-        self._check(self.lib.bayens_mvn_factor_batch(self.h, HOST, B, N, _ptr(cov), _ptr(chol), _ptr(logdet),
-                                                     _ptr(info)))
-        return chol, logdet
+        basis = None
+        if mu is not None:
+            mu = _f64(mu).reshape(B, N)
+            basis = np.empty((B, 2, N))
+        self._check(self.lib.bayens_mvn_factor_batch(self.h, HOST, B, N, _ptr(cov), _ptr(mu), _ptr(chol), _ptr(logdet),
+                                                     _ptr(basis), _ptr(info)))
+        return (chol, logdet, basis) if mu is not None else (chol, logdet)
+
+    def loglik_rows_basis(self, basis, logdet, obs):
+        basis, logdet, obs = _f64(basis), _f64(logdet), _f64(obs)
+        B, _, N = basis.shape
+        out = np.empty((B, N))
+        self._check(self.lib.bayens_loglik_rows_basis(self.h, HOST, B, N, obs.shape[0], _ptr(basis), _ptr(logdet),
+                                                      _ptr(obs), _ptr(out)))
+        return out
+
+    def loglik_rows_basis_dev(self, B, N, R_obs, basis, logdet, obs, ll_mean):
+        self._check(self.lib.bayens_loglik_rows_basis(self.h, DEVICE, B, N, R_obs, _ptr(basis), _ptr(logdet),
+                                                      _ptr(obs), _ptr(ll_mean)))
 
     def extract_diag(self, cov):
         cov = _f64(cov)

@@ -65,6 +65,17 @@ struct bayens_ctx {
   std::vector<hipStream_t> gstreams;
   std::vector<HipPrims*> gprims;
   int ngroups = 1;
+  double* sscratch = nullptr;      // small persistent device scratch (per-member scalars)
+  size_t sscratch_cap = 0;
+  double* small_scratch(size_t count) {
+    if (count > sscratch_cap) {
+      if (sscratch) (void)hipFree(sscratch);
+      sscratch = nullptr;
+      if (hipMalloc((void**)&sscratch, count * sizeof(double)) != hipSuccess) throw HipError{BAYENS_E_ALLOC, "hipMalloc"};
+      sscratch_cap = count;
+    }
+    return sscratch;
+  }
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -136,7 +147,7 @@ FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) {
 
 // Runs the fit of B resident members split into groups, one HIP stream + host thread per group.
 void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
-                   double* dmu, double* dcov, double* dchol, double* dld, double* dhyp) {
+                   double* dmu, double* dcov, double* dchol, double* dld, double* dhyp, double* dbasis) {
   const int N = fp.N, R = fp.R;
   const int G = std::max(1, std::min(std::min(c->ngroups, (int)c->gstreams.size()), B));
   BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
@@ -151,7 +162,8 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
         FitWorkspace w = ws_view(c, b0, b1 - b0);
         gp_fit(*c->gprims[g], w, fp, dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
                dmu + (size_t)b0 * N, dcov + (size_t)b0 * N * N, dchol ? dchol + (size_t)b0 * N * N : nullptr,
-               dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr);
+               dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr,
+               dbasis ? dbasis + (size_t)b0 * 2 * N : nullptr);
         BAYENS_HIP(hipStreamSynchronize(c->gstreams[g]));
       } catch (const HipError& e) {
         errs[g] = e;
@@ -243,6 +255,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && c->rccl.CommDestroy) c->rccl.CommDestroy(c->comm);
   free_ws(c);
+  if (c->sscratch) (void)hipFree(c->sscratch);
   for (auto* p : c->gprims) delete p;
   for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   delete c->prims;
@@ -351,7 +364,7 @@ int bayens_set_groups(bayens_ctx* c, int n_groups) {
 int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
                         const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
                         double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
-                        double* loss_trace, int* info) {
+                        double* loss_trace, int* info, double* ll_basis) {
   return guarded(c, [&]() {
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch: bad argument");
@@ -368,8 +381,9 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     double* dchol = st.out(cov_chol, (size_t)B * N * N);
     double* dld = st.out(logdet, (size_t)B);
     double* dhyp = st.out(hyp, (size_t)B * 2);
+    double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
     FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
-    fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp);
+    fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
     std::vector<int> hinfo(B, 0);
     BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();
@@ -380,8 +394,8 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
   });
 }
 
-int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* cov, double* chol, double* logdet,
-                            int* info) {
+int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* cov, const double* mu, double* chol,
+                            double* logdet, double* ll_basis, int* info) {
   return guarded(c, [&]() {
     if (B <= 0 || N <= 0 || !cov) return fail(c, BAYENS_E_ARG, "mvn_factor_batch: bad argument");
     const int Np = pad_to_leaf(N);
@@ -390,10 +404,14 @@ int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* 
     const double* dcov = st.in(cov, (size_t)B * N * N);
     double* dchol = st.out(chol, (size_t)B * N * N);
     double* dld = st.out(logdet, (size_t)B);
+    if (ll_basis && !mu) return fail(c, BAYENS_E_ARG, "mvn_factor_batch: ll_basis needs mu");
+    const double* dmu = st.in(mu, (size_t)B * N);
+    double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
     FitWorkspace w = ws_view(c, 0, B);
     BAYENS_HIP(hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), c->stream));
-    c->prims->pad_in(B, N, Np, dcov, w.T1);
-    mvn_factor(*c->prims, w, N, dchol, dld);
+    c->prims->pad_in(B, N, Np, dcov, w.T2);
+    if (dbasis) c->prims->pad_vec(B, N, Np, dmu, w.muvec);
+    mvn_factor(*c->prims, w, N, w.muvec, dchol, dld, dbasis);
     std::vector<int> hinfo(B, 0);
     BAYENS_HIP(hipMemcpyAsync(hinfo.data(), w.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();
@@ -429,6 +447,22 @@ int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const do
     double* dll = st.out(ll_mean, (size_t)B * N);
     double* ac = st.scratch<double>((size_t)B * 2 * N);
     c->prims->loglik_rows(B, N, R_obs, dmu, dch, dld, dobs, dll, ac);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_loglik_rows_basis(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* ll_basis,
+                             const double* logdet, const double* obs, double* ll_mean) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R_obs <= 0 || !ll_basis || !logdet || !obs || !ll_mean)
+      return fail(c, BAYENS_E_ARG, "loglik_rows_basis: bad argument");
+    Stage st(c, loc);
+    const double* db = st.in(ll_basis, (size_t)B * 2 * N);
+    const double* dld = st.in(logdet, (size_t)B);
+    const double* dobs = st.in(obs, (size_t)R_obs * N);
+    double* dll = st.out(ll_mean, (size_t)B * N);
+    c->prims->loglik_rows_basis(B, N, R_obs, db, dld, dobs, dll, c->small_scratch((size_t)B * 3));
     st.finish();
     return 0;
   });

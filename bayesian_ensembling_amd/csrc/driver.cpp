@@ -53,26 +53,48 @@ void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv
   trsm_rln_rec(P, nb, m, n, L, inv, inv_stride, B, rhs_lower, 0);
 }
 
-static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int base) {
+// Blocked Cholesky with `extra` rows appended below the matrix (rows n .. n+extra-1 of the same buffer).  The
+// panel solves and trailing updates that factor A also carry the appended rows E to E L^-T (the bordered-matrix
+// identity), which is how L_c^-1 1 and L_c^-1 mu are obtained without a separate triangular solve.
+static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int base,
+                      int extra) {
   if (n == LEAF) {
     P.potrf_leaf(nb, A, inv, inv_stride, base, info);
+    if (extra > 0) {
+      Mat I{inv, LEAF, inv_stride};
+      P.gemm(nb, extra, LEAF, LEAF, 1.0, A.sub(LEAF, 0), I, 0.0, A.sub(LEAF, 0), GEMM_TB, 0.0);
+    }
     return;
   }
   int n1 = split_point(n), n2 = n - n1;
-  potrf_rec(P, nb, n1, A, inv, inv_stride, info, base);
-  // L21 = A21 L11^-T
-  trsm_rlt(P, nb, n2, n1, A, inv, inv_stride, A.sub(n1, 0));
-  // A22 -= L21 L21^T   (lower 64-blocks only)
-  P.gemm(nb, n2, n2, n1, -1.0, A.sub(n1, 0), A.sub(n1, 0), 1.0, A.sub(n1, n1), GEMM_TB | GEMM_TRI_OUT, 0.0);
-  potrf_rec(P, nb, n2, A.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, info, base + n1);
+  potrf_rec(P, nb, n1, A, inv, inv_stride, info, base, 0);
+  // [L21; E1] = [A21; E1] L11^-T
+  trsm_rlt(P, nb, n2 + extra, n1, A, inv, inv_stride, A.sub(n1, 0));
+  // [A22; E2] -= [L21; E1] L21^T   (lower 64-blocks only; the appended rows lie below every column block)
+  P.gemm(nb, n2 + extra, n2, n1, -1.0, A.sub(n1, 0), A.sub(n1, 0), 1.0, A.sub(n1, n1), GEMM_TB | GEMM_TRI_OUT, 0.0);
+  potrf_rec(P, nb, n2, A.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, info, base + n1, extra);
 }
 
-void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info) {
-  potrf_rec(P, nb, n, A, inv, inv_stride, info, 0);
+void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows) {
+  potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+}
+
+// chol(cov) + logdet + the log-likelihood basis (L_c^-1 1, L_c^-1 mu), covariance (lower part valid) in `src`
+static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const double* mu_pad, double* chol,
+                              double* logdet, double* basis) {
+  const int nb = ws.nb, Np = ws.Np;
+  P.tri_copy(nb, Np, src, ws.T1);
+  const int extra = basis ? LEAF : 0;
+  if (basis) P.basis_rows_set(nb, N, Np, ws.T1.sub(Np, 0), mu_pad);     // row 0 = 1 (first N), row 1 = mu
+  potrf(P, nb, Np, ws.T1, ws.invL, ws.inv_stride(), ws.info, extra);
+  if (chol) P.extract(nb, N, ws.T1, chol, 2);
+  if (logdet) P.logdet(nb, N, ws.T1, logdet);
+  if (basis) P.basis_rows_get(nb, N, Np, ws.T1.sub(Np, 0), basis);
 }
 
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
-            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp) {
+            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp,
+            double* basis) {
   const int nb = ws.nb, Np = ws.Np, N = fp.N;
   const long is = ws.inv_stride();
   P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info);
@@ -124,22 +146,16 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   P.gemm(nb, Np, Np, Np, -1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
   P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
   P.extract(nb, N, ws.Lam, cov, 1);
-  if (chol || logdet) {
+  if (chol || logdet || basis) {
     // Distribution.__post_init__ : distrax caches chol(cov) and its log-determinant  (data.py:38-39)
-    P.tri_copy(nb, Np, ws.Lam, ws.T1);
-    potrf(P, nb, Np, ws.T1, ws.invL, is, ws.info);
-    if (chol) P.extract(nb, N, ws.T1, chol, 2);
-    if (logdet) P.logdet(nb, N, ws.T1, logdet);
+    factor_with_basis(P, ws, N, ws.Lam, ws.muvec, chol, logdet, basis);
   }
   if (hyp) P.hyp_out(nb, ws.ustate, hyp);
 }
 
-void mvn_factor(Prims& P, FitWorkspace& ws, int N, double* chol, double* logdet) {
-  const int nb = ws.nb, Np = ws.Np;
-  P.tri_copy(nb, Np, ws.T1, ws.T2);
-  potrf(P, nb, Np, ws.T2, ws.invL, ws.inv_stride(), ws.info);
-  if (chol) P.extract(nb, N, ws.T2, chol, 2);
-  if (logdet) P.logdet(nb, N, ws.T2, logdet);
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
+                double* basis) {
+  factor_with_basis(P, ws, N, ws.T2, mu_pad, chol, logdet, basis);
 }
 
 double fit_flops(int N, int R, int n_iters) {

@@ -35,7 +35,8 @@ struct FitWorkspace {
 // Blocked Cholesky (lower, in place) of the n x n matrices A; inv receives the inverted diagonal blocks
 // ([leaf][64][64] per member, leaf index relative to A's first row).  A's strictly-upper 64-blocks are
 // never touched (callers keep them zero).
-void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info);
+// extra_rows (0 or a multiple of 64) rows stored directly below A in the same buffer are carried to E L^-T.
+void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows = 0);
 
 // B[m x n] <- B * L^-T  (solve X L^T = B), L n x n lower with inverted diagonal blocks in inv.
 void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B);
@@ -51,12 +52,15 @@ struct FitParams {
 
 // Runs the whole fit on resident inputs.  X [nb][N][R], y_in/nu_in [nb][N] (compact, device).
 // Outputs (device, compact): mu [nb][N], cov [nb][N][N], chol (nullable), logdet (nullable, [nb]),
-// hyp (nullable, [nb][2]).  info: ws.info (device).
+// hyp (nullable, [nb][2]), basis (nullable, [nb][2][N]: L_c^-1 1 and L_c^-1 mu, the two vectors every
+// constant-vector log-likelihood of the posterior needs).  info: ws.info (device).
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
-            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp);
+            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp,
+            double* basis);
 
-// chol/logdet of caller-supplied covariances already placed (padded, full) in ws.T1.
-void mvn_factor(Prims& P, FitWorkspace& ws, int N, double* chol, double* logdet);
+// chol/logdet/basis of caller-supplied covariances already placed (padded, full) in ws.T2; mu_pad [nb][Np].
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
+                double* basis);
 
 // Algorithmic flop of one member fit (2 flop per FMA, triangular structure exploited).
 double fit_flops(int N, int R, int n_iters);

@@ -58,6 +58,8 @@ struct HipPrims : Prims {
                     double* theta1) override;
   void aug_set(int nb, int n, Mat rows, const double* vec) override;
   void aug_get(int nb, int n, Mat rows, double* vec) override;
+  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) override;
+  void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override;
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
   void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override;
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
@@ -71,10 +73,14 @@ struct HipPrims : Prims {
 
   // not part of the driver interface: pad a compact [nb][N][N] matrix into a padded Mat (identity pad)
   void pad_in(int nb, int N, int Np, const double* src, Mat dst);
+  void pad_vec(int nb, int N, int Np, const double* src, double* dst);   // [nb][N] -> [nb][Np], zero pad
 
   // weights / weighted-posterior kernels (compact layouts, see include/bayens.h)
   void loglik_rows(int B, int N, int R_obs, const double* mu, const double* chol, const double* logdet,
                    const double* obs, double* ll_mean, double* scratch_ac /*[B][2][N]*/);
+  // same rows from the precomputed basis [B][2][N] (L_c^-1 1, L_c^-1 mu); dots: scratch [B][3]
+  void loglik_rows_basis(int B, int N, int R_obs, const double* basis, const double* logdet, const double* obs,
+                         double* ll_mean, double* dots);
   void normal_loglik_rows(int B, int N, int R_obs, const double* mu, const double* scale,
                           const double* obs, double* ll_mean);
   void weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw);

@@ -183,6 +183,12 @@ __global__ void pad_in_kernel(int N, int Np, const double* src, Mat dst) {
   }
 }
 
+__global__ void pad_vec_kernel(int N, int Np, const double* src, double* dst) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Np) dst[(long)b * Np + i] = i < N ? src[(long)b * N + i] : 0.0;
+}
+
 __global__ void extract_vec_kernel(int N, int Np, const double* src, double* dst) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -505,6 +511,64 @@ __global__ __launch_bounds__(256) void trsv_fwd2_kernel(int N, const double* cho
   }
 }
 
+// rows appended to the covariance factorisation (prims.h basis_rows_set / _get)
+__global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const double* mu_pad) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Np) return;
+  double* r = rows.p + b * rows.stride;
+  r[j] = j < N ? 1.0 : 0.0;
+  r[(long)rows.ld + j] = j < N ? mu_pad[(long)b * Np + j] : 0.0;
+  for (int q = 2; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
+}
+
+__global__ void basis_rows_get_kernel(int N, Mat rows, double* basis) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const double* r = rows.p + b * rows.stride;
+  basis[((long)b * 2) * N + j] = r[j];
+  basis[((long)b * 2 + 1) * N + j] = r[(long)rows.ld + j];
+}
+
+// (a.a, a.c, c.c) of the log-likelihood basis a = L_c^-1 1, c = L_c^-1 mu: one workgroup per member,
+// fixed-order tree reduction (deterministic)
+__global__ __launch_bounds__(256) void basis_dots_kernel(int N, const double* basis, double* dots) {
+  __shared__ double red[3][256];
+  const int b = blockIdx.x;
+  const double* a = basis + ((long)b * 2) * N;
+  const double* c = a + N;
+  double aa = 0.0, ac = 0.0, cc = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const double ai = a[i], ci = c[i];
+    aa += ai * ai; ac += ai * ci; cc += ci * ci;
+  }
+  red[0][threadIdx.x] = aa; red[1][threadIdx.x] = ac; red[2][threadIdx.x] = cc;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2)
+      for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) dots[b * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// weights.py:98-104 from the basis: ||x a - c||^2 = x^2 a.a - 2 x a.c + c.c ; mean over realisations
+__global__ void loglik_basis_kernel(int N, int R_obs, const double* dots, const double* logdet, const double* obs,
+                                    double* ll_mean) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const double aa = dots[b * 3], ac = dots[b * 3 + 1], cc = dots[b * 3 + 2];
+  const double cst = -logdet[b] - 0.5 * N * LOG2PI;
+  double acc = 0.0;
+  for (int r = 0; r < R_obs; ++r) {
+    const double x = obs[(long)r * N + t];
+    acc += -0.5 * ((x * x) * aa - 2.0 * x * ac + cc) + cst;
+  }
+  ll_mean[(long)b * N + t] = acc / R_obs;
+}
+
 constexpr int MAX_ROBS = 4;
 // thread per (member, t): q_r = sum_i (x_rt a_i - c_i)^2 for every observation realisation (chunks of 4)
 __global__ __launch_bounds__(256) void loglik_rows_kernel(int N, int R_obs, const double* ac, const double* logdet,
@@ -706,6 +770,22 @@ void HipPrims::aug_get(int nb, int n, Mat rows, double* vec) {
   hipLaunchKernelGGL(aug_get_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
   LAUNCH_CHECK();
 }
+void HipPrims::basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) {
+  hipLaunchKernelGGL(basis_rows_set_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, rows, mu_pad);
+  LAUNCH_CHECK();
+}
+void HipPrims::basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) {
+  (void)Np;
+  hipLaunchKernelGGL(basis_rows_get_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, rows, basis);
+  LAUNCH_CHECK();
+}
+void HipPrims::loglik_rows_basis(int B, int N, int R_obs, const double* basis, const double* logdet,
+                                 const double* obs, double* ll_mean, double* dots) {
+  hipLaunchKernelGGL(basis_dots_kernel, dim3(B), dim3(256), 0, stream, N, basis, dots);
+  hipLaunchKernelGGL(loglik_basis_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, dots, logdet, obs,
+                     ll_mean);
+  LAUNCH_CHECK();
+}
 void HipPrims::resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) {
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
   LAUNCH_CHECK();
@@ -749,6 +829,11 @@ void HipPrims::hyp_out(int nb, const double* ustate, double* hyp) {
 }
 void HipPrims::pad_in(int nb, int N, int Np, const double* src, Mat dst) {
   hipLaunchKernelGGL(pad_in_kernel, tile_grid(Np, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+
+void HipPrims::pad_vec(int nb, int N, int Np, const double* src, double* dst) {
+  hipLaunchKernelGGL(pad_vec_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
   LAUNCH_CHECK();
 }
 

@@ -69,6 +69,10 @@ struct Prims {
   // triangular solves (x^T C^-T C^-1 = (C^-T C^-1 x)^T), rows 1..63 are zero
   virtual void aug_set(int nb, int n, Mat rows, const double* vec) = 0;   // rows[0][:] = vec, others 0
   virtual void aug_get(int nb, int n, Mat rows, double* vec) = 0;         // vec = rows[0][:]
+  // the two appended rows of the covariance factorisation: row 0 = 1 (columns < N, else 0), row 1 = mu_pad
+  // (rows 2..63 zero); and their read-back into basis [nb][2][N]
+  virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) = 0;
+  virtual void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) = 0;
   virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
   // X_ij <- (i >= j) ? (a_i m_j + X_ij) / nu_i : 0
   virtual void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) = 0;

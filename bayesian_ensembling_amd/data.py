@@ -24,11 +24,12 @@ class Distribution:
     covariance: np.ndarray
     dim_array: DataArray
     dist_type: tp.Any
-    _factor: tp.Any = field(default=None, repr=False)   # (chol, logdet) handed over by the GPU fit
+    _factor: tp.Any = field(default=None, repr=False)   # (chol, logdet, basis) handed over by the GPU fit
 
     def __post_init__(self):
         if self.dist_type is dx.MultivariateNormalFullCovariance and self._factor is not None:
-            self._dist = self.dist_type(self.mu, self.covariance, _chol=self._factor[0], _logdet=self._factor[1])
+            self._dist = self.dist_type(self.mu, self.covariance, _chol=self._factor[0], _logdet=self._factor[1],
+                                        _basis=self._factor[2])
         else:
             self._dist = self.dist_type(self.mu, self.covariance)
 

@@ -85,16 +85,18 @@ class MultivariateNormalFullCovariance:
     factor comes from the GPU - either handed over by the fit that produced the covariance, or computed by
     bayens_mvn_factor_batch."""
 
-    def __init__(self, loc, covariance_matrix, _chol=None, _logdet=None):
+    def __init__(self, loc, covariance_matrix, _chol=None, _logdet=None, _basis=None):
         self.loc = np.asarray(loc, dtype=np.float64).reshape(-1)
         self._cov = np.asarray(covariance_matrix, dtype=np.float64)
         N = self.loc.size
         assert self._cov.shape == (N, N), "covariance must be (N, N)"
-        if _chol is None or _logdet is None:
-            chol, logdet = _lib.default_context().mvn_factor_batch(self._cov[None])
-            _chol, _logdet = chol[0], float(logdet[0])
+        if _chol is None or _logdet is None or _basis is None:
+            chol, logdet, basis = _lib.default_context().mvn_factor_batch(self._cov[None], self.loc[None])
+            _chol, _logdet, _basis = chol[0], float(logdet[0]), basis[0]
         self._scale_tri = np.asarray(_chol, dtype=np.float64)
         self._logdet = float(_logdet)
+        # (L^-1 1, L^-1 loc): by-products of the bordered factorisation; all a constant-vector log_prob needs
+        self._basis = np.asarray(_basis, dtype=np.float64)
 
     def mean(self):
         return self.loc
@@ -122,7 +124,7 @@ class MultivariateNormalFullCovariance:
                 chunk = np.zeros(N)
                 seg = vals[s:s + N]
                 chunk[:seg.size] = seg
-                ll = ctx.loglik_rows(self.loc[None], self._scale_tri[None], np.array([self._logdet]), chunk[None])
+                ll = ctx.loglik_rows_basis(self._basis[None], np.array([self._logdet]), chunk[None])
                 out[s:s + seg.size] = ll[0, :seg.size]
             return out
         raise NotImplementedError(

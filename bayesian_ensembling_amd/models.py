@@ -67,7 +67,7 @@ class GPDTW1D:
                 dists[i] = Distribution(mu=out["mu"][j], covariance=out["cov"][j],
                                         dim_array=_blank_array(process_models[i]),
                                         dist_type=dx.MultivariateNormalFullCovariance,
-                                        _factor=(out["chol"][j], float(out["logdet"][j])))
+                                        _factor=(out["chol"][j], float(out["logdet"][j]), out["basis"][j]))
                 dists[i].hyperparameters = {"variance": float(out["hyp"][j, 0]), "lengthscale": float(out["hyp"][j, 1])}
         return dists
 

@@ -66,10 +66,9 @@ class LogLikelihoodWeight(AbstractWeight):
                     d = models[i].distribution._dist
                     ll_mean[i] = np.mean([d.log_prob(o[:, None]) for o in obs], axis=0)
             else:
-                mu = np.stack([d.loc for d in ds])
-                chol = np.stack([d._scale_tri for d in ds])
+                basis = np.stack([d._basis for d in ds])
                 logdet = np.array([d._logdet for d in ds])
-                ll_mean[full] = ctx.loglik_rows(mu, chol, logdet, obs)
+                ll_mean[full] = ctx.loglik_rows_basis(basis, logdet, obs)
         if diag:
             mu = np.stack([models[i].distribution._dist.loc.reshape(-1) for i in diag])
             sc = np.stack([models[i].distribution._dist.scale.reshape(-1) for i in diag])

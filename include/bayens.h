@@ -76,18 +76,20 @@ int bayens_set_groups(bayens_ctx* ctx, int n_groups);
  * outputs (any may be NULL except mu/cov):
  *   mu [B][N], cov [B][N][N] (predict_f full_cov + diag(y_var), models.py:217-220),
  *   cov_chol [B][N][N] lower Cholesky of cov, logdet [B] = sum(log(diag(chol))),
- *   hyp [B][2] final (variance, lengthscale), info [B] 0 or 1-based failing pivot.
+ *   hyp [B][2] final (variance, lengthscale), info [B] 0 or 1-based failing pivot,
+ *   ll_basis [B][2][N] = (L_c^-1 1, L_c^-1 mu): the two vectors a later log_prob at a constant vector needs
+ *   (weights.py:98-100); they fall out of the bordered Cholesky of cov at no extra pass.
  *   loss_trace must be NULL in this version (models.py:211-215 only feeds a progress bar). */
 int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         const double* X, const double* y_mean, const double* y_var,
                         int kernel, int n_iters, double gamma, double lr, double jitter,
                         double* mu, double* cov, double* cov_chol, double* logdet,
-                        double* hyp, double* loss_trace, int* info);
+                        double* hyp, double* loss_trace, int* info, double* ll_basis);
 
 /* Distribution.__post_init__ for a caller-supplied full covariance (ensembles/data.py:38-39):
- * chol [B][N][N] lower, logdet [B]. */
-int bayens_mvn_factor_batch(bayens_ctx* ctx, int loc, int B, int N, const double* cov,
-                            double* chol, double* logdet, int* info);
+ * chol [B][N][N] lower, logdet [B]; with mu [B][N] given, ll_basis [B][2][N] as above (both may be NULL). */
+int bayens_mvn_factor_batch(bayens_ctx* ctx, int loc, int B, int N, const double* cov, const double* mu,
+                            double* chol, double* logdet, double* ll_basis, int* info);
 
 /* _dist.variance() of a full-covariance posterior = diag(cov)  (ensemble_scheme.py:64-65, weights.py:311) */
 int bayens_extract_diag(bayens_ctx* ctx, int loc, int B, int N, const double* cov, double* var);
@@ -97,6 +99,10 @@ int bayens_extract_diag(bayens_ctx* ctx, int loc, int B, int N, const double* co
 int bayens_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                        const double* mu, const double* cov_chol, const double* logdet,
                        const double* obs, double* ll_mean);
+
+/* the same rows from the basis a fit / factorisation returned (no triangular solve, no pass over chol) */
+int bayens_loglik_rows_basis(bayens_ctx* ctx, int loc, int B, int N, int R_obs, const double* ll_basis,
+                             const double* logdet, const double* obs, double* ll_mean);
 
 /* same, dx.Normal branch (ensembles/weights.py:95-96): elementwise log N(obs; mu, scale) */
 int bayens_normal_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,

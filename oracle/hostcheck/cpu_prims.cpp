@@ -173,6 +173,19 @@ struct CpuPrims : Prims {
     for (int b = 0; b < nb; ++b)
       for (int j = 0; j < n; ++j) vec[(size_t)b * n + j] = rows.p[b * rows.stride + j];
   }
+  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) override {
+    for (int b = 0; b < nb; ++b)
+      for (int r = 0; r < LEAF; ++r)
+        for (int j = 0; j < Np; ++j)
+          rows.p[b * rows.stride + (size_t)r * rows.ld + j] =
+              r == 0 ? (j < N ? 1.0 : 0.0) : (r == 1 ? (j < N ? mu_pad[(size_t)b * Np + j] : 0.0) : 0.0);
+  }
+  void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override {
+    (void)Np;
+    for (int b = 0; b < nb; ++b)
+      for (int r = 0; r < 2; ++r)
+        for (int j = 0; j < N; ++j) basis[((size_t)b * 2 + r) * N + j] = rows.p[b * rows.stride + (size_t)r * rows.ld + j];
+  }
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i) {
@@ -280,11 +293,11 @@ extern "C" {
 
 int hostcheck_gp_fit(int B, int N, int R, const double* X, const double* y_mean, const double* y_var,
                      int kernel, int n_iters, double gamma, double lr, double jitter, double* mu,
-                     double* cov, double* chol, double* logdet, double* hyp, int* info) {
+                     double* cov, double* chol, double* logdet, double* hyp, int* info, double* basis) {
   CpuPrims P;
   HostWs h(B, pad_to_leaf(N));
   FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
-  gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp);
+  gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp, basis);
   for (int b = 0; b < B; ++b) info[b] = h.info[b];
   return 0;
 }

@@ -32,6 +32,9 @@ def test_fit_matches_oracle(ctx, M, N, R, T, kernel):
         assert relerr(out["chol"][m], Lc) < tight and abs(out["logdet"][m] - ld) < 1e-6
         assert relerr(out["hyp"][m], ho) < tight
         assert np.array_equal(out["cov"][m], out["cov"][m].T)
+        import scipy.linalg as sla
+        assert relerr(out["basis"][m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 10 * tight
+        assert relerr(out["basis"][m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 10 * tight
 
 
 def test_fit_with_api_default_iterations(ctx):
@@ -68,7 +71,7 @@ def test_fit_is_deterministic_and_independent_of_workspace_history(ctx):
     other, _ = go.synthetic_ensemble(2, 200, R=8, seed=22)
     ctx.gp_fit_batch(*member_inputs(other), 2)              # dirties every workspace matrix
     again = ctx.gp_fit_batch(X, y, nu, 3)
-    for k in ("mu", "cov", "chol", "logdet", "hyp"):
+    for k in ("mu", "cov", "chol", "logdet", "hyp", "basis"):
         assert np.array_equal(first[k], again[k]), k
     mo, co, ho = go.gp_fit(X[0], y[0], nu[0], 3)
     assert relerr(again["cov"][0], co) < 1e-10 and relerr(again["hyp"][0], ho) < 1e-12

@@ -26,6 +26,10 @@ def test_loglik_rows_and_weights(ctx, M, N, R_obs):
     ll_ref = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(out["mu"][m], out["chol"][m], out["logdet"][m], obs))
                        for m in range(M)])
     assert relerr(ll, ll_ref) < 1e-12
+    # the basis path (bordered Cholesky by-product, expanded quadratic form) must agree with the direct form
+    assert relerr(ctx.loglik_rows_basis(out["basis"], out["logdet"], obs), ll_ref) < 1e-11
+    chol2, ld2, basis2 = ctx.mvn_factor_batch(out["cov"], out["mu"])
+    assert relerr(basis2, out["basis"]) < 1e-11 and relerr(chol2, out["chol"]) < 1e-12
     for c in (1e-3, 1e-2):
         w, raw = ctx.weights_normalise(ll, c, return_raw=True)
         w_ref, raw_ref = go.loglik_weights(ll_ref, c)

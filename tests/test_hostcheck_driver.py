@@ -21,8 +21,11 @@ def hc_fit(lib, X, y, nu, T, kernel=0):
     B, N, R = X.shape
     mu, cov, chol = np.zeros((B, N)), np.zeros((B, N, N)), np.zeros((B, N, N))
     ld, hyp, info = np.zeros(B), np.zeros((B, 2)), np.zeros(B, dtype=np.int32)
+    basis = np.zeros((B, 2, N))
     lib.hostcheck_gp_fit(B, N, R, P(X), P(y), P(nu), kernel, T, ctypes.c_double(0.5), ctypes.c_double(0.01),
-                         ctypes.c_double(1e-6), P(mu), P(cov), P(chol), P(ld), P(hyp), info.ctypes.data_as(ip))
+                         ctypes.c_double(1e-6), P(mu), P(cov), P(chol), P(ld), P(hyp), info.ctypes.data_as(ip),
+                         P(basis))
+    hc_fit.basis = basis
     return mu, cov, chol, ld, hyp, info
 
 
@@ -38,6 +41,10 @@ def test_driver_matches_oracle(hostcheck, M, N, R, T, kernel):
         Lc, l = go.mvn_factor(co)
         assert relerr(mu[m], mo) < 1e-9 and relerr(cov[m], co) < 1e-9
         assert relerr(chol[m], Lc) < 1e-9 and abs(ld[m] - l) < 1e-8 and relerr(hyp[m], ho) < 1e-11
+        # the bordered factorisation carries 1 and mu to L_c^-1 1 and L_c^-1 mu
+        import scipy.linalg as sla
+        assert relerr(hc_fit.basis[m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 1e-8
+        assert relerr(hc_fit.basis[m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 1e-8
 
 
 def test_blocked_potrf_and_trsm(hostcheck):
