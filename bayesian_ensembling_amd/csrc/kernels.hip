@@ -335,62 +335,165 @@ __global__ void adam_kernel(int ntiles, const double* gpart, double* ustate, dou
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64x64 diagonal block: Cholesky in LDS + inverse of the factor (one workgroup per member)
+// 64x64 diagonal block: Cholesky + inverse of the factor, one workgroup (4 waves) per member.
+// The block lives in LDS and is processed as 4x4 sub-blocks of 16x16:
+//   P1  the 16x16 diagonal sub-block is factored AND inverted in registers by 16 lanes of wave 0
+//       (lane i owns row i; pivots/columns travel by v_readlane; 1/L_ii comes from a Newton-refined v_rsq_f64,
+//       so there is no fp64 divide or sqrt sequence on the serial chain)
+//   P2  panel below:   P <- P inv(L_dd)^T          fp64 MFMA 16x16x4, one 16-row block per wave
+//   P3  trailing part: S_rc -= P_r P_c^T           fp64 MFMA, lower block pairs dealt over the waves
+//   P4  off-diagonal blocks of the inverse, block row by block row: M_IJ = -M_II sum_K L_IK M_KJ (MFMA)
+// 3 barriers per block column instead of 5 per scalar column.
 // ------------------------------------------------------------------------------------------------
+constexpr int LS = 66;   // LDS row stride (doubles) of the 64x64 images
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  double r = __builtin_amdgcn_rsq(d);            // v_rsq_f64: ~2^-26 relative
+  r = r * (1.5 - 0.5 * d * r * r);               // Newton: quadratic convergence, two steps reach fp64
+  r = r * (1.5 - 0.5 * d * r * r);
+  // one correction in fma form: r <- r + r * (1 - d r^2) / 2
+  const double e = fma(-d * r, r, 1.0);
+  return fma(0.5 * r, e, r);
+}
+
+// 16x16 MFMA tile helpers on LDS images (row stride LS).  acc rows (lane>>4)+4r, col lane&15.
+__device__ __forceinline__ v4d tile_load(const double (*T)[LS], int r0, int c0, int lane) {
+  v4d acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)];
+  return acc;
+}
+__device__ __forceinline__ void tile_store(double (*T)[LS], int r0, int c0, int lane, v4d acc) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)] = acc[r];
+}
+// acc += sgn * A(16x16 at (ar,ac)) * B, where B[k][j] = Bm[br + j][bc + k] (i.e. A * Bm^T) if BT else Bm[br + k][bc + j]
+template <bool BT>
+__device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LS], int ar, int ac, const double (*Bm)[LS], int br,
+                                        int bc, int lane, double sgn) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double a = sgn * Am[ar + lr][ac + kk * 4 + lk];
+    const double b = BT ? Bm[br + lr][bc + kk * 4 + lk] : Bm[br + kk * 4 + lk][bc + lr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
                                                          int* info) {
-  __shared__ double S[64][65];
-  __shared__ double Iv[64][65];
-  __shared__ double part[4][64];
+  __shared__ double S[64][LS];     // the block -> its lower factor
+  __shared__ double Mi[64][LS];    // inverse of the factor
+  __shared__ double Tt[4][16][LS]; // per-wave 16x16 scratch for P4
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   double* a = Ablk.p + b * Ablk.stride;
-  const int c = tid & 63, r0 = tid >> 6;
-  for (int q = 0; q < 16; ++q) {
-    const int r = r0 + 4 * q;
-    S[r][c] = c <= r ? a[(long)r * Ablk.ld + c] : 0.0;
+  {
+    const int c = tid & 63, r0 = tid >> 6;
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      S[r][c] = c <= r ? a[(long)r * Ablk.ld + c] : 0.0;
+      Mi[r][c] = 0.0;
+    }
   }
   __syncthreads();
-  // right-looking unblocked factorisation; thread (i = tid/4, kq = tid%4) updates row i, columns k = kq (mod 4)
-  const int ui = tid >> 2, kq = tid & 3;
-  for (int j = 0; j < 64; ++j) {
-    if (tid == 0) {
-      double d = S[j][j];
-      if (!(d > 0.0)) {
-        if (info[b] == 0) info[b] = pivot_base + j + 1;
-        d = 1.0;
+
+  for (int bj = 0; bj < 4; ++bj) {
+    const int d0 = 16 * bj;
+    // ---- P1: factor + invert the 16x16 diagonal sub-block (wave 0, lanes 0..15 own rows) ----
+    if (wave == 0) {
+      double row[16], rinv[16], m[16];
+      const int li = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) row[j] = S[d0 + li][d0 + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double d = readlane_d(row[j], j);
+        if (!(d > 0.0)) {
+          if (lane == 0 && info[b] == 0) info[b] = pivot_base + d0 + j + 1;
+          d = 1.0;
+        }
+        const double r = rsqrt_refined(d);
+        rinv[j] = r;
+        row[j] = li == j ? d * r : (li > j ? row[j] * r : 0.0);
+        const double lij = row[j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = readlane_d(row[j], k);
+          row[k] = fma(-lij, lkj, row[k]);
+        }
       }
-      S[j][j] = sqrt(d);
+      // inverse by columns: lane c owns column c; m[i] = (delta_ic - sum_{k<i} L_ik m_k) * rinv_i
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double sacc = li == i ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc = fma(-readlane_d(row[k], i), m[k], sacc);
+        m[i] = sacc * rinv[i];
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          S[d0 + li][d0 + j] = row[j];
+          Mi[d0 + j][d0 + li] = m[j];     // m[j] = Minv[j][li]
+        }
+      }
     }
     __syncthreads();
-    if (tid > j && tid < 64) S[tid][j] /= S[j][j];
+    // ---- P2: panel rows below: P <- P * inv(L_dd)^T ----
+    const int nrb = 3 - bj;                         // 16-row blocks below the diagonal sub-block
+    if (wave < nrb) {
+      const int r0 = d0 + 16 * (wave + 1);
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_mma<true>(acc, S, r0, d0, Mi, d0, d0, lane, 1.0);
+      tile_store(S, r0, d0, lane, acc);
+    }
     __syncthreads();
-    if (ui > j) {
-      const double lij = S[ui][j];
-      for (int k = j + 1 + kq; k <= ui; k += 4) S[ui][k] -= lij * S[k][j];
+    // ---- P3: trailing update of the lower block pairs (rb >= cb > bj) ----
+    {
+      int p = 0;
+      for (int rb = bj + 1; rb < 4; ++rb)
+        for (int cb = bj + 1; cb <= rb; ++cb, ++p)
+          if ((p & 3) == wave) {
+            v4d acc = tile_load(S, 16 * rb, 16 * cb, lane);
+            acc = tile_mma<true>(acc, S, 16 * rb, d0, S, 16 * cb, d0, lane, -1.0);
+            tile_store(S, 16 * rb, 16 * cb, lane, acc);
+          }
     }
     __syncthreads();
   }
-  // inverse M = L^-1 by rows: M[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] M[k][c]) / L[i][i]
-  // thread (c = tid&63, q = tid>>6) sums k = q (mod 4); the four partials are combined through LDS.
-  for (int q = 0; q < 16; ++q) Iv[r0 + 4 * q][c] = 0.0;
-  __syncthreads();
-  for (int i = 0; i < 64; ++i) {
-    double s = 0.0;
-    if (c < i)
-      for (int k = c + r0; k < i; k += 4) s += S[i][k] * Iv[k][c];
-    part[r0][c] = s;
-    __syncthreads();
-    if (r0 == 0 && c <= i) {
-      const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-      Iv[i][c] = ((c == i ? 1.0 : 0.0) - tot) / S[i][i];
+
+  // ---- P4: off-diagonal 16x16 blocks of the inverse, block row I needs rows < I ----
+  for (int I = 1; I < 4; ++I) {
+    if (wave < I) {
+      const int J = wave;
+      v4d t = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) t = tile_mma<false>(t, S, 16 * I, 16 * K, Mi, 16 * K, 16 * J, lane, 1.0);
+      tile_store(Tt[wave], 0, 0, lane, t);
+      // same wave wrote and reads Tt[wave]: make the LDS writes visible to its own later reads
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_mma<false>(acc, Mi, 16 * I, 16 * I, Tt[wave], 0, 0, lane, -1.0);
+      tile_store(Mi, 16 * I, 16 * J, lane, acc);
     }
     __syncthreads();
   }
+
   double* iv = inv + b * inv_stride;
-  for (int q = 0; q < 16; ++q) {
-    const int r = r0 + 4 * q;
-    a[(long)r * Ablk.ld + c] = S[r][c];     // lower factor, zeros above the diagonal
-    iv[r * 64 + c] = Iv[r][c];
+  {
+    const int c = tid & 63, r0 = tid >> 6;
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      a[(long)r * Ablk.ld + c] = c <= r ? S[r][c] : 0.0;     // lower factor, zeros above the diagonal
+      iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+    }
   }
 }
 
