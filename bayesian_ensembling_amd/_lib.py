@@ -81,6 +81,7 @@ def load():
     lib.bayens_allgather_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
     lib.bayens_test_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
+    lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
@@ -365,6 +366,11 @@ class Context:
         self._check(self.lib.bayens_test_gemm(self.h, nb, m, n, k, alpha, _ptr(A), A.shape[2], _ptr(B), B.shape[2],
                                               beta, _ptr(Cm), Cm.shape[2], flags, diag_add))
         return Cm
+
+    def bench_gemm(self, nb, m, n, k, flags=0, reps=10):
+        ms = C.c_double()
+        self._check(self.lib.bayens_bench_gemm(self.h, nb, m, n, k, flags, reps, C.byref(ms)))
+        return ms.value
 
     def test_potrf(self, A):
         A = np.array(A, dtype=np.float64, order="C", copy=True)

@@ -618,6 +618,32 @@ int bayens_test_gemm(bayens_ctx* c, int nb, int m, int n, int k, double alpha, c
   });
 }
 
+int bayens_bench_gemm(bayens_ctx* c, int nb, int m, int n, int k, int flags, int reps, double* ms_per_launch) {
+  return guarded(c, [&]() {
+    if (nb <= 0 || reps <= 0) return fail(c, BAYENS_E_ARG, "bench_gemm: bad argument");
+    const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
+    const int lda = ta ? m : k, ldb = tb ? k : n;
+    const size_t an = (size_t)(ta ? k : m) * lda, bn = (size_t)(tb ? n : k) * ldb, cn = (size_t)m * n;
+    Stage st(c, BAYENS_DEVICE);
+    double* dA = st.scratch<double>(an * nb);
+    double* dB = st.scratch<double>(bn * nb);
+    double* dC = st.scratch<double>(cn * nb);
+    c->prims->fill_random(dA, an * nb, 1);
+    c->prims->fill_random(dB, bn * nb, 2);
+    c->prims->fill_random(dC, cn * nb, 3);
+    Mat A{dA, lda, (long)an}, B{dB, ldb, (long)bn}, Cm{dC, n, (long)cn};
+    c->prims->gemm(nb, m, n, k, 1.0, A, B, 0.5, Cm, flags, 0.0);     // warm-up
+    BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+    for (int r = 0; r < reps; ++r) c->prims->gemm(nb, m, n, k, 1.0, A, B, 0.5, Cm, flags, 0.0);
+    BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+    BAYENS_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    BAYENS_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    if (ms_per_launch) *ms_per_launch = f / reps;
+    return 0;
+  });
+}
+
 int bayens_test_potrf(bayens_ctx* c, int nb, int n, double* A, int* info) {
   return guarded(c, [&]() {
     if (n % LEAF) return fail(c, BAYENS_E_ARG, "test_potrf: n must be a multiple of 64");

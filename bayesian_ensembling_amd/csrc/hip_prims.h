@@ -73,6 +73,7 @@ struct HipPrims : Prims {
 
   // not part of the driver interface: pad a compact [nb][N][N] matrix into a padded Mat (identity pad)
   void pad_in(int nb, int N, int Np, const double* src, Mat dst);
+  void fill_random(double* dst, size_t count, unsigned seed);           // uniform [-1, 1), diagnostics only
   void pad_vec(int nb, int N, int Np, const double* src, double* dst);   // [nb][N] -> [nb][Np], zero pad
 
   // weights / weighted-posterior kernels (compact layouts, see include/bayens.h)

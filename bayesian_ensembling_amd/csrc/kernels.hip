@@ -183,6 +183,18 @@ __global__ void pad_in_kernel(int N, int Np, const double* src, Mat dst) {
   }
 }
 
+__global__ void fill_random_kernel(double* dst, size_t count, unsigned seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    dst[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+
 __global__ void pad_vec_kernel(int N, int Np, const double* src, double* dst) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -935,6 +947,10 @@ void HipPrims::pad_in(int nb, int N, int Np, const double* src, Mat dst) {
   LAUNCH_CHECK();
 }
 
+void HipPrims::fill_random(double* dst, size_t count, unsigned seed) {
+  hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, stream, dst, count, seed);
+  LAUNCH_CHECK();
+}
 void HipPrims::pad_vec(int nb, int N, int Np, const double* src, double* dst) {
   hipLaunchKernelGGL(pad_vec_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
   LAUNCH_CHECK();

@@ -141,6 +141,9 @@ int bayens_allgather_rows(bayens_ctx* ctx, const double* local_dev, double* all_
 int bayens_test_gemm(bayens_ctx* ctx, int nb, int m, int n, int k, double alpha,
                      const double* A, int lda, const double* B, int ldb, double beta,
                      double* C, int ldc, int flags, double diag_add);
+/* times `reps` launches of one GEMM shape on device-resident pseudo-random operands (HIP events on the ctx
+ * stream); *ms_per_launch is the average.  Used by tools/gemm_bench.py and the PMC profiles. */
+int bayens_bench_gemm(bayens_ctx* ctx, int nb, int m, int n, int k, int flags, int reps, double* ms_per_launch);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
