@@ -3,6 +3,8 @@
 
 namespace bayens {
 
+constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve takes
+
 static inline int split_point(int n) {
   int leaves = n / LEAF;
   return (leaves / 2) * LEAF;   // >= LEAF whenever leaves >= 2
@@ -14,10 +16,8 @@ static inline double* inv_at(double* inv, int leaf) { return inv + (long)leaf * 
 // X L^T = B.  L = [L11 0; L21 L22]  =>  X1 = B1 L11^-T ; B2 -= X1 L21^T ; X2 = B2 L22^-T
 void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B) {
   if (m <= 0 || n <= 0) return;
-  if (n == LEAF) {
-    Mat I{const_cast<double*>(inv), LEAF, inv_stride};
-    // X = B * inv^T  (in place: one column tile, each block reads only its own rows)
-    P.gemm(nb, m, LEAF, LEAF, 1.0, B, I, 0.0, B, GEMM_TB, 0.0);
+  if (n <= PANEL_MAX) {   // the bottom levels of the recursion run fused: one pass over the m x n panel
+    P.trsm_panel(nb, m, n, L, inv, inv_stride, B, 0);
     return;
   }
   int n1 = split_point(n), n2 = n - n1;
@@ -34,9 +34,9 @@ static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const double* in
   if (m <= 0 || n <= 0) return;
   int r0 = rhs_lower ? c0 : 0;
   if (r0 >= m) return;
-  if (n == LEAF) {
-    Mat I{const_cast<double*>(inv), LEAF, inv_stride};
-    P.gemm(nb, m - r0, LEAF, LEAF, 1.0, B.sub(r0, 0), I, 0.0, B.sub(r0, 0), 0, 0.0);
+  if (n <= PANEL_MAX) {
+    // (with rhs_lower the rows [c0, c0+n) x columns above the diagonal hold zeros and stay zero)
+    P.trsm_panel(nb, m - r0, n, L, inv, inv_stride, B.sub(r0, 0), 1);
     return;
   }
   int n1 = split_point(n), n2 = n - n1;

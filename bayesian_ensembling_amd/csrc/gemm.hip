@@ -248,6 +248,111 @@ __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused triangular solve of a narrow diagonal block (n = 64 * nsub <= 256): B <- B L^-T (RLN=false) or
+// B <- B L^-1 (RLN=true).  Rows of a right-side solve are independent, so a workgroup owns 64 rows and walks
+// the column blocks itself:   X_j = (B_j - sum_k X_k op(L_jk)) op(M_j)   with M_j the inverted diagonal block.
+// Every product is a 64x64x64 fp64 MFMA product (16 rows per wave); the accumulator becomes the A operand of
+// the product with M_j through the wave's own rows of the LDS tile, finished blocks X_k come back from L2.
+// One launch and one HBM pass over the panel replace the 2*nsub-1 launches of the recursion's bottom levels.
+// ------------------------------------------------------------------------------------------------
+struct PanelArgs {
+  const double* L;     // n x n lower block
+  const double* inv;   // inverted 64x64 diagonal blocks of that block, [nsub][64][64]
+  double* B;           // m x n panel, in place
+  long sL, sInv, sB;
+  int ldl, ldb, m, nsub;
+};
+
+template <bool TR>
+__device__ __forceinline__ void stage64_load(const double* src, int ld, int tid, v2d (&reg)[8]) {
+  const int c2 = tid & 31, r = tid >> 5;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) reg[p] = *reinterpret_cast<const v2d*>(src + (long)(r + 8 * p) * ld + 2 * c2);
+}
+// TR=false: tile[row][col] = src[row][col]; TR=true: tile[col][row] = src[row][col]
+template <bool TR>
+__device__ __forceinline__ void stage64_store(double (*tile)[SLD], int tid, const v2d (&reg)[8]) {
+  const int c2 = tid & 31, r = tid >> 5;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    if (TR) {
+      tile[2 * c2][r + 8 * p] = reg[p].x;
+      tile[2 * c2 + 1][r + 8 * p] = reg[p].y;
+    } else {
+      *reinterpret_cast<v2d*>(&tile[r + 8 * p][2 * c2]) = reg[p];
+    }
+  }
+}
+
+// acc[jt] += sgn * As[wave rows][:] * Bs[:][16 jt ..]   (Bs is the k-major image B[k][col])
+__device__ __forceinline__ void panel_mma(v4d (&acc)[4], const double (*As)[SLD], const double (*Bs)[SLD], int wave,
+                                          int lane, double sgn) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const double a = sgn * As[wave * 16 + lr][kk * 4 + lk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j], 0, 0, 0);
+  }
+}
+
+template <bool RLN>
+__global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[SK][SLD];
+  __shared__ __attribute__((aligned(16))) double Bs[SK][SLD];
+  const int tiles_m = g.m / SK;
+  const int batch = blockIdx.x / tiles_m;
+  const int row0 = (blockIdx.x - batch * tiles_m) * SK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* L = g.L + batch * g.sL;
+  const double* inv = g.inv + batch * g.sInv;
+  double* B = g.B + batch * g.sB + (long)row0 * g.ldb;
+  v2d ra[8], rb[8];
+
+  for (int s = 0; s < g.nsub; ++s) {
+    const int j = RLN ? g.nsub - 1 - s : s;
+    v4d acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr];
+    // acc -= X_k op(L): RLT k < j with B-operand[kk][jj] = L[64j+jj][64k+kk]; RLN k > j with L[64k+kk][64j+jj]
+    for (int t = 0; t < s; ++t) {
+      const int k = RLN ? g.nsub - 1 - t : t;
+      stage64_load<false>(B + 64 * k, g.ldb, tid, ra);
+      if (RLN) stage64_load<false>(L + (long)(64 * k) * g.ldl + 64 * j, g.ldl, tid, rb);
+      else stage64_load<true>(L + (long)(64 * j) * g.ldl + 64 * k, g.ldl, tid, rb);
+      __syncthreads();                       // previous product finished with As / Bs
+      stage64_store<false>(As, tid, ra);
+      stage64_store<!RLN>(Bs, tid, rb);
+      __syncthreads();
+      panel_mma(acc, As, Bs, wave, lane, -1.0);
+    }
+    // X_j = acc op(M_j): the accumulator goes to the wave's own rows of As
+    stage64_load<!RLN>(inv + (long)j * 4096, 64, tid, rb);
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = acc[jt][r];
+    stage64_store<!RLN>(Bs, tid, rb);
+    __syncthreads();
+    v4d x[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0.0, 0.0, 0.0, 0.0};
+    panel_mma(x, As, Bs, wave, lane, 1.0);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr] = x[jt][r];
+    // the next column block stages X_j through other threads of this workgroup: make the stores visible
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 double algorithmic_flop(int nb, int m, int n, int k, int flags) {
   double f = 2.0 * m * (double)n * k * nb;
   if ((flags & GEMM_TRI_OUT) && (flags & GEMM_KTRIM_TN_LOWER)) return f / 6.0;
@@ -300,6 +405,37 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
     BAYENS_HIP(hipEventRecord(e1, stream));
     prof.events.emplace_back(e0, e1);
     prof.flop += algorithmic_flop(nb, m, n, k, flags);
+    prof.launches += 1;
+  }
+}
+
+void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) {
+  if (nb <= 0 || m <= 0 || n <= 0) return;
+  if ((m % 64) || (n % 64) || n > 256 || (L.ld & 1) || (B.ld & 1))
+    throw HipError{-1, "trsm_panel: m, n must be multiples of 64, n <= 256"};
+  PanelArgs g;
+  g.L = L.p; g.inv = inv; g.B = B.p;
+  g.sL = L.stride; g.sInv = inv_stride; g.sB = B.stride;
+  g.ldl = L.ld; g.ldb = B.ld; g.m = m; g.nsub = n / 64;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof.enabled) {
+    auto take = [&]() {
+      hipEvent_t e;
+      if (!prof.pool.empty()) { e = prof.pool.back(); prof.pool.pop_back(); }
+      else BAYENS_HIP(hipEventCreate(&e));
+      return e;
+    };
+    e0 = take(); e1 = take();
+    BAYENS_HIP(hipEventRecord(e0, stream));
+  }
+  dim3 grid((m / 64) * nb), block(256);
+  if (mode == 0) hipLaunchKernelGGL((trsm_panel_kernel<false>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((trsm_panel_kernel<true>), grid, block, 0, stream, g);
+  BAYENS_HIP(hipGetLastError());
+  if (prof.enabled) {
+    BAYENS_HIP(hipEventRecord(e1, stream));
+    prof.events.emplace_back(e0, e1);
+    prof.flop += (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
     prof.launches += 1;
   }
 }

@@ -45,6 +45,7 @@ struct HipPrims : Prims {
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
             double diag_add) override;
+  void trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) override;
   void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;

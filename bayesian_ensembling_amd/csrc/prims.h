@@ -42,6 +42,11 @@ struct Prims {
   virtual void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C,
                     int flags, double diag_add) = 0;
 
+  // Whole triangular solve of a narrow diagonal block in one launch: B[m x n] <- B L^-T (mode 0) or B L^-1
+  // (mode 1), n in {64, 128, 192, 256}, L the n x n lower block whose inverted 64x64 diagonal blocks are in inv.
+  // Rows are independent, so every workgroup carries its 64 rows through all column blocks (one pass over B).
+  virtual void trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) = 0;
+
   // Cholesky of one 64x64 diagonal block per member, in place (lower; strict upper set to 0), plus its
   // inverse into inv (64x64 row-major per member, member stride inv_stride).  A non-positive pivot j
   // (0-based inside the block) records info[b] = pivot_base + j + 1 if info[b] was 0.

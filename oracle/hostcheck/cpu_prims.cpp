@@ -59,6 +59,28 @@ struct CpuPrims : Prims {
     }
   }
 
+  void trsm_panel(int nb, int m, int n, Mat L, const double*, long, Mat B, int mode) override {
+    for (int b = 0; b < nb; ++b) {
+      const double* l = L.p + b * L.stride;
+      for (int i = 0; i < m; ++i) {
+        double* x = B.p + b * B.stride + (size_t)i * B.ld;
+        if (mode == 0) {        // x L^T = b : forward over columns
+          for (int j = 0; j < n; ++j) {
+            double s = x[j];
+            for (int k = 0; k < j; ++k) s -= x[k] * l[(size_t)j * L.ld + k];
+            x[j] = s / l[(size_t)j * L.ld + j];
+          }
+        } else {                // x L = b : backward over columns
+          for (int j = n - 1; j >= 0; --j) {
+            double s = x[j];
+            for (int k = j + 1; k < n; ++k) s -= x[k] * l[(size_t)k * L.ld + j];
+            x[j] = s / l[(size_t)j * L.ld + j];
+          }
+        }
+      }
+    }
+  }
+
   void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override {
     for (int b = 0; b < nb; ++b) {
       double* a = Ablk.p + b * Ablk.stride;
