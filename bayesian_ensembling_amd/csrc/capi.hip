@@ -632,9 +632,11 @@ int bayens_bench_gemm(bayens_ctx* c, int nb, int m, int n, int k, int flags, int
     c->prims->fill_random(dB, bn * nb, 2);
     c->prims->fill_random(dC, cn * nb, 3);
     Mat A{dA, lda, (long)an}, B{dB, ldb, (long)bn}, Cm{dC, n, (long)cn};
-    c->prims->gemm(nb, m, n, k, 1.0, A, B, 0.5, Cm, flags, 0.0);     // warm-up
+    double beta = 0.5;
+    if (const char* env = getenv("BAYENS_BENCH_BETA")) beta = atof(env);
+    c->prims->gemm(nb, m, n, k, 1.0, A, B, beta, Cm, flags, 0.0);     // warm-up
     BAYENS_HIP(hipEventRecord(c->t0, c->stream));
-    for (int r = 0; r < reps; ++r) c->prims->gemm(nb, m, n, k, 1.0, A, B, 0.5, Cm, flags, 0.0);
+    for (int r = 0; r < reps; ++r) c->prims->gemm(nb, m, n, k, 1.0, A, B, beta, Cm, flags, 0.0);
     BAYENS_HIP(hipEventRecord(c->t1, c->stream));
     BAYENS_HIP(hipEventSynchronize(c->t1));
     float f = 0;

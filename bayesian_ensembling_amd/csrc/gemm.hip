@@ -159,24 +159,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   }
 
   if (!active) return;
-  // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile
+  // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile.  The C values of one 16-row
+  // strip (16 per lane) are all loaded before the first store of that strip: with a runtime ldc the compiler
+  // cannot reorder a load past an earlier store, and one exposed memory round trip per element (64 per lane)
+  // cost ~27 us per tile; batched, it is one round trip per strip.
   const bool phi = g.flags & GEMM_EPI_PHI;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    double cv[4][4];
+    if (g.beta != 0.0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cv[j][r] = C[(long)(row0 + wm * 64 + i * 16 + lk + 4 * r) * g.ldc + col0 + wn * 64 + j * 16 + lr];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = col0 + wn * 64 + j * 16 + lr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wm * 64 + i * 16 + lk + 4 * r;
-        double* cp = C + (long)row * g.ldc + col;
         double v = g.alpha * acc[i][j][r];
-        if (g.beta != 0.0) v += g.beta * (*cp);
+        if (g.beta != 0.0) v += g.beta * cv[j][r];
         if (row == col) v += g.diag_add;
         if (phi) v = row < col ? 0.0 : (row == col ? 0.5 * v : v);
-        *cp = v;
+        C[(long)row * g.ldc + col] = v;
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
