@@ -62,6 +62,7 @@ def load():
     lib.bayens_timer_stop.argtypes = [_vp, _dp]
     lib.bayens_profile_enable.argtypes = [_vp, C.c_int]
     lib.bayens_set_groups.argtypes = [_vp, C.c_int]
+    lib.bayens_profile_stages.argtypes = [_vp, C.c_char_p, C.c_int]
     lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -196,6 +197,11 @@ class Context:
 
     def profile_enable(self, on=True):
         self._check(self.lib.bayens_profile_enable(self.h, 1 if on else 0))
+
+    def profile_stages(self):
+        buf = C.create_string_buffer(8192)
+        self._check(self.lib.bayens_profile_stages(self.h, buf, 8192))
+        return buf.value.decode()
 
     def profile_get(self, family=0):
         ms, fl, n = C.c_double(), C.c_double(), C.c_long()

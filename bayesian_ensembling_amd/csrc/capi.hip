@@ -355,6 +355,28 @@ int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long
   });
 }
 
+int bayens_profile_stages(bayens_ctx* c, char* buf, int buf_len) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipDeviceSynchronize());
+    auto& marks = c->gprims[0]->prof.marks;
+    std::string out;
+    std::vector<std::pair<std::string, double>> agg;
+    for (size_t i = 0; i + 1 < marks.size(); ++i) {
+      float f = 0;
+      BAYENS_HIP(hipEventElapsedTime(&f, marks[i].second, marks[i + 1].second));
+      bool found = false;
+      for (auto& a : agg) if (a.first == marks[i].first) { a.second += f; found = true; }
+      if (!found) agg.emplace_back(marks[i].first, f);
+    }
+    char line[160];
+    for (auto& a : agg) { snprintf(line, sizeof line, "%-24s %9.3f ms\n", a.first.c_str(), a.second); out += line; }
+    for (auto& m : marks) (void)hipEventDestroy(m.second);
+    marks.clear();
+    if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", out.c_str());
+    return 0;
+  });
+}
+
 int bayens_set_groups(bayens_ctx* c, int n_groups) {
   if (!c || n_groups < 1 || n_groups > 16) return BAYENS_E_ARG;
   c->ngroups = n_groups;

@@ -106,15 +106,20 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
 
   for (int it = 0; it < fp.n_iters; ++it) {
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
+    P.mark("kmat");
     P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
+    P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    P.mark("Lam update");
     // natural-gradient step:  Lam <- (1-g) Lam + g (I + L^T D L),  theta1 <- (1-g) theta1 + g L^T D y
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
     P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 1.0 - fp.gamma, ws.Lam,
            GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, fp.gamma);
     P.theta_update(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, ws.theta1);
+    P.mark("potrf Lam");
     P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
+    P.mark("L S solves");
     // [L; theta1^T] C^-T C^-1 = [L S; m^T]: the variational mean m = Lam^-1 theta1 rides through the two
     // solves that produce L S for the Adam step (models.py:210) as one extra row block of the right-hand side
     P.copy(nb, Np, ws.Lb, ws.T1);
@@ -122,35 +127,45 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     trsm_rlt(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1);        // [L; theta1^T] C^-T
     trsm_rln(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1, false); // ... C^-1
     P.aug_get(nb, Np, ws.T1.sub(Np, 0), ws.mvec);                     // m
+    P.mark("Lbar, Phi");
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
     P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))
     P.gemm(nb, Np, Np, Np, 1.0, ws.Lb, ws.T1, 0.0, ws.T2,
            GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI | GEMM_ZERO_SKIPPED, 0.0);   // Phi(L^T Lbar): a clean
     // lower-triangular right-hand side (the solve below reads whole row panels of it)
+    P.mark("Phi L^-1");
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
+    P.mark("W^T L^-1");
     P.transpose_lower(nb, Np, ws.T2, ws.T1);                          // W^T
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1, false);        // Kbar^T = W^T L^-1
+    P.mark("grad+adam");
     P.grad_adam(nb, N, Np, fp.R, X, fp.kernel, ws.T1, ws.ustate, fp.lr);
   }
+  P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
   P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+  P.mark("predict: K0 L^-T");
   P.copy(nb, Np, ws.K0, ws.T1);
   trsm_rlt(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1);                 // A^T = K0 L^-T
   P.gemv_n(nb, Np, ws.T1, ws.mvec, ws.muvec);                         // mu = A^T m
   P.extract_vec(nb, N, Np, ws.muvec, mu);
+  P.mark("predict: A^T C^-T");
   P.copy(nb, Np, ws.T1, ws.T2);
   trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2);                 // A^T C^-T
+  P.mark("predict: cov syrk x2");
   P.cov_init(nb, Np, ws.K0, ws.nu, ws.Lam);                           // Lam reused: K0 + diag(nu)
   P.gemm(nb, Np, Np, Np, -1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
   P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
   P.extract(nb, N, ws.Lam, cov, 1);
+  P.mark("chol(cov)");
   if (chol || logdet || basis) {
     // Distribution.__post_init__ : distrax caches chol(cov) and its log-determinant  (data.py:38-39)
     factor_with_basis(P, ws, N, ws.Lam, ws.muvec, chol, logdet, basis);
   }
   if (hyp) P.hyp_out(nb, ws.ustate, hyp);
+  P.mark("end");
 }
 
 void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,

@@ -28,6 +28,7 @@ struct KernelProfile {
   std::vector<hipEvent_t> pool;
   double flop = 0;
   long launches = 0;
+  std::vector<std::pair<std::string, hipEvent_t>> marks;   // stage profile of the driver
 };
 
 struct HipPrims : Prims {
@@ -42,6 +43,7 @@ struct HipPrims : Prims {
   explicit HipPrims(hipStream_t s) : stream(s) {}
   ~HipPrims() override;
   void ensure_scratch(int nb, int Np, int R4);
+  void mark(const char* phase) override;
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
             double diag_add) override;

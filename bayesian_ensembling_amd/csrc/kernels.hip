@@ -828,6 +828,14 @@ HipPrims::~HipPrims() {
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
 }
 
+void HipPrims::mark(const char* phase) {
+  if (!prof.enabled) return;
+  hipEvent_t e;
+  BAYENS_HIP(hipEventCreate(&e));
+  BAYENS_HIP(hipEventRecord(e, stream));
+  prof.marks.emplace_back(phase, e);
+}
+
 void HipPrims::ensure_scratch(int nb, int Np, int R4) {
   size_t need_xs = (size_t)nb * Np * R4 * sizeof(double);
   size_t need_s = (size_t)nb * Np * sizeof(double);

@@ -36,6 +36,8 @@ enum : int {
 
 struct Prims {
   virtual ~Prims() {}
+  // phase marker for the optional stage profile (no-op unless the implementation records it)
+  virtual void mark(const char* /*phase*/) {}
 
   // C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C  (+ diag_add where i == j).
   // C may alias A when n <= 128 and C/A address the same rows (used by the in-place leaf solves).

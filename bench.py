@@ -155,12 +155,23 @@ def main():
         ctx.profile_enable(True)
         fit()
         p = ctx.profile_get(0)
+        stages = ctx.profile_stages()
         ctx.profile_enable(False)
+        if os.environ.get("BAYENS_PRINT_STAGES"):
+            print(stages, file=sys.stderr, flush=True)
         ctx.set_groups(args.groups)
         gemm_tflops = p["flop"] / (p["ms"] * 1e-3) / 1e12
+        traffic = None     # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if files:
+                traffic = round(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_f64_mfma", "achieved": round(gemm_tflops, 3),
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / F64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_fit_batch": p["launches"],
+                "traffic": traffic, "launches_per_fit_batch": p["launches"],
                 "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
                 "gemm_ms_per_fit_batch": round(p["ms"], 3), "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
                 "note": "HIP events around every GEMM launch of one fit batch run on ONE stream (no overlap)"}

@@ -57,6 +57,9 @@ int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
 int bayens_profile_enable(bayens_ctx* ctx, int on);
 int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
 
+/* text table "stage  ms" of the fit stages recorded (HIP events) while profiling was enabled, one stream */
+int bayens_profile_stages(bayens_ctx* ctx, char* buf, int buf_len);
+
 /* Number of member groups (HIP streams + host threads) a fit batch is split over; 1 = one stream, kernels
  * run strictly one after the other (what the per-kernel roofline measurement uses).  Default 1
  * (env BAYENS_STREAMS at context creation), at most 16.  Measured on MI355X at 32 x 2000: 2 groups tie
