@@ -83,6 +83,7 @@ def load():
     lib.bayens_test_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
     lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+    lib.bayens_bench_leaf.argtypes = [_vp, C.c_int, C.c_int, _dp, _vp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
@@ -377,6 +378,12 @@ class Context:
         ms = C.c_double()
         self._check(self.lib.bayens_bench_gemm(self.h, nb, m, n, k, flags, reps, C.byref(ms)))
         return ms.value
+
+    def bench_leaf(self, nb=32, reps=50):
+        us = C.c_double()
+        st = np.zeros(16, dtype=np.uint64)
+        self._check(self.lib.bayens_bench_leaf(self.h, nb, reps, C.byref(us), st.ctypes.data))
+        return us.value, st
 
     def test_potrf(self, A):
         A = np.array(A, dtype=np.float64, order="C", copy=True)

@@ -668,6 +668,37 @@ int bayens_bench_gemm(bayens_ctx* c, int nb, int m, int n, int k, int flags, int
   });
 }
 
+int bayens_bench_leaf(bayens_ctx* c, int nb, int reps, double* us_per_launch, unsigned long long* stamps16) {
+  return guarded(c, [&]() {
+    Stage st(c, BAYENS_DEVICE);
+    const int n = 64;
+    double* dA = st.scratch<double>((size_t)nb * n * n);
+    double* dS = st.scratch<double>((size_t)nb * n * n);
+    double* inv = st.scratch<double>((size_t)nb * n * n);
+    int* dinfo = st.scratch<int>(nb);
+    unsigned long long* dst = st.scratch<unsigned long long>(16);
+    BAYENS_HIP(hipMemsetAsync(dinfo, 0, nb * sizeof(int), c->stream));
+    BAYENS_HIP(hipMemsetAsync(dst, 0, 16 * sizeof(unsigned long long), c->stream));
+    c->prims->fill_random(dA, (size_t)nb * n * n, 7);
+    Mat A{dA, n, (long)n * n}, S{dS, n, (long)n * n};
+    // S = A A^T + 64 I  (SPD)
+    c->prims->gemm(nb, n, n, n, 1.0, A, A, 0.0, S, GEMM_TB, 64.0);
+    c->prims->copy(nb, n, S, A);
+    c->prims->leaf_stamps = dst;
+    c->prims->potrf_leaf(nb, A, inv, (long)n * n, 0, dinfo);
+    c->prims->leaf_stamps = nullptr;
+    BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+    for (int r = 0; r < reps; ++r) { c->prims->copy(nb, n, S, A); c->prims->potrf_leaf(nb, A, inv, (long)n * n, 0, dinfo); }
+    BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+    BAYENS_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    BAYENS_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    if (us_per_launch) *us_per_launch = f * 1e3 / reps;
+    if (stamps16) BAYENS_HIP(hipMemcpy(stamps16, dst, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+  });
+}
+
 int bayens_test_potrf(bayens_ctx* c, int nb, int n, double* A, int* info) {
   return guarded(c, [&]() {
     if (n % LEAF) return fail(c, BAYENS_E_ARG, "test_potrf: n must be a multiple of 64");

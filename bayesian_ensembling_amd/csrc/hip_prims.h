@@ -39,6 +39,7 @@ struct HipPrims : Prims {
   double* ssq = nullptr;      // [nb][Np]
   double* gpart = nullptr;    // [nb][tiles][2]
   size_t xs_cap = 0, ssq_cap = 0, gpart_cap = 0;
+  unsigned long long* leaf_stamps = nullptr;   // diagnostic only (bayens_bench_leaf)
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
   ~HipPrims() override;

@@ -399,8 +399,12 @@ __device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LS], int ar,
   return acc;
 }
 
+// `stamps` (diagnostic build of the call only, nullptr in the fit): wave 0 lane 0 of member 0 writes
+// s_memtime at the phase boundaries into stamps[0..]
+#define LEAF_STAMP(k) do { if (stamps && b == 0 && tid == 0) stamps[k] = __builtin_readcyclecounter(); } while (0)
+
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
-                                                         int* info) {
+                                                         int* info, unsigned long long* stamps) {
   __shared__ double S[64][LS];     // the block -> its lower factor
   __shared__ double Mi[64][LS];    // inverse of the factor
   __shared__ double Tt[4][16][LS]; // per-wave 16x16 scratch for P4
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
     }
   }
   __syncthreads();
+  LEAF_STAMP(0);
 
   for (int bj = 0; bj < 4; ++bj) {
     const int d0 = 16 * bj;
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
       }
     }
     __syncthreads();
+    LEAF_STAMP(1 + 3 * bj);
     // ---- P2: panel rows below: P <- P * inv(L_dd)^T ----
     const int nrb = 3 - bj;                         // 16-row blocks below the diagonal sub-block
     if (wave < nrb) {
@@ -468,6 +474,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
       tile_store(S, r0, d0, lane, acc);
     }
     __syncthreads();
+    LEAF_STAMP(2 + 3 * bj);
     // ---- P3: trailing update of the lower block pairs (rb >= cb > bj) ----
     {
       int p = 0;
@@ -480,6 +487,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
           }
     }
     __syncthreads();
+    LEAF_STAMP(3 + 3 * bj);
   }
 
   // ---- P4: off-diagonal 16x16 blocks of the inverse, block row I needs rows < I ----
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
     }
     __syncthreads();
   }
+  LEAF_STAMP(13);
 
   double* iv = inv + b * inv_stride;
   {
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
       iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
     }
   }
+  LEAF_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,7 +856,8 @@ void HipPrims::ensure_scratch(int nb, int Np, int R4) {
 }
 
 void HipPrims::potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
-  hipLaunchKernelGGL(potrf_leaf_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info);
+  hipLaunchKernelGGL(potrf_leaf_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info,
+                     leaf_stamps);
   LAUNCH_CHECK();
 }
 void HipPrims::copy(int nb, int n, Mat src, Mat dst) {

@@ -78,12 +78,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    force_comm = bool(os.environ.get("BAYENS_FORCE_COMM"))    # exercise the RCCL path with a single rank
+    if world > 1 or force_comm:
+        # torch (gloo) is the control plane of the multi-process run.  It must be imported BEFORE libbayens: torch
+        # bundles its own libamdhip64 / librccl (same sonames as /opt/rocm's); whichever HIP runtime is loaded
+        # first is the one the whole process uses, and RCCL only initialises on the runtime it was built against.
+        import torch.distributed as dist
     from bayesian_ensembling_amd import _lib, parallel
     ctx = _lib.Context(local_rank)          # raises when libbayens / the GPU is missing: no fallback
     ctx.set_groups(args.groups)
     host = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or force_comm:
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only (barrier, max, uid)
         host = parallel.HostGather()
         parallel.init_rccl(ctx, host)       # data plane: ncclAllGather over xGMI inside libbayens
@@ -96,7 +101,7 @@ def main():
     dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
     Mtot = M * world
     dll_loc, dvar_loc = ctx.empty((M, N)), ctx.empty((M, N))
-    if world > 1:
+    if host:
         dll_all, dmean_all, dvar_all = ctx.empty((Mtot, N)), ctx.empty((Mtot, N)), ctx.empty((Mtot, N))
     else:
         dll_all, dmean_all, dvar_all = dll_loc, dmu, dvar_loc
@@ -110,7 +115,7 @@ def main():
         # RCCL (log-likelihoods, means, variances), then normalisation over ALL members and the barycentre
         ctx.loglik_rows_basis_dev(M, N, R_obs, dbasis, dld, dobs, dll_loc)
         ctx.extract_diag_dev(M, N, dcov, dvar_loc)
-        if world > 1:
+        if host:
             ctx.allgather_rows(dll_loc, dll_all, M, N)
             ctx.allgather_rows(dmu, dmean_all, M, N)
             ctx.allgather_rows(dvar_loc, dvar_all, M, N)
@@ -183,7 +188,6 @@ def main():
             cpu = cpu_baseline(N, R, T, args.cpu_members)
     if host:
         host.barrier()
-        import torch.distributed as dist
         ctx.comm_destroy()
         dist.destroy_process_group()
 
