@@ -73,6 +73,7 @@ def load():
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_weights_normalise.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]
     lib.bayens_w2_temporal.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
+    lib.bayens_w2_single.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_barycentre.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_double,
                                       _vp, _vp, _ip]
     lib.bayens_weighted_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -317,6 +318,17 @@ class Context:
         w = np.empty((M, P))
         self._check(self.lib.bayens_w2_temporal(self.h, HOST, M, P, _ptr(mean), _ptr(var), _ptr(w)))
         return w
+
+    def w2_single(self, mu, chol=None, sd=None):
+        """ModelSimilarityWeight(mode='single'): (w [M], D [M][M]) from full-covariance factors or stddevs."""
+        mu = _f64(mu)
+        M, N = mu.shape
+        chol = None if chol is None else _f64(chol)
+        sd = None if sd is None else _f64(sd)
+        w = np.empty(M)
+        D = np.empty((M, M))
+        self._check(self.lib.bayens_w2_single(self.h, HOST, M, N, _ptr(mu), _ptr(chol), _ptr(sd), _ptr(w), _ptr(D)))
+        return w, D
 
     def barycentre(self, w, mean, var, tol=1e-6, init_var=1.0):
         w, mean, var = _f64(w), _f64(mean), _f64(var)

@@ -534,6 +534,56 @@ int bayens_w2_temporal(bayens_ctx* c, int loc, int M, int P, const double* mean,
   });
 }
 
+int bayens_w2_single(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, const double* sd,
+                     double* w, double* D) {
+  return guarded(c, [&]() {
+    if (M <= 0 || N <= 0 || !mu || !w || (!chol && !sd)) return fail(c, BAYENS_E_ARG, "w2_single: bad argument");
+    Stage st(c, loc);
+    const double* dmu = st.in(mu, (size_t)M * N);
+    double* dw = st.out(w, (size_t)M);
+    double* dD = st.out(D, (size_t)M * M);
+    double* gap = st.scratch<double>((size_t)M * M);
+    HipPrims& P = *c->prims;
+    if (!chol) {
+      const double* dsd = st.in(sd, (size_t)M * N);
+      double* dt = st.scratch<double>((size_t)M * M);
+      P.pair_terms(M, N, dmu, dsd, gap, dt);
+      P.w2_single_finish(M, nullptr, nullptr, gap, dt, dD, dw);
+      st.finish();
+      return 0;
+    }
+    const double* dch = st.in(chol, (size_t)M * N * N);
+    const int Np = pad_to_leaf(N);
+    ensure_ws(c, M, Np);
+    FitWorkspace ws = ws_view(c, 0, M);
+    BAYENS_HIP(hipMemsetAsync(ws.info, 0, (size_t)M * sizeof(int), c->stream));
+    double* Lpad = st.scratch<double>((size_t)M * Np * Np);
+    Mat Lp{Lpad, Np, (long)Np * Np};
+    P.pad_in(M, N, Np, dch, Lp);                       // identity padding: contributes exactly Np - N to every norm
+    double* tr = st.scratch<double>((size_t)M);
+    double* nuc = st.scratch<double>((size_t)M * M);
+    double* rel = st.scratch<double>((size_t)M);
+    P.dot_all(M, Np, Lp, Lp, tr);                      // tr S_i = ||L_i||_F^2 (+ padding)
+    P.pair_terms(M, N, dmu, nullptr, gap, nullptr);
+    for (int i = 0; i + 1 < M; ++i) {
+      const int nb = M - 1 - i;
+      FitWorkspace wsi = ws;
+      wsi.nb = nb;
+      nuclear_norms(P, wsi, nb, Mat{Lpad + (size_t)i * Np * Np, Np, 0}, Mat{Lpad + (size_t)(i + 1) * Np * Np, Np, (long)Np * Np},
+                    nuc + (size_t)i * M + i + 1, rel);
+    }
+    // remove the identity padding's share (Np - N) from traces and nuclear norms: both enter as tr_i + tr_j - 2 nuc,
+    // i.e. 2 (Np - N) - 2 (Np - N) = 0, so no correction is needed in D.
+    P.w2_single_finish(M, tr, nuc, gap, nullptr, dD, dw);
+    std::vector<int> hinfo(M, 0);
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), ws.info, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    for (int b = 0; b < M; ++b)
+      if (hinfo[b]) return fail(c, BAYENS_E_NOTPD, "w2_single: a polar-iteration Cholesky failed");
+    return 0;
+  });
+}
+
 int bayens_barycentre(bayens_ctx* c, int loc, int M, int P, const double* w, const double* mean, const double* var,
                       double tol, double init_var, double* mu_out, double* var_out, int* n_not_converged) {
   return guarded(c, [&]() {

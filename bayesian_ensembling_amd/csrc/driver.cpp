@@ -1,6 +1,9 @@
 // driver.cpp - see driver.h.  Pure host code: no HIP calls here, only Prims launches.
 #include "driver.h"
 
+#include <cmath>
+#include <vector>
+
 namespace bayens {
 
 constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve takes
@@ -171,6 +174,41 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
 void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
                 double* basis) {
   factor_with_basis(P, ws, N, ws.T2, mu_pad, chol, logdet, basis);
+}
+
+int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel, double ell0,
+                  double tol, int max_iters) {
+  const int Np = ws.Np;
+  const long is = ws.inv_stride();
+  Mat M = ws.K0, X = ws.Lb, Z = ws.Cb, T = ws.T1;
+  // M = L_j^T L_i  (both lower triangular: k >= max(i0, j0))
+  P.gemm(nb, Np, Np, Np, 1.0, Lj, Li, 0.0, M, GEMM_TA | GEMM_KTRIM_TN_LOWER, 0.0);
+  P.frob_normalise(nb, Np, M, X);
+  double ell = ell0;
+  std::vector<double> rel(nb);
+  int it = 0;
+  for (; it < max_iters; ++it) {
+    // dynamically weighted Halley coefficients from the current lower bound of the singular values
+    const double l2 = ell * ell;
+    const double dd = std::cbrt(4.0 * (1.0 - l2) / (l2 * l2));
+    const double a = std::sqrt(1.0 + dd) + 0.5 * std::sqrt(8.0 - 4.0 * dd + 8.0 * (2.0 - l2) / (l2 * std::sqrt(1.0 + dd)));
+    const double b = (a - 1.0) * (a - 1.0) / 4.0, c = a + b - 1.0;
+    // Z = I + c X^T X = W W^T ;  X <- (b/c) X + (a - b/c) X Z^-1
+    P.gemm(nb, Np, Np, Np, c, X, X, 0.0, Z, GEMM_TA | GEMM_TRI_OUT | GEMM_ZERO_SKIPPED, 1.0);
+    potrf(P, nb, Np, Z, ws.invC, is, ws.info);
+    P.copy(nb, Np, X, T);
+    trsm_rlt(P, nb, Np, Np, Z, ws.invC, is, T);
+    trsm_rln(P, nb, Np, Np, Z, ws.invC, is, T, false);
+    P.axpby_rel(nb, Np, b / c, X, a - b / c, T, scratch_rel);
+    ell = ell * (a + b * l2) / (1.0 + c * l2);
+    if (ell > 1.0) ell = 1.0;
+    P.read_back(scratch_rel, rel.data(), nb);
+    double worst = 0.0;
+    for (double r : rel) worst = r > worst || r != r ? r : worst;
+    if (worst < tol) { ++it; break; }
+  }
+  P.dot_all(nb, Np, X, M, nuc);    // ||M||_* = tr(U^T M)
+  return it;
 }
 
 double fit_flops(int N, int R, int n_iters) {

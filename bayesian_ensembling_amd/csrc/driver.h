@@ -62,6 +62,15 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
 void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
                 double* basis);
 
+// Nuclear norms ||L_j^T L_i||_* for nb pairs sharing L_i (Li: stride-0 Mat) - the trace term of the Gaussian
+// W2 distance of ensembles/wasserstein.py:41-45: tr (S_i^1/2 S_j S_i^1/2)^1/2 = sum of singular values of L_j^T L_i.
+// Polar factor by the Cholesky form of the QDWH iteration (Nakatsukasa, Bai, Gygi 2010): per step one X^T X,
+// one Cholesky and two triangular solves, all on the existing batched primitives; <= max_iters steps, stops when
+// every pair moved by less than tol.  Lj: the nb factors L_j (padded, lower).  Uses ws.K0 (M), ws.Lb (X), ws.Cb (Z),
+// ws.T1 (T).  nuc: device [nb], scratch_rel: device [nb].  Returns the number of iterations taken.
+int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel,
+                  double ell0 = 1e-7, double tol = 1e-13, int max_iters = 16);
+
 // Algorithmic flop of one member fit (2 flop per FMA, triangular structure exploited).
 double fit_flops(int N, int R, int n_iters);
 

@@ -74,6 +74,14 @@ struct HipPrims : Prims {
   void extract_vec(int nb, int N, int Np, const double* src, double* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;
+  void frob_normalise(int nb, int n, Mat M, Mat X) override;
+  void axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) override;
+  void dot_all(int nb, int n, Mat A, Mat B, double* out) override;
+  void read_back(const double* dev, double* host, int n) override;
+  // ModelSimilarityWeight(mode='single') assembly (compact [M][N] inputs, [M][M] tables)
+  void pair_terms(int M, int N, const double* mu, const double* sd, double* gap, double* diagterm);
+  void w2_single_finish(int M, const double* tr, const double* nuc, const double* gap, const double* diagterm,
+                        double* D, double* w);
 
   // not part of the driver interface: pad a compact [nb][N][N] matrix into a padded Mat (identity pad)
   void pad_in(int nb, int N, int Np, const double* src, Mat dst);

@@ -823,6 +823,116 @@ __global__ void weighted_model_mean_kernel(int M, int R_max, const int* R, int P
   var_out[t] = wv;
 }
 
+// ------------------------------------------------------------------------------------------------
+// full-covariance Wasserstein distance (wasserstein.py:21-47, weights.py:240-265): reductions around the
+// polar iteration of driver.cpp::nuclear_norms.  Two-phase deterministic reductions: 64x64 tile partials,
+// then one small kernel per member.
+// ------------------------------------------------------------------------------------------------
+// mode 0: p0 = sum A^2 (Frobenius);  mode 1: X <- a X + b T, p0 = sum (new-old)^2, p1 = sum new^2;
+// mode 2: p0 = sum A B
+__global__ __launch_bounds__(256) void tile_reduce_kernel(int mode, Mat A, Mat B, double a, double bcoef, double* part) {
+  __shared__ double red[2][4];
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  double* pa = A.p + b * A.stride;
+  const double* pb = B.p ? B.p + b * B.stride : nullptr;
+  double s0 = 0.0, s1 = 0.0;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    double* x = pa + (long)i * A.ld + j;
+    if (mode == 0) { s0 += (*x) * (*x); }
+    else if (mode == 1) {
+      const double nv = a * (*x) + bcoef * pb[(long)i * B.ld + j];
+      const double d = nv - *x;
+      s0 += d * d; s1 += nv * nv;
+      *x = nv;
+    } else { s0 += (*x) * pb[(long)i * B.ld + j]; }
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long t = (long)blockIdx.y * gridDim.x + blockIdx.x, nt = (long)gridDim.x * gridDim.y;
+    part[((long)b * nt + t) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[((long)b * nt + t) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// mode 0: out = sqrt(p0) ; mode 1: out = sqrt(p0 / p1) ; mode 2: out = p0
+__global__ void tile_finish_kernel(int mode, int ntiles, const double* part, double* out) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) { s0 += part[((long)b * ntiles + t) * 2]; s1 += part[((long)b * ntiles + t) * 2 + 1]; }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) { red[0][threadIdx.x] += red[0][threadIdx.x + s2]; red[1][threadIdx.x] += red[1][threadIdx.x + s2]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = mode == 0 ? sqrt(red[0][0]) : (mode == 1 ? sqrt(red[0][0] / red[1][0]) : red[0][0]);
+}
+
+__global__ void scale_by_norm_kernel(int n, Mat M, Mat X, const double* norms) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double r = 1.0 / norms[b];
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    X.p[b * X.stride + (long)i * X.ld + j] = M.p[b * M.stride + (long)i * M.ld + j] * r;
+  }
+}
+
+// one workgroup per ordered pair (i, j): ||mu_i - mu_j||_2 and, for diagonal posteriors, sum_t (sd_i - sd_j)^2
+__global__ __launch_bounds__(256) void pair_terms_kernel(int M, int N, const double* mu, const double* sd, double* gap,
+                                                         double* diagterm) {
+  __shared__ double red[2][4];
+  const int i = blockIdx.x / M, j = blockIdx.x % M;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = threadIdx.x; t < N; t += 256) {
+    const double d = mu[(long)i * N + t] - mu[(long)j * N + t];
+    s0 += d * d;
+    if (sd) { const double e = sd[(long)i * N + t] - sd[(long)j * N + t]; s1 += e * e; }
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gap[(long)i * M + j] = sqrt((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));   // un-squared norm (wasserstein.py:40)
+    if (diagterm) diagterm[(long)i * M + j] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// D[i][j] = gap + tr_i + tr_j - 2 nuc_ij (full covariance; nuc holds i<j, D[i][i] = 0) or gap + diagterm;
+// w_i = mean_j D[i][j] / sum_i mean_j D[i][j]      (weights.py:259-265,331)
+__global__ void w2_single_finish_kernel(int M, const double* tr, const double* nuc, const double* gap,
+                                        const double* diagterm, double* D, double* w) {
+  __shared__ double rowmean[1024];
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    double s = 0.0;
+    for (int j = 0; j < M; ++j) {
+      double d;
+      if (diagterm) d = gap[(long)i * M + j] + diagterm[(long)i * M + j];
+      else if (i == j) d = 0.0;
+      else {
+        const double nn = i < j ? nuc[(long)i * M + j] : nuc[(long)j * M + i];
+        d = gap[(long)i * M + j] + ((tr[i] + tr[j]) - 2.0 * nn);
+      }
+      if (D) D[(long)i * M + j] = d;
+      s += d;
+    }
+    rowmean[i] = s / M;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < M; ++i) tot += rowmean[i];
+    for (int i = 0; i < M; ++i) w[i] = rowmean[i] / tot;
+  }
+}
+
 inline dim3 tile_grid(int n, int nb) { return dim3(n / 64, n / 64, nb); }
 inline dim3 tile_grid_up(int n, int nb) { return dim3((n + 63) / 64, (n + 63) / 64, nb); }
 
@@ -959,6 +1069,40 @@ void HipPrims::logdet(int nb, int N, Mat Lc, double* out) {
 }
 void HipPrims::hyp_out(int nb, const double* ustate, double* hyp) {
   hipLaunchKernelGGL(hyp_out_kernel, dim3((nb + 63) / 64), dim3(64), 0, stream, nb, ustate, hyp);
+  LAUNCH_CHECK();
+}
+void HipPrims::frob_normalise(int nb, int n, Mat M, Mat X) {
+  ensure_scratch(nb, n, 4);
+  double* norms = ssq;    // [nb] (ssq holds >= nb * n doubles)
+  hipLaunchKernelGGL(tile_reduce_kernel, tile_grid(n, nb), dim3(256), 0, stream, 0, M, Mat{nullptr, 0, 0}, 0.0, 0.0, gpart);
+  hipLaunchKernelGGL(tile_finish_kernel, dim3(nb), dim3(256), 0, stream, 0, (n / 64) * (n / 64), gpart, norms);
+  hipLaunchKernelGGL(scale_by_norm_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, M, X, norms);
+  LAUNCH_CHECK();
+}
+void HipPrims::axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) {
+  ensure_scratch(nb, n, 4);
+  hipLaunchKernelGGL(tile_reduce_kernel, tile_grid(n, nb), dim3(256), 0, stream, 1, X, T, a, b, gpart);
+  hipLaunchKernelGGL(tile_finish_kernel, dim3(nb), dim3(256), 0, stream, 1, (n / 64) * (n / 64), gpart, rel);
+  LAUNCH_CHECK();
+}
+void HipPrims::dot_all(int nb, int n, Mat A, Mat B, double* out) {
+  ensure_scratch(nb, n, 4);
+  hipLaunchKernelGGL(tile_reduce_kernel, tile_grid(n, nb), dim3(256), 0, stream, 2, A, B, 0.0, 0.0, gpart);
+  hipLaunchKernelGGL(tile_finish_kernel, dim3(nb), dim3(256), 0, stream, 2, (n / 64) * (n / 64), gpart, out);
+  LAUNCH_CHECK();
+}
+void HipPrims::read_back(const double* dev, double* host, int n) {
+  BAYENS_HIP(hipMemcpyAsync(host, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  BAYENS_HIP(hipStreamSynchronize(stream));
+}
+void HipPrims::pair_terms(int M, int N, const double* mu, const double* sd, double* gap, double* diagterm) {
+  hipLaunchKernelGGL(pair_terms_kernel, dim3(M * M), dim3(256), 0, stream, M, N, mu, sd, gap, diagterm);
+  LAUNCH_CHECK();
+}
+void HipPrims::w2_single_finish(int M, const double* tr, const double* nuc, const double* gap, const double* diagterm,
+                                double* D, double* w) {
+  if (M > 1024) throw HipError{-1, "w2_single: at most 1024 members"};
+  hipLaunchKernelGGL(w2_single_finish_kernel, dim3(1), dim3(256), 0, stream, M, tr, nuc, gap, diagterm, D, w);
   LAUNCH_CHECK();
 }
 void HipPrims::pad_in(int nb, int N, int Np, const double* src, Mat dst) {

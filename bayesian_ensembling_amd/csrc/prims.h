@@ -95,6 +95,16 @@ struct Prims {
   virtual void extract_vec(int nb, int N, int Np, const double* src, double* dst) = 0;
   virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii
   virtual void hyp_out(int nb, const double* ustate, double* hyp) = 0;  // softplus(u) -> (variance, lengthscale)
+
+  // ---- pieces of the full-covariance Wasserstein distance (polar iteration on L_j^T L_i) ----
+  // X = M / ||M||_F per member (Frobenius norms are not returned)
+  virtual void frob_normalise(int nb, int n, Mat M, Mat X) = 0;
+  // X <- a X + b T ; rel[b] = ||X_new - X_old||_F / ||X_new||_F   (rel: device array [nb])
+  virtual void axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) = 0;
+  // out[b] = sum_ij A_ij B_ij over the n x n matrices (out: device array [nb])
+  virtual void dot_all(int nb, int n, Mat A, Mat B, double* out) = 0;
+  // synchronise and copy n device doubles to the host (the only host read-back of the polar iteration)
+  virtual void read_back(const double* dev, double* host, int n) = 0;
 };
 
 }  // namespace bayens

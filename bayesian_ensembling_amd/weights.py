@@ -114,8 +114,23 @@ class ModelSimilarityWeight(AbstractWeight):
                              "time": process_models[0].model_data.coords["time"]},
                             "Model similarity weights")
             return out
-        if mode in ("single", "spatial"):
+        if mode == "single":
+            ctx = _lib.default_context()
+            dists = [m.distribution._dist for m in process_models.models]
+            mu = np.stack([np.asarray(d.mean()).reshape(-1) for d in dists])
+            if all(isinstance(d, dx.MultivariateNormalFullCovariance) for d in dists):
+                w, _ = ctx.w2_single(mu, chol=np.stack([d._scale_tri for d in dists]))
+            elif all(isinstance(d, dx.Normal) for d in dists):
+                # full_cov=False: sigma = diag(variance()) (wasserstein.py:35-38) -> the trace term is sum (sd_i - sd_j)^2
+                w, _ = ctx.w2_single(mu, sd=np.stack([np.asarray(d.stddev()).reshape(-1) for d in dists]))
+            else:
+                raise NotImplementedError("mode='single' needs all-full-covariance or all-dx.Normal posteriors")
+            return DataArray(w[:, None], ("model", "time"),
+                             {"model": np.asarray(process_models.model_names), "time": np.asarray([0])},
+                             "Model similarity weights")
+        if mode == "spatial":
             raise NotImplementedError(
-                f"ModelSimilarityWeight(mode='{mode}') is not on the device yet (full-covariance W2 needs a "
-                "batched symmetric eigen-solver; SURVEY 8(e)/7-9).  Use mode='temporal'.")
+                "ModelSimilarityWeight(mode='spatial') needs spatial posteriors (GPDTW3D), which are out of scope; "
+                "the reference's own full-covariance branch of this mode references a non-existent dx.MultiVariate "
+                "(weights.py:284).")
         raise ValueError('Mode must be "single", "spatial", or "temporal"')

@@ -121,6 +121,14 @@ int bayens_weights_normalise(bayens_ctx* ctx, int loc, int M, int P, const doubl
 int bayens_w2_temporal(bayens_ctx* ctx, int loc, int M, int P, const double* mean,
                        const double* var, double* w);
 
+/* ModelSimilarityWeight mode='single' (ensembles/weights.py:240-265,331 + ensembles/wasserstein.py:10-47):
+ * D[i][j] = ||mu_i - mu_j||_2 + tr(S_i + S_j - 2 (S_i^1/2 S_j S_i^1/2)^1/2), w_i = mean_j D[i][j] / sum.
+ * Full-covariance posteriors: chol [M][N][N] are the lower factors (S = L L^T); the trace of the matrix square
+ * root is the nuclear norm of L_j^T L_i, obtained from a polar iteration (no SVD).  Diagonal posteriors
+ * (dx.Normal): pass chol = NULL and sd [M][N] = the distributions' stddev().  D [M][M] may be NULL. */
+int bayens_w2_single(bayens_ctx* ctx, int loc, int M, int N, const double* mu, const double* chol,
+                     const double* sd, double* w, double* D);
+
 /* Barycentre._compute (ensembles/ensemble_scheme.py:52-78) + gaussian_barycentre
  * (ensembles/wasserstein.py:61-100).  w, mean, var [M][P]; mu_out, var_out [P] (var_out = sigma*^2). */
 int bayens_barycentre(bayens_ctx* ctx, int loc, int M, int P, const double* w, const double* mean,

@@ -285,6 +285,33 @@ struct CpuPrims : Prims {
       out[b] = s;
     }
   }
+  void frob_normalise(int nb, int n, Mat M, Mat X) override {
+    for (int b = 0; b < nb; ++b) {
+      double s = 0;
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double v = M.p[b * M.stride + (size_t)i * M.ld + j]; s += v * v; }
+      s = 1.0 / std::sqrt(s);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) X.p[b * X.stride + (size_t)i * X.ld + j] = M.p[b * M.stride + (size_t)i * M.ld + j] * s;
+    }
+  }
+  void axpby_rel(int nb, int n, double a, Mat X, double bb, Mat T, double* rel) override {
+    for (int b = 0; b < nb; ++b) {
+      double d = 0, s = 0;
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        double& x = X.p[b * X.stride + (size_t)i * X.ld + j];
+        double nv = a * x + bb * T.p[b * T.stride + (size_t)i * T.ld + j];
+        d += (nv - x) * (nv - x); s += nv * nv; x = nv;
+      }
+      rel[b] = std::sqrt(d / s);
+    }
+  }
+  void dot_all(int nb, int n, Mat A, Mat B, double* out) override {
+    for (int b = 0; b < nb; ++b) {
+      double s = 0;
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) s += A.p[b * A.stride + (size_t)i * A.ld + j] * B.p[b * B.stride + (size_t)i * B.ld + j];
+      out[b] = s;
+    }
+  }
+  void read_back(const double* dev, double* host, int n) override { std::memcpy(host, dev, n * sizeof(double)); }
   void hyp_out(int nb, const double* ustate, double* hyp) override {
     for (int b = 0; b < nb; ++b) { hyp[b * 2] = softplus(ustate[b * 8]); hyp[b * 2 + 1] = softplus(ustate[b * 8 + 1]); }
   }
@@ -365,4 +392,22 @@ int hostcheck_trsm(int nb, int m, int n, const double* L, double* Bm, int mode, 
 }
 
 double hostcheck_fit_flops(int N, int R, int T) { return fit_flops(N, R, T); }
+
+// nuclear norms ||L_j^T L_0||_* for j = 1..nb of compact lower factors L [nb+1][N][N] (identity padding; the
+// padding's contribution Np - N is removed)
+int hostcheck_nuclear(int nb, int N, const double* L, double* nuc) {
+  CpuPrims P;
+  const int Np = pad_to_leaf(N);
+  HostWs h(nb + 1, Np);
+  std::vector<double> Lp((size_t)(nb + 1) * Np * Np, 0.0), rel(nb + 1), out(nb + 1);
+  for (int b = 0; b <= nb; ++b)
+    for (int i = 0; i < Np; ++i)
+      for (int j = 0; j <= i; ++j)
+        Lp[((size_t)b * Np + i) * Np + j] = (i < N && j < N) ? L[((size_t)b * N + i) * N + j] : (i == j ? 1.0 : 0.0);
+  Mat Li{Lp.data(), Np, 0}, Lj{Lp.data() + (size_t)Np * Np, Np, (long)Np * Np};
+  h.ws.nb = nb;
+  int it = nuclear_norms(P, h.ws, nb, Li, Lj, out.data(), rel.data());
+  for (int b = 0; b < nb; ++b) nuc[b] = out[b] - (Np - N);
+  return it;
+}
 }

@@ -61,6 +61,32 @@ def test_w2_temporal(ctx):
     assert relerr(ctx.w2_temporal(mean, var), go.w2_weights_temporal(mean, var)) < 1e-13
 
 
+@pytest.mark.parametrize("M,N", [(4, 40), (3, 100), (5, 64)])
+def test_w2_single_full_covariance(ctx, M, N):
+    """mode='single' (weights.py:240-265): all-pairs Gaussian W2 with SVD-based sqrtm in the oracle, polar iteration
+    on L_j^T L_i on the device."""
+    data, _, out = _posteriors(ctx, M, N, R=5, seed=11)
+    w, D = ctx.w2_single(out["mu"], chol=out["chol"])
+    w_ref, D_ref = go.w2_weights_single(list(out["mu"]), list(out["cov"]))
+    off = ~np.eye(M, dtype=bool)
+    assert relerr(D[off], D_ref[off]) < 1e-9
+    assert np.all(np.abs(D_ref[~off]) < 1e-9) and not D[~off].any()      # i == j: exactly 0 here, ~1e-12 noise there
+    assert relerr(w, w_ref) < 1e-9 and abs(w.sum() - 1.0) < 1e-14
+    assert np.allclose(D, D.T, rtol=0, atol=0)
+
+
+def test_w2_single_diagonal_posteriors(ctx):
+    rng = np.random.default_rng(12)
+    M, N = 4, 33
+    mu, sd = rng.standard_normal((M, N)), rng.uniform(0.1, 2.0, (M, N))
+    w, D = ctx.w2_single(mu, sd=sd)
+    D_ref = np.array([[go.gaussian_w2(mu[i], np.diag(sd[i] ** 2), mu[j], np.diag(sd[j] ** 2)) for j in range(M)]
+                      for i in range(M)])
+    assert relerr(D, D_ref) < 1e-10
+    v = D_ref.mean(axis=1)
+    assert relerr(w, v / v.sum()) < 1e-10
+
+
 def test_barycentre_both_sides_of_the_signed_test(ctx):
     rng = np.random.default_rng(3)
     M, P = 6, 500
@@ -118,6 +144,10 @@ def test_weightings_api(ctx, n_models, obs_n_reals):
         assert isinstance(weights, DataArray)
         assert weights.shape == (n_models,) + obs.model_data.mean("realisation").shape
         assert np.all(weights.sum("model").values == pytest.approx(1.0, 1e-6))
+    single = es.ModelSimilarityWeight()(mc)                      # the reference's default mode
+    assert single.shape == (n_models, 1) and single.sum("model").values == pytest.approx(1.0, 1e-12)
+    w_ref, _ = go.w2_weights_single([m.distribution.mu for m in mc.models], [m.distribution.covariance for m in mc.models])
+    assert relerr(single.values[:, 0], w_ref) < 1e-8
     # the whole path against the oracle
     data = np.stack([m.model_data.values for m in mc.models])
     X, y, nu = member_inputs(data)

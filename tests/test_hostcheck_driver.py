@@ -83,3 +83,18 @@ def test_flop_model(hostcheck):
     f = hostcheck.hostcheck_fit_flops(2000, 8, 2)
     n3 = 2000.0 ** 3
     assert abs(f - (2 * (14 / 3 * n3 + 2 * 2000 * 2000 * 8) + 13 / 3 * n3 + 2 * 2000 * 2000 * 8 + n3 / 3)) < 1.0
+
+
+def test_polar_iteration_gives_the_w2_trace_term(hostcheck):
+    """||L_j^T L_i||_* from the QDWH polar iteration == tr (S_i^1/2 S_j S_i^1/2)^1/2 of wasserstein.py:41-45."""
+    rng = np.random.default_rng(0)
+    N, nb = 40, 3
+    covs = []
+    for b in range(nb + 1):
+        A = rng.standard_normal((N, N))
+        covs.append(A @ A.T / N + 0.01 * (1 + b) * np.eye(N))
+    L = np.ascontiguousarray(np.stack([np.linalg.cholesky(c) for c in covs]))
+    nuc = np.zeros(nb)
+    iters = hostcheck.hostcheck_nuclear(nb, N, P(L), P(nuc))
+    ref = [np.trace(go.sqrtm_svd(go.sqrtm_svd(covs[0]) @ covs[j] @ go.sqrtm_svd(covs[0]))) for j in range(1, nb + 1)]
+    assert iters <= 8 and relerr(nuc, np.array(ref)) < 1e-12
