@@ -4,10 +4,11 @@ path of mattramos/bayesian_ensembling (reference package name: `ensembles`).
 Same public names as ensembles/__init__.py for that path; the arithmetic runs in hand-written HIP kernels
 (libbayens.so, include/bayens.h) reached through ctypes.  There is no CPU fallback."""
 from .data import Distribution, ModelCollection, ProcessModel
-from .ensemble_scheme import AbstractEnsembleScheme, Barycentre, WeightedModelMean
+from .ensemble_scheme import AbstractEnsembleScheme, Barycentre, MultiModelMean, WeightedModelMean
 from .labelled import DataArray, concat
-from .models import GPDTW1D
-from .weights import AbstractWeight, LogLikelihoodWeight, ModelSimilarityWeight
+from .models import GPDTW1D, MeanFieldApproximation
+from .weights import (AbstractWeight, CRPSWeight, InverseSquareWeight, KSDWeight, LogLikelihoodWeight,
+                      ModelSimilarityWeight, UniformWeight)
 from . import distributions
 
 __version__ = "0.1.0"

@@ -77,6 +77,9 @@ def load():
     lib.bayens_barycentre.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_double,
                                       _vp, _vp, _ip]
     lib.bayens_weighted_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    lib.bayens_score_weights.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_inverse_square_weights.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
+    lib.bayens_multi_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
     lib.bayens_comm_unique_id.argtypes = [_vp, _vp]
     lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.bayens_comm_destroy.argtypes = [_vp]
@@ -358,6 +361,32 @@ class Context:
         v = np.empty(P)
         self._check(self.lib.bayens_weighted_model_mean(self.h, HOST, M, R_max, _ptr(R), P, _ptr(data), _ptr(w),
                                                         _ptr(mu), _ptr(v)))
+        return mu, v
+
+    def score_weights(self, kind, mean, var, obs):
+        """kind 'crps' | 'ksd' -> (w [M][P], score [M][P])"""
+        mean, var, obs = _f64(mean), _f64(var), _f64(obs)
+        M, P = mean.shape
+        w, sc = np.empty((M, P)), np.empty((M, P))
+        self._check(self.lib.bayens_score_weights(self.h, HOST, {"crps": 0, "ksd": 1}[kind], M, P, obs.shape[0],
+                                                  _ptr(mean), _ptr(var), _ptr(obs), _ptr(w), _ptr(sc)))
+        return w, sc
+
+    def inverse_square_weights(self, data, R, obs):
+        data, obs = _f64(data), _f64(obs)
+        M, R_max, P = data.shape
+        R = np.ascontiguousarray(R, dtype=np.int32)
+        w = np.empty((M, P))
+        self._check(self.lib.bayens_inverse_square_weights(self.h, HOST, M, R_max, _ptr(R), P, _ptr(data), obs.shape[0],
+                                                           _ptr(obs), _ptr(w)))
+        return w
+
+    def multi_model_mean(self, data, R):
+        data = _f64(data)
+        M, R_max, P = data.shape
+        R = np.ascontiguousarray(R, dtype=np.int32)
+        mu, v = np.empty(P), np.empty(P)
+        self._check(self.lib.bayens_multi_model_mean(self.h, HOST, M, R_max, _ptr(R), P, _ptr(data), _ptr(mu), _ptr(v)))
         return mu, v
 
     # -- RCCL ------------------------------------------------------------------------------------------

@@ -622,6 +622,55 @@ int bayens_weighted_model_mean(bayens_ctx* c, int loc, int M, int R_max, const i
   });
 }
 
+int bayens_score_weights(bayens_ctx* c, int loc, int kind, int M, int P, int R_obs, const double* mean,
+                         const double* var, const double* obs, double* w, double* score) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || R_obs <= 0 || kind < 0 || kind > 1 || !mean || !var || !obs || !w)
+      return fail(c, BAYENS_E_ARG, "score_weights: bad argument");
+    Stage st(c, loc);
+    const double* dm = st.in(mean, (size_t)M * P);
+    const double* dv = st.in(var, (size_t)M * P);
+    const double* dobs = st.in(obs, (size_t)R_obs * P);
+    double* dw = st.out(w, (size_t)M * P);
+    double* ds = st.out(score, (size_t)M * P);
+    c->prims->score_weights(kind, M, P, R_obs, dm, dv, dobs, dw, ds);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_inverse_square_weights(bayens_ctx* c, int loc, int M, int R_max, const int* R, int P, const double* data,
+                                  int R_obs, const double* obs, double* w) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || R_max <= 0 || R_obs <= 0 || !R || !data || !obs || !w)
+      return fail(c, BAYENS_E_ARG, "inverse_square_weights: bad argument");
+    Stage st(c, loc);
+    const int* dR = st.in(R, (size_t)M);
+    const double* dd = st.in(data, (size_t)M * R_max * P);
+    const double* dobs = st.in(obs, (size_t)R_obs * P);
+    double* dw = st.out(w, (size_t)M * P);
+    c->prims->inverse_square_weights(M, R_max, dR, P, dd, R_obs, dobs, dw);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_multi_model_mean(bayens_ctx* c, int loc, int M, int R_max, const int* R, int P, const double* data,
+                            double* mu_out, double* var_out) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || R_max <= 0 || !R || !data || !mu_out || !var_out)
+      return fail(c, BAYENS_E_ARG, "multi_model_mean: bad argument");
+    Stage st(c, loc);
+    const int* dR = st.in(R, (size_t)M);
+    const double* dd = st.in(data, (size_t)M * R_max * P);
+    double* dmu = st.out(mu_out, (size_t)P);
+    double* dvar = st.out(var_out, (size_t)P);
+    c->prims->multi_model_mean(M, R_max, dR, P, dd, dmu, dvar);
+    st.finish();
+    return 0;
+  });
+}
+
 // ---- RCCL ---------------------------------------------------------------------------------------
 int bayens_comm_unique_id(bayens_ctx* c, void* id128) {
   return guarded(c, [&]() {

@@ -103,6 +103,12 @@ struct HipPrims : Prims {
   void weighted_model_mean(int M, int R_max, const int* R, int P, const double* data, const double* w,
                            double* mu_out, double* var_out);
   void extract_diag(int B, int N, const double* cov, double* var);
+  // kind 0 = CRPS, 1 = KSD; score (nullable) receives the un-inverted scores
+  void score_weights(int kind, int M, int P, int R_obs, const double* mean, const double* var, const double* obs,
+                     double* w, double* score);
+  void inverse_square_weights(int M, int R_max, const int* R, int P, const double* data, int R_obs, const double* obs,
+                              double* w);
+  void multi_model_mean(int M, int R_max, const int* R, int P, const double* data, double* mu_out, double* var_out);
 };
 
 }  // namespace bayens

@@ -933,6 +933,100 @@ __global__ void w2_single_finish_kernel(int M, const double* tr, const double* n
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the remaining weight plug-ins, one thread per point, [M][P] tables
+// ------------------------------------------------------------------------------------------------
+// CRPSWeight (weights.py:444-515): properscoring.crps_gaussian against Normal(mean, scale = variance)
+__global__ void crps_weights_kernel(int M, int P, int R_obs, const double* mean, const double* var, const double* obs,
+                                    double* w, double* score) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  const double inv_sqrt_pi = 0.5641895835477563, inv_sqrt_2pi = 0.3989422804014327, inv_sqrt2 = 0.7071067811865476;
+  double tot = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double mu = mean[(long)m * P + t], sg = var[(long)m * P + t];
+    double acc = 0.0;
+    for (int r = 0; r < R_obs; ++r) {
+      const double z = (obs[(long)r * P + t] - mu) / sg;
+      const double cdf = 0.5 * erfc(-z * inv_sqrt2), pdf = inv_sqrt_2pi * exp(-0.5 * z * z);
+      acc += sg * (z * (2.0 * cdf - 1.0) + 2.0 * pdf - inv_sqrt_pi);
+    }
+    const double sc = acc / R_obs;
+    if (score) score[(long)m * P + t] = sc;
+    w[(long)m * P + t] = 1.0 / sc;
+    tot += 1.0 / sc;
+  }
+  for (int m = 0; m < M; ++m) w[(long)m * P + t] /= tot;
+}
+
+// KSDWeight (weights.py:336-441): inverse-multiquadric Stein kernel, c = 1, beta = -1/2, d = 1
+__global__ void ksd_weights_kernel(int M, int P, int R_obs, const double* mean, const double* var, const double* obs,
+                                   double* w, double* score) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  const double beta = -0.5;
+  double tot = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double mu = mean[(long)m * P + t], v = var[(long)m * P + t];
+    const double iv2 = 1.0 / (v * v);
+    double sum = 0.0;
+    for (int a = 0; a < R_obs; ++a) {
+      const double xa = obs[(long)a * P + t], ga = -(xa - mu) * iv2;
+      for (int b = 0; b < R_obs; ++b) {
+        const double xb = obs[(long)b * P + t], gb = -(xb - mu) * iv2;
+        const double diff = xa - xb, q = 1.0 + diff * diff;
+        const double qb = pow(q, beta), qb1 = qb / q, qb2 = qb1 / q;
+        sum += ga * gb * qb - 2.0 * beta * ga * diff * qb1 + 2.0 * beta * gb * diff * qb1 - 2.0 * beta * qb1 -
+               4.0 * beta * (beta - 1.0) * qb2 * diff * diff;
+      }
+    }
+    const double ksd = sqrt(sum) / R_obs;
+    if (score) score[(long)m * P + t] = ksd;
+    w[(long)m * P + t] = 1.0 / ksd;
+    tot += 1.0 / ksd;
+  }
+  for (int m = 0; m < M; ++m) w[(long)m * P + t] /= tot;
+}
+
+// InverseSquareWeight (weights.py:157-169)
+__global__ void inverse_square_weights_kernel(int M, int R_max, const int* R, int P, const double* data, int R_obs,
+                                              const double* obs, double* w) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double om = 0.0;
+  for (int r = 0; r < R_obs; ++r) om += obs[(long)r * P + t];
+  om /= R_obs;
+  double tot = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double* d = data + (long)m * R_max * P;
+    double s = 0.0;
+    for (int r = 0; r < R[m]; ++r) s += d[(long)r * P + t];
+    const double e = s / R[m] - om;
+    const double raw = 1.0 / (e * e);
+    w[(long)m * P + t] = raw;
+    tot += raw;
+  }
+  for (int m = 0; m < M; ++m) w[(long)m * P + t] /= tot;
+}
+
+// MultiModelMean (ensemble_scheme.py:108-128): mean and std**2 over every realisation of every model
+__global__ void multi_model_mean_kernel(int M, int R_max, const int* R, int P, const double* data, double* mu_out,
+                                        double* var_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  double s = 0.0;
+  int n = 0;
+  for (int m = 0; m < M; ++m)
+    for (int r = 0; r < R[m]; ++r) { s += data[((long)m * R_max + r) * P + t]; ++n; }
+  const double mean = s / n;
+  double q = 0.0;
+  for (int m = 0; m < M; ++m)
+    for (int r = 0; r < R[m]; ++r) { const double e = data[((long)m * R_max + r) * P + t] - mean; q += e * e; }
+  const double sd = sqrt(q / n);
+  mu_out[t] = mean;
+  var_out[t] = sd * sd;
+}
+
 inline dim3 tile_grid(int n, int nb) { return dim3(n / 64, n / 64, nb); }
 inline dim3 tile_grid_up(int n, int nb) { return dim3((n + 63) / 64, (n + 63) / 64, nb); }
 
@@ -1156,6 +1250,24 @@ void HipPrims::weighted_model_mean(int M, int R_max, const int* R, int P, const 
                                    double* mu_out, double* var_out) {
   hipLaunchKernelGGL(weighted_model_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, R_max, R, P, data, w,
                      mu_out, var_out);
+  LAUNCH_CHECK();
+}
+void HipPrims::score_weights(int kind, int M, int P, int R_obs, const double* mean, const double* var,
+                             const double* obs, double* w, double* score) {
+  if (kind == 0) hipLaunchKernelGGL(crps_weights_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, R_obs, mean, var, obs, w, score);
+  else hipLaunchKernelGGL(ksd_weights_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, R_obs, mean, var, obs, w, score);
+  LAUNCH_CHECK();
+}
+void HipPrims::inverse_square_weights(int M, int R_max, const int* R, int P, const double* data, int R_obs,
+                                      const double* obs, double* w) {
+  hipLaunchKernelGGL(inverse_square_weights_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, R_max, R, P, data,
+                     R_obs, obs, w);
+  LAUNCH_CHECK();
+}
+void HipPrims::multi_model_mean(int M, int R_max, const int* R, int P, const double* data, double* mu_out,
+                                double* var_out) {
+  hipLaunchKernelGGL(multi_model_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, R_max, R, P, data, mu_out,
+                     var_out);
   LAUNCH_CHECK();
 }
 void HipPrims::extract_diag(int B, int N, const double* cov, double* var) {

@@ -55,6 +55,22 @@ class Barycentre(AbstractEnsembleScheme):
                             dist_type=dx.MultivariateNormalDiag)
 
 
+class MultiModelMean(AbstractEnsembleScheme):
+    def __init__(self, name: str = "MultiModelMean") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, weights=None) -> Distribution:
+        """ensemble_scheme.py:108-128: mean and std**2 over every realisation of every model."""
+        models = list(process_models.models)
+        R = np.array([m.n_realisations for m in models], dtype=np.int32)
+        P = int(models[0].model_data.size / models[0].n_realisations)
+        data = np.zeros((len(models), int(R.max()), P))
+        for i, m in enumerate(models):
+            data[i, :R[i]] = np.asarray(m.model_data.values, dtype=np.float64).reshape(R[i], -1)
+        mu, v = _lib.default_context().multi_model_mean(data, R)
+        return Distribution(mu=mu, covariance=v, dim_array=_blank(models[0]), dist_type=dx.MultivariateNormalDiag)
+
+
 class WeightedModelMean(AbstractEnsembleScheme):
     def __init__(self, name: str = "MultiModelMean") -> None:   # (sic) the reference names it "MultiModelMean"
         super().__init__(name)

@@ -73,3 +73,20 @@ class GPDTW1D:
 
     def fit(self, model, n_optim_nits: int = 500, compile_objective: bool = False, progress_bar: bool = True):
         return self.fit_collection([model], n_optim_nits, compile_objective, progress_bar)[0]
+
+
+class MeanFieldApproximation:
+    """ensembles/models.py:73-132.  The reference returns dx.Normal(mean, scale = variance) of the realisation set
+    computed BEFORE its optimiser loop - the optimised parameters are discarded (models.py:129-131) -
+    so the loop is not run here; `optimiser`, `n_optim_nits` and `compile_objective` are accepted and ignored."""
+
+    def __init__(self, name="MeanFieldModel"):
+        self.name = name
+
+    def fit(self, model, optimiser=None, n_optim_nits: int = 500, compile_objective: bool = False) -> Distribution:
+        del optimiser, n_optim_nits, compile_objective
+        R = model.n_realisations
+        data = np.asarray(model.model_data.values, dtype=np.float64).reshape(1, R, -1)
+        mean, var = _lib.default_context().multi_model_mean(data, np.array([R], dtype=np.int32))
+        blank = ones_like(model.model_data[0].drop_vars("realisation")) * np.nan
+        return Distribution(mu=mean, covariance=var, dim_array=blank.rename("blank"), dist_type=dx.Normal)

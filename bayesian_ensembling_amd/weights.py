@@ -14,7 +14,8 @@ from . import distributions as dx
 from .data import ModelCollection, ProcessModel
 from .labelled import DataArray, concat
 
-__all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight"]
+__all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight", "InverseSquareWeight", "UniformWeight",
+           "KSDWeight", "CRPSWeight"]
 
 
 class AbstractWeight:
@@ -134,3 +135,84 @@ class ModelSimilarityWeight(AbstractWeight):
                 "the reference's own full-covariance branch of this mode references a non-existent dx.MultiVariate "
                 "(weights.py:284).")
         raise ValueError('Mode must be "single", "spatial", or "temporal"')
+
+
+def _packed_realisations(models):
+    """[M][R_max][P] zero-padded realisations + the realisation counts (members may differ in R)."""
+    R = np.array([m.n_realisations for m in models], dtype=np.int32)
+    P = int(models[0].model_data.size / models[0].n_realisations)
+    data = np.zeros((len(models), int(R.max()), P))
+    for i, m in enumerate(models):
+        data[i, :R[i]] = np.asarray(m.model_data.values, dtype=np.float64).reshape(R[i], -1)
+    return data, R
+
+
+def _stack_rows(models, vals, name):
+    rows = []
+    for i, m in enumerate(models):
+        row = _row_template(m)
+        row.data = vals[i].reshape(row.shape)
+        rows.append(row.assign_coords(model=m.model_name))
+    return concat(rows, dim="model").rename(name)
+
+
+class InverseSquareWeight(AbstractWeight):
+    def __init__(self, name: str = "InverseSquareWeight") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, observations):
+        """weights.py:147-174: (mean_r model - mean_r obs)^-2, normalised over the models."""
+        models = list(process_models.models)
+        data, R = _packed_realisations(models)
+        obs = np.asarray(observations.model_data.values, dtype=np.float64).reshape(observations.n_realisations, -1)
+        w = _lib.default_context().inverse_square_weights(data, R, obs)
+        weights = _stack_rows(models, w, "Inverse square weights")
+        assert weights.shape[1] == models[-1].model_data.shape[1], \
+            "Weight is not the same size as model. Check observations and model time coordinates match!"
+        return weights
+
+
+class UniformWeight(AbstractWeight):
+    def __init__(self, name: str = "UniformWeight") -> None:
+        super().__init__(name)
+
+    def _compute(self, process_models, observations):
+        """weights.py:190-212: 1 / n_models everywhere (exp(0) normalised over the models on the device)."""
+        models = list(process_models.models)
+        P = int(models[0].model_data.size / models[0].n_realisations)
+        w = _lib.default_context().weights_normalise(np.zeros((len(models), P)), 1.0)
+        return _stack_rows(models, w, "Uniform weights")
+
+
+class _ScoreWeight(AbstractWeight):
+    kind = None
+    label = None
+
+    def _compute(self, process_models, observations):
+        assert len(process_models.time) == len(observations.time), \
+            "Time coordinates do not match between models and observations"
+        assert hasattr(process_models[0].distribution, "_dist"), "Distribution not defined - fit models first"
+        models = list(process_models.models)
+        obs = np.asarray(observations.model_data.values, dtype=np.float64).reshape(observations.n_realisations, -1)
+        mean = np.stack([np.asarray(m.distribution._dist.mean()).reshape(-1) for m in models])
+        var = np.stack([np.asarray(m.distribution._dist.variance()).reshape(-1) for m in models])
+        w, _ = _lib.default_context().score_weights(self.kind, mean, var, obs)
+        return _stack_rows(models, w, self.label)
+
+
+class KSDWeight(_ScoreWeight):
+    """weights.py:336-441: weight ~ 1 / (IMQ kernel Stein discrepancy of the observation values at each point
+    against dx.Normal(mean_i, scale = variance_i))."""
+    kind, label = "ksd", "Kernel Stein Discrepancy weights"
+
+    def __init__(self, name: str = "KernelSteinDiscrepancyWeight") -> None:
+        super().__init__(name)
+
+
+class CRPSWeight(_ScoreWeight):
+    """weights.py:444-515: weight ~ 1 / mean_r crps_gaussian(obs_r; mean_i, sig = variance_i) - the scheme the
+    reference's published experiment uses (experiments/full_experiment_script.py:116)."""
+    kind, label = "crps", "Continuous Ranked Probability Scores weights"
+
+    def __init__(self, name: str = "ContinuousRankedProbabilityScoreWeight") -> None:
+        super().__init__(name)

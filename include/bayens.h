@@ -140,6 +140,18 @@ int bayens_barycentre(bayens_ctx* ctx, int loc, int M, int P, const double* w, c
 int bayens_weighted_model_mean(bayens_ctx* ctx, int loc, int M, int R_max, const int* R, int P,
                                const double* data, const double* w, double* mu_out, double* var_out);
 
+/* ---- callers of the path ("next" rows): the other weight plug-ins and MultiModelMean ---- */
+/* CRPSWeight (kind 0, ensembles/weights.py:444-515) / KSDWeight (kind 1, weights.py:336-441) against
+ * dx.Normal(mean, scale = variance) per point; mean, var, w [M][P], obs [R_obs][P]; score [M][P] or NULL. */
+int bayens_score_weights(bayens_ctx* ctx, int loc, int kind, int M, int P, int R_obs, const double* mean,
+                         const double* var, const double* obs, double* w, double* score);
+/* InverseSquareWeight (ensembles/weights.py:157-169); data [M][R_max][P], R [M] */
+int bayens_inverse_square_weights(bayens_ctx* ctx, int loc, int M, int R_max, const int* R, int P,
+                                  const double* data, int R_obs, const double* obs, double* w);
+/* MultiModelMean (ensembles/ensemble_scheme.py:108-128) */
+int bayens_multi_model_mean(bayens_ctx* ctx, int loc, int M, int R_max, const int* R, int P, const double* data,
+                            double* mu_out, double* var_out);
+
 /* ---- multi-GPU: RCCL all-gather of per-member rows ------------------------ */
 int bayens_comm_unique_id(bayens_ctx* ctx, void* id128);            /* 128-byte ncclUniqueId, rank 0 */
 int bayens_comm_init(bayens_ctx* ctx, int rank, int nranks, const void* id128);

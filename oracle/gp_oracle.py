@@ -370,6 +370,57 @@ def weighted_model_mean(datas, weights):
 
 
 # --------------------------------------------------------------------------------------
+# "Next" rows 8(f)-1: the remaining weight plug-ins and MultiModelMean
+# --------------------------------------------------------------------------------------
+def crps_weights(mean, var, obs):
+    """CRPSWeight (weights.py:444-515): target dx.Normal(mean_i, scale=variance_i), properscoring.crps_gaussian
+    with sig = stddev() = variance_i; score = mean over observation realisations; weight ~ 1/score."""
+    from scipy.stats import norm
+    mean, var, obs = np.asarray(mean), np.asarray(var), np.atleast_2d(obs)
+    z = (obs[None, :, :] - mean[:, None, :]) / var[:, None, :]
+    crps = var[:, None, :] * (z * (2.0 * norm.cdf(z) - 1.0) + 2.0 * norm.pdf(z) - 1.0 / math.sqrt(math.pi))
+    score = crps.mean(axis=1)
+    inv = 1.0 / score
+    return inv / inv.sum(axis=0, keepdims=True), score
+
+
+def ksd_weights(mean, var, obs, c=1.0, beta=-0.5):
+    """KSDWeight (weights.py:336-441): IMQ-kernel Stein discrepancy of the R_obs observation values at each point
+    against dx.Normal(mean_i, scale=variance_i) (so grad log p = -(x - mean)/variance^2); weight ~ 1/KSD."""
+    mean, var, obs = np.asarray(mean), np.asarray(var), np.atleast_2d(obs)
+    M, P = mean.shape
+    R = obs.shape[0]
+    ksd = np.empty((M, P))
+    for m in range(M):
+        for t in range(P):
+            x = obs[:, t]
+            g = -(x - mean[m, t]) / var[m, t] ** 2
+            tot = 0.0
+            for a in range(R):
+                diff = x[a] - x
+                q = c * c + diff * diff
+                k0 = (g[a] * g * q ** beta - 2 * beta * g[a] * diff * q ** (beta - 1) + 2 * beta * g * diff * q ** (beta - 1)
+                      - 2 * 1 * beta * q ** (beta - 1) - 4 * beta * (beta - 1) * q ** (beta - 2) * diff * diff)
+                tot += k0.sum()
+            ksd[m, t] = math.sqrt(tot) / R
+    inv = 1.0 / ksd
+    return inv / inv.sum(axis=0, keepdims=True), ksd
+
+
+def inverse_square_weights(datas, obs):
+    """InverseSquareWeight (weights.py:157-169): (mean_r model - mean_r obs)^-2 normalised over the models."""
+    om = np.atleast_2d(obs).mean(axis=0)
+    raw = np.stack([(np.asarray(d).mean(axis=0) - om) ** -2.0 for d in datas])
+    return raw / raw.sum(axis=0, keepdims=True)
+
+
+def multi_model_mean(datas):
+    """MultiModelMean (ensemble_scheme.py:108-128): mean and std**2 over all realisations of all models."""
+    allv = np.concatenate([np.asarray(d) for d in datas], axis=0)
+    return allv.mean(axis=0), allv.std(axis=0) ** 2
+
+
+# --------------------------------------------------------------------------------------
 # distrax log_prob of the diagonal ensemble posterior (utils.py:139; Appendix C of SURVEY)
 # --------------------------------------------------------------------------------------
 def mvn_diag_logprob(loc, scale_diag, x):

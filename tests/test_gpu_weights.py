@@ -87,6 +87,27 @@ def test_w2_single_diagonal_posteriors(ctx):
     assert relerr(w, v / v.sum()) < 1e-10
 
 
+def test_crps_ksd_inverse_square_and_multi_model_mean(ctx):
+    rng = np.random.default_rng(21)
+    M, P, R_obs = 4, 57, 5
+    mean, var, obs = rng.standard_normal((M, P)), rng.uniform(0.05, 1.5, (M, P)), rng.standard_normal((R_obs, P))
+    w, sc = ctx.score_weights("crps", mean, var, obs)
+    w_ref, sc_ref = go.crps_weights(mean, var, obs)
+    assert relerr(sc, sc_ref) < 1e-12 and relerr(w, w_ref) < 1e-12
+    w, sc = ctx.score_weights("ksd", mean, var, obs)
+    w_ref, sc_ref = go.ksd_weights(mean, var, obs)
+    assert relerr(sc, sc_ref) < 1e-11 and relerr(w, w_ref) < 1e-11
+    R = np.array([3, 5, 2, 4], dtype=np.int32)
+    datas = [rng.standard_normal((r, P)) for r in R]
+    packed = np.zeros((M, 5, P))
+    for i, d in enumerate(datas):
+        packed[i, :R[i]] = d
+    assert relerr(ctx.inverse_square_weights(packed, R, obs), go.inverse_square_weights(datas, obs)) < 1e-12
+    mu, v = ctx.multi_model_mean(packed, R)
+    rm, rv = go.multi_model_mean(datas)
+    assert relerr(mu, rm) < 1e-13 and relerr(v, rv) < 1e-13
+
+
 def test_barycentre_both_sides_of_the_signed_test(ctx):
     rng = np.random.default_rng(3)
     M, P = 6, 500
@@ -144,6 +165,18 @@ def test_weightings_api(ctx, n_models, obs_n_reals):
         assert isinstance(weights, DataArray)
         assert weights.shape == (n_models,) + obs.model_data.mean("realisation").shape
         assert np.all(weights.sum("model").values == pytest.approx(1.0, 1e-6))
+    # the other four plug-ins of the reference's test (tests/test_weights.py:79-86): type, shape, sum == 1
+    for weighting in [es.InverseSquareWeight(), es.UniformWeight(), es.KSDWeight(), es.CRPSWeight()]:
+        weights = weighting(mc, obs)
+        assert isinstance(weights, DataArray)
+        assert weights.shape == (n_models,) + obs.model_data.mean("realisation").shape
+        assert np.all(weights.sum("model").values == pytest.approx(1.0, 1e-6))
+    mmm = es.MultiModelMean()(mc, None)
+    rm, rv = go.multi_model_mean([m.model_data.values for m in mc.models])
+    assert relerr(mmm.mu, rm) < 1e-12 and relerr(mmm.covariance, rv) < 1e-12
+    mfa = es.MeanFieldApproximation().fit(mc[0])
+    assert mfa.dist_type is dx.Normal and relerr(mfa.mu, mc[0].model_data.values.mean(axis=0)) < 1e-13
+    assert relerr(mfa.covariance, mc[0].model_data.values.var(axis=0)) < 1e-12
     single = es.ModelSimilarityWeight()(mc)                      # the reference's default mode
     assert single.shape == (n_models, 1) and single.sum("model").values == pytest.approx(1.0, 1e-12)
     w_ref, _ = go.w2_weights_single([m.distribution.mu for m in mc.models], [m.distribution.covariance for m in mc.models])
