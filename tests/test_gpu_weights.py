@@ -231,3 +231,49 @@ def test_return_lls_and_members_with_different_realisation_counts(ctx):
     assert list(w.coords["model"]) == ["a", "b", "c"]
     one = es.GPDTW1D().fit(mc[1], n_optim_nits=2)
     assert np.array_equal(one.covariance, mc[1].distribution.covariance)
+
+
+def test_perfect_model_test_metrics_against_the_oracle(ctx, tmp_path):
+    """ensembles/utils.py:83-225 (leave-one-out harness): the three metrics of the barycentre and of the MMM."""
+    from bayesian_ensembling_amd.utils import PerfectModelTest
+    rng = np.random.default_rng(5)
+    N, T = 30, 2
+    time = np.arange(N)
+
+    def coll(seed):
+        r = np.random.default_rng(seed)
+        return es.ModelCollection([es.ProcessModel(DataArray(r.random((3, N)) + 0.1 * i, ("realisation", "time"),
+                                   {"realisation": np.arange(3), "time": time}), f"m{i}") for i in range(4)])
+    hind, fore = coll(1), coll(2)
+    pmt = PerfectModelTest(hind, fore, es.GPDTW1D, es.LogLikelihoodWeight, es.Barycentre, ssp="test", save_dir=str(tmp_path))
+    header, rows = pmt.run(n_optim_nits=T)
+    assert len(rows) == 4 and len(header) == 7 and (tmp_path / "csvs").exists()
+    # oracle for the first held-out member
+    i = 0
+    hd = [m.model_data.values for k, m in enumerate(hind.models) if k != i]
+    fd = [m.model_data.values for k, m in enumerate(fore.models) if k != i]
+    obs_past, obs_fut = hind[i].model_data.values, fore[i].model_data.values
+
+    def post(d):
+        X, y, nu = go.prologue(d)
+        mo, co, _ = go.gp_fit(X, y, nu, T)
+        return mo, co
+    hp, fp = [post(d) for d in hd], [post(d) for d in fd]
+    ll = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(m_, *go.mvn_factor(c_), obs_past)) for m_, c_ in hp])
+    w, _ = go.loglik_weights(ll, 1.0)
+    wm = w.mean(axis=1)
+    mean = np.stack([m_ for m_, _ in fp])
+    var = np.stack([np.diag(c_) for _, c_ in fp])
+    bmu, bvar, _ = go.barycentre(np.repeat(wm[:, None], N, axis=1), mean, var)
+    nll = -np.mean(go.mvn_diag_logprob(bmu, bvar, obs_fut))
+    rmse = np.mean(np.sqrt(np.mean((bmu[:, None] - obs_fut.T) ** 2, axis=0)))
+    om, oc = post(obs_fut)
+    w2 = go.gaussian_w2(bmu, np.diag(bvar ** 2), om, oc)
+    got = rows[0]
+    if np.all(np.isfinite(w)):
+        assert abs(got[1] - nll) < 1e-7 * abs(nll) and abs(got[2] - rmse) < 1e-9 and abs(got[3] - w2) < 1e-7 * abs(w2)
+    allr = np.vstack(fd)
+    mm, mv = allr.mean(axis=0), allr.var(axis=0)
+    assert abs(got[4] + np.mean(go.normal_loglik(mm, mv, obs_fut))) < 1e-9
+    assert abs(got[5] - np.mean(np.sqrt(np.mean((mm[None] - obs_fut) ** 2, axis=0)))) < 1e-12
+    assert abs(got[6] - go.gaussian_w2(mm, np.diag(mv ** 2), om, np.diag(np.diag(oc)))) < 1e-8
