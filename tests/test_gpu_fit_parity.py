@@ -123,3 +123,38 @@ def test_full_size_properties(ctx):
     # one member against the oracle at full size
     mo, co, ho = go.gp_fit(X[0], y[0], nu[0], T)
     assert relerr(out["mu"][0], mo) < REL_TOL and relerr(out["cov"][0], co) < REL_TOL and relerr(out["hyp"][0], ho) < REL_TOL
+
+
+def test_member_groups_do_not_change_the_result(ctx):
+    data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
+    X, y, nu = member_inputs(data)
+    one = ctx.gp_fit_batch(X, y, nu, 2)
+    ctx.set_groups(3)
+    try:
+        three = ctx.gp_fit_batch(X, y, nu, 2)
+    finally:
+        ctx.set_groups(1)
+    for k in ("mu", "cov", "chol", "logdet", "hyp", "basis"):
+        assert np.array_equal(one[k], three[k]), k
+
+
+def test_bench_contract_line(ctx):
+    """bench.py prints ONE JSON line with the driver's contract fields (small shape so it runs in seconds)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--members", "4", "--timesteps", "200",
+                          "--steps", "2", "--warmup", "1", "--cpu-members", "1"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 78.6
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
