@@ -34,7 +34,7 @@ struct GemmArgs {
   int m, n, k;
   double alpha, beta, diag_add;
   int flags;
-  int tiles_m, tiles_n, total;
+  int tiles_m, tiles_n, total, nb;
 };
 
 // Stage one 128 x 16 operand tile into registers.  TR=true: memory is [row][k] (k contiguous) -> each
@@ -85,10 +85,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   // XCD-aware dealing: consecutive hardware block ids go round-robin over the 8 XCDs; give every XCD a
   // contiguous chunk of the (member, tile) space so that its L2 sees few members' panels.
   int bid = blockIdx.x;
-  if ((g.total & 7) == 0) bid = (bid & 7) * (g.total >> 3) + (bid >> 3);
   const int tiles = g.tiles_m * g.tiles_n;
-  const int batch = bid / tiles;
-  const int t = bid - batch * tiles;
+  int batch, t;
+  if ((g.flags & GEMM_TRI_OUT) && (g.nb & 7) == 0) {
+    // triangular launches have unequal tiles (skipped ones, k-trimmed ones): inside an XCD's share walk the
+    // tiles of all its members together (tile-major, member-minor) so that every member's long tiles start first
+    const int mpc = g.nb >> 3, loc = bid >> 3;
+    t = loc / mpc;
+    batch = (bid & 7) * mpc + (loc - t * mpc);
+  } else {
+    if ((g.total & 7) == 0) bid = (bid & 7) * (g.total >> 3) + (bid >> 3);
+    batch = bid / tiles;
+    t = bid - batch * tiles;
+  }
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -386,6 +395,7 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   g.tiles_m = (m + BM - 1) / BM;
   g.tiles_n = (n + BN - 1) / BN;
   g.total = g.tiles_m * g.tiles_n * nb;
+  g.nb = nb;
   if ((m % 64) || (n % 64) || (k % 64) || (A.ld & 1) || (B.ld & 1))
     throw HipError{-1, "gemm: dimensions must be multiples of 64 and leading dimensions even"};
   hipEvent_t e0 = nullptr, e1 = nullptr;
