@@ -87,12 +87,16 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
                               double* logdet, double* basis) {
   const int nb = ws.nb, Np = ws.Np;
   P.tri_copy(nb, Np, src, ws.T1);
-  const int extra = basis ? LEAF : 0;
-  if (basis) P.basis_rows_set(nb, N, Np, ws.T1.sub(Np, 0), mu_pad);     // row 0 = 1 (first N), row 1 = mu
+  // bordering rows (1^T, mu^T): in the padding when the member has at least two padded rows (no extra rows to
+  // drag through the factorisation), else in a 64-row block appended below the matrix
+  const bool in_pad = Np - N >= 2;
+  const int extra = (basis && !in_pad) ? LEAF : 0;
+  Mat rows = ws.T1.sub(in_pad ? N : Np, 0);
+  if (basis) P.basis_rows_set(nb, N, Np, rows, mu_pad, in_pad ? 1 : 0);
   potrf(P, nb, Np, ws.T1, ws.invL, ws.inv_stride(), ws.info, extra);
   if (chol) P.extract(nb, N, ws.T1, chol, 2);
   if (logdet) P.logdet(nb, N, ws.T1, logdet);
-  if (basis) P.basis_rows_get(nb, N, Np, ws.T1.sub(Np, 0), basis);
+  if (basis) P.basis_rows_get(nb, N, Np, rows, basis);
 }
 
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
@@ -125,11 +129,15 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     P.mark("L S solves");
     // [L; theta1^T] C^-T C^-1 = [L S; m^T]: the variational mean m = Lam^-1 theta1 rides through the two
     // solves that produce L S for the Adam step (models.py:210) as one extra row block of the right-hand side
+    // (the theta1 row replaces the last padded row of L when the member has padding, else it is appended)
     P.copy(nb, Np, ws.Lb, ws.T1);
-    P.aug_set(nb, Np, ws.T1.sub(Np, 0), ws.theta1);
-    trsm_rlt(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1);        // [L; theta1^T] C^-T
-    trsm_rln(P, nb, Np + LEAF, Np, ws.Cb, ws.invC, is, ws.T1, false); // ... C^-1
-    P.aug_get(nb, Np, ws.T1.sub(Np, 0), ws.mvec);                     // m
+    const bool in_pad = Np > N;
+    const int mrows = in_pad ? Np : Np + LEAF;
+    Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
+    P.aug_set(nb, Np, trow, ws.theta1, in_pad ? 0 : LEAF - 1);
+    trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);            // [L; theta1^T] C^-T
+    trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);     // ... C^-1
+    P.aug_get(nb, Np, trow, ws.mvec);                                 // m
     P.mark("Lbar, Phi");
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
     P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))

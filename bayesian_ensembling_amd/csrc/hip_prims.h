@@ -60,9 +60,9 @@ struct HipPrims : Prims {
   void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
   void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
                     double* theta1) override;
-  void aug_set(int nb, int n, Mat rows, const double* vec) override;
+  void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) override;
   void aug_get(int nb, int n, Mat rows, double* vec) override;
-  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) override;
+  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) override;
   void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override;
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
   void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override;

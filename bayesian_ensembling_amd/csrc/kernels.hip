@@ -558,13 +558,13 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const doub
 }
 
 // the 64-row block appended to a right-hand side (prims.h aug_set / aug_get)
-__global__ void aug_set_kernel(int n, Mat rows, const double* vec) {
+__global__ void aug_set_kernel(int n, Mat rows, const double* vec, int zero_rows) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   double* r = rows.p + b * rows.stride;
   r[j] = vec[(long)b * n + j];
-  for (int q = 1; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
+  for (int q = 1; q <= zero_rows; ++q) r[(long)q * rows.ld + j] = 0.0;
 }
 
 __global__ void aug_get_kernel(int n, Mat rows, double* vec) {
@@ -637,14 +637,20 @@ __global__ __launch_bounds__(256) void trsv_fwd2_kernel(int N, const double* cho
 }
 
 // rows appended to the covariance factorisation (prims.h basis_rows_set / _get)
-__global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const double* mu_pad) {
+__global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const double* mu_pad, int in_padding) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= Np) return;
   double* r = rows.p + b * rows.stride;
-  r[j] = j < N ? 1.0 : 0.0;
-  r[(long)rows.ld + j] = j < N ? mu_pad[(long)b * Np + j] : 0.0;
-  for (int q = 2; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
+  double v0 = j < N ? 1.0 : 0.0, v1 = j < N ? mu_pad[(long)b * Np + j] : 0.0;
+  if (in_padding) {            // rows N and N+1 of the matrix itself: huge pivots keep them positive definite
+    if (j == N) v0 = 1e30;
+    if (j == N + 1) v1 = 1e30;
+  }
+  r[j] = v0;
+  r[(long)rows.ld + j] = v1;
+  if (!in_padding)
+    for (int q = 2; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
 }
 
 __global__ void basis_rows_get_kernel(int N, Mat rows, double* basis) {
@@ -1100,16 +1106,17 @@ void HipPrims::theta_update(int nb, int n, Mat L, const double* y, const double*
   hipLaunchKernelGGL(theta_update_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, y, nu, gamma, theta1);
   LAUNCH_CHECK();
 }
-void HipPrims::aug_set(int nb, int n, Mat rows, const double* vec) {
-  hipLaunchKernelGGL(aug_set_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
+void HipPrims::aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) {
+  hipLaunchKernelGGL(aug_set_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec, zero_rows);
   LAUNCH_CHECK();
 }
 void HipPrims::aug_get(int nb, int n, Mat rows, double* vec) {
   hipLaunchKernelGGL(aug_get_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
   LAUNCH_CHECK();
 }
-void HipPrims::basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) {
-  hipLaunchKernelGGL(basis_rows_set_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, rows, mu_pad);
+void HipPrims::basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) {
+  hipLaunchKernelGGL(basis_rows_set_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, rows, mu_pad,
+                     in_padding);
   LAUNCH_CHECK();
 }
 void HipPrims::basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) {

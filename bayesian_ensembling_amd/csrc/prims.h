@@ -72,13 +72,18 @@ struct Prims {
   // theta1 = (1-gamma) theta1 + gamma * L^T (y / nu)
   virtual void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
                             double* theta1) = 0;
-  // a 64-row block appended below an n x n right-hand side: row 0 carries a vector through the same
-  // triangular solves (x^T C^-T C^-1 = (C^-T C^-1 x)^T), rows 1..63 are zero
-  virtual void aug_set(int nb, int n, Mat rows, const double* vec) = 0;   // rows[0][:] = vec, others 0
+  // a row of an n-column right-hand side that carries a vector through the same triangular solves
+  // (x^T C^-T C^-1 = (C^-T C^-1 x)^T): rows[0][:] = vec and the `zero_rows` rows after it are cleared.
+  // The row is either the first of a 64-row block appended below the matrix (zero_rows = 63) or, when the
+  // member has padding (Np > N), the last padded row (zero_rows = 0): padded rows are decoupled from the real
+  // block, so whatever they carry never reaches the real part of any later product.
+  virtual void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) = 0;
   virtual void aug_get(int nb, int n, Mat rows, double* vec) = 0;         // vec = rows[0][:]
-  // the two appended rows of the covariance factorisation: row 0 = 1 (columns < N, else 0), row 1 = mu_pad
-  // (rows 2..63 zero); and their read-back into basis [nb][2][N]
-  virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) = 0;
+  // the two bordering rows of the covariance factorisation: row 0 = 1 (columns < N, else 0), row 1 = mu_pad.
+  // in_padding = 0: rows of an appended 64-row block (rows 2..63 zeroed).  in_padding = 1: `rows` are rows N and
+  // N+1 of the padded matrix itself; they also get a huge diagonal entry (1e30) so that their pivots stay
+  // positive - it only touches the padded part, which is excluded from chol / logdet / basis outputs.
+  virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) = 0;
   virtual void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) = 0;
   virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
   // X_ij <- (i >= j) ? (a_i m_j + X_ij) / nu_i : 0

@@ -186,21 +186,23 @@ struct CpuPrims : Prims {
         theta1[(size_t)b * n + j] = (1 - gamma) * theta1[(size_t)b * n + j] + gamma * s;
       }
   }
-  void aug_set(int nb, int n, Mat rows, const double* vec) override {
+  void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) override {
     for (int b = 0; b < nb; ++b)
-      for (int r = 0; r < LEAF; ++r)
+      for (int r = 0; r <= zero_rows; ++r)
         for (int j = 0; j < n; ++j) rows.p[b * rows.stride + (size_t)r * rows.ld + j] = r == 0 ? vec[(size_t)b * n + j] : 0.0;
   }
   void aug_get(int nb, int n, Mat rows, double* vec) override {
     for (int b = 0; b < nb; ++b)
       for (int j = 0; j < n; ++j) vec[(size_t)b * n + j] = rows.p[b * rows.stride + j];
   }
-  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad) override {
+  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) override {
     for (int b = 0; b < nb; ++b)
-      for (int r = 0; r < LEAF; ++r)
-        for (int j = 0; j < Np; ++j)
-          rows.p[b * rows.stride + (size_t)r * rows.ld + j] =
-              r == 0 ? (j < N ? 1.0 : 0.0) : (r == 1 ? (j < N ? mu_pad[(size_t)b * Np + j] : 0.0) : 0.0);
+      for (int r = 0; r < (in_padding ? 2 : LEAF); ++r)
+        for (int j = 0; j < Np; ++j) {
+          double v = r == 0 ? (j < N ? 1.0 : 0.0) : (r == 1 ? (j < N ? mu_pad[(size_t)b * Np + j] : 0.0) : 0.0);
+          if (in_padding && j == N + r) v = 1e30;
+          rows.p[b * rows.stride + (size_t)r * rows.ld + j] = v;
+        }
   }
   void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override {
     (void)Np;
