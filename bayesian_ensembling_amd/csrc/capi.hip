@@ -322,9 +322,9 @@ int bayens_profile_enable(bayens_ctx* c, int on) {
     all.push_back(c->prims);
     for (HipPrims* hp : all) {
       KernelProfile& p = hp->prof;
-      for (auto& e : p.events) { p.pool.push_back(e.first); p.pool.push_back(e.second); }
+      for (auto& e : p.events) { p.pool.push_back(e.a); p.pool.push_back(e.b); }
       p.events.clear();
-      p.flop = 0; p.launches = 0;
+      for (int f = 0; f < FAM_COUNT; ++f) { p.flop[f] = 0; p.launches[f] = 0; }
       p.enabled = on != 0;
     }
     return 0;
@@ -332,7 +332,7 @@ int bayens_profile_enable(bayens_ctx* c, int on) {
 }
 int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long* launches) {
   return guarded(c, [&]() {
-    if (family != 0) return fail(c, BAYENS_E_ARG, "unknown kernel family");
+    if (family < 0 || family >= FAM_COUNT) return fail(c, BAYENS_E_ARG, "unknown kernel family");
     BAYENS_HIP(hipDeviceSynchronize());
     std::vector<HipPrims*> all = c->gprims;
     all.push_back(c->prims);
@@ -341,12 +341,13 @@ int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long
     for (HipPrims* hp : all) {
       KernelProfile& p = hp->prof;
       for (auto& e : p.events) {
+        if (family != FAM_ALL && e.fam != family) continue;
         float f = 0;
-        BAYENS_HIP(hipEventElapsedTime(&f, e.first, e.second));
+        BAYENS_HIP(hipEventElapsedTime(&f, e.a, e.b));
         tot += f;
       }
-      fl += p.flop;
-      n += p.launches;
+      fl += p.flop[family];
+      n += p.launches[family];
     }
     if (ms) *ms = tot;
     if (flop) *flop = fl;

@@ -412,7 +412,9 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
   dim3 grid(g.total), block(256);
   const int special = GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI | GEMM_ZERO_SKIPPED;
+  int fam = ta ? FAM_GEMM_TN : (tb ? FAM_GEMM_NT : FAM_GEMM_NN);
   if (n == 64 && k == 64 && !ta && !(flags & special)) {
+    fam = FAM_PANEL64;
     // with n = 64 every output block lies on or below the block diagonal, so GEMM_TRI_OUT skips nothing
     dim3 pgrid((m / 64) * nb);
     if (tb) hipLaunchKernelGGL((gemm_panel64<true>), pgrid, block, 0, stream, g);
@@ -424,9 +426,10 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   BAYENS_HIP(hipGetLastError());
   if (prof.enabled) {
     BAYENS_HIP(hipEventRecord(e1, stream));
-    prof.events.emplace_back(e0, e1);
-    prof.flop += algorithmic_flop(nb, m, n, k, flags);
-    prof.launches += 1;
+    prof.events.push_back(KernelProfile::Ev{e0, e1, fam});
+    const double f = algorithmic_flop(nb, m, n, k, flags);
+    prof.flop[FAM_ALL] += f; prof.flop[fam] += f;
+    prof.launches[FAM_ALL] += 1; prof.launches[fam] += 1;
   }
 }
 
@@ -455,9 +458,10 @@ void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long i
   BAYENS_HIP(hipGetLastError());
   if (prof.enabled) {
     BAYENS_HIP(hipEventRecord(e1, stream));
-    prof.events.emplace_back(e0, e1);
-    prof.flop += (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
-    prof.launches += 1;
+    prof.events.push_back(KernelProfile::Ev{e0, e1, FAM_TRSM_PANEL});
+    const double f = (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
+    prof.flop[FAM_ALL] += f; prof.flop[FAM_TRSM_PANEL] += f;
+    prof.launches[FAM_ALL] += 1; prof.launches[FAM_TRSM_PANEL] += 1;
   }
 }
 

@@ -22,12 +22,16 @@ struct HipError {
       throw ::bayens::HipError{(int)e__, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
   } while (0)
 
+// kernel families of the per-launch accounting (bayens_profile_get): one per kernel symbol of the GEMM group
+enum { FAM_ALL = 0, FAM_GEMM_NT = 1, FAM_GEMM_NN = 2, FAM_GEMM_TN = 3, FAM_PANEL64 = 4, FAM_TRSM_PANEL = 5, FAM_COUNT = 6 };
+
 struct KernelProfile {
   bool enabled = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // per GEMM launch
+  struct Ev { hipEvent_t a, b; int fam; };
+  std::vector<Ev> events;   // per launch
   std::vector<hipEvent_t> pool;
-  double flop = 0;
-  long launches = 0;
+  double flop[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+  long launches[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
   std::vector<std::pair<std::string, hipEvent_t>> marks;   // stage profile of the driver
 };
 

@@ -1044,7 +1044,7 @@ HipPrims::~HipPrims() {
   if (xs) (void)hipFree(xs);
   if (ssq) (void)hipFree(ssq);
   if (gpart) (void)hipFree(gpart);
-  for (auto& e : prof.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : prof.events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
 }
 

@@ -52,8 +52,9 @@ int bayens_sync(bayens_ctx* ctx);
 /* HIP-event timer on the ctx stream (the stream every kernel of this library is launched on) */
 int bayens_timer_start(bayens_ctx* ctx);
 int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
-/* per-kernel-family accounting (HIP events around every launch of the family; off by default).
- * family 0 = the batched fp64 MFMA GEMM.  Returns summed device ms, algorithmic flop, launches. */
+/* per-kernel accounting (HIP events around every launch; off by default).  family 0 = the whole GEMM group,
+ * 1/2/3 = gemm_f64_mfma<false,true> (NT) / <false,false> (NN) / <true,false> (TN), 4 = gemm_panel64,
+ * 5 = trsm_panel_kernel.  Returns summed device ms, algorithmic flop, launches. */
 int bayens_profile_enable(bayens_ctx* ctx, int on);
 int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
 
