@@ -4,6 +4,7 @@ path of mattramos/bayesian_ensembling (reference package name: `ensembles`).
 Same public names as ensembles/__init__.py for that path; the arithmetic runs in hand-written HIP kernels
 (libbayens.so, include/bayens.h) reached through ctypes.  There is no CPU fallback."""
 from .data import Distribution, ModelCollection, ProcessModel
+from .dtwa import performDBA
 from .ensemble_scheme import AbstractEnsembleScheme, Barycentre, MultiModelMean, WeightedModelMean
 from .labelled import DataArray, concat
 from .models import GPDTW1D, MeanFieldApproximation

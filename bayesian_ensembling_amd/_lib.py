@@ -80,6 +80,7 @@ def load():
     lib.bayens_score_weights.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_inverse_square_weights.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.bayens_multi_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
+    lib.bayens_dba_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.bayens_comm_unique_id.argtypes = [_vp, _vp]
     lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.bayens_comm_destroy.argtypes = [_vp]
@@ -388,6 +389,16 @@ class Context:
         mu, v = np.empty(P), np.empty(P)
         self._check(self.lib.bayens_multi_model_mean(self.h, HOST, M, R_max, _ptr(R), P, _ptr(data), _ptr(mu), _ptr(v)))
         return mu, v
+
+    def dba_batch(self, series, n_iterations=10):
+        """DTW barycentre of every member's realisations: series [B][R][N] -> (center [B][N], medoid [B])."""
+        series = _f64(series)
+        B, R, N = series.shape
+        center = np.empty((B, N))
+        medoid = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.bayens_dba_batch(self.h, HOST, B, R, N, _ptr(series), int(n_iterations), _ptr(center),
+                                              _ptr(medoid)))
+        return center, medoid
 
     # -- RCCL ------------------------------------------------------------------------------------------
     def comm_unique_id(self):

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbayens.so")
-SOURCES = ["gemm.hip", "kernels.hip", "capi.hip", "driver.cpp"]
+SOURCES = ["gemm.hip", "kernels.hip", "dba.hip", "capi.hip", "driver.cpp"]
 ARCH = "gfx950"
 
 

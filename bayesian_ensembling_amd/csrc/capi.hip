@@ -672,6 +672,24 @@ int bayens_multi_model_mean(bayens_ctx* c, int loc, int M, int R_max, const int*
   });
 }
 
+int bayens_dba_batch(bayens_ctx* c, int loc, int B, int R, int N, const double* series, int n_iterations, double* center,
+                     int* medoid) {
+  return guarded(c, [&]() {
+    if (B <= 0 || R <= 0 || N <= 0 || n_iterations < 0 || !series || !center) return fail(c, BAYENS_E_ARG, "dba_batch: bad argument");
+    Stage st(c, loc);
+    const double* ds = st.in(series, (size_t)B * R * N);
+    double* dc = st.out(center, (size_t)B * N);
+    int* dm = medoid ? st.out(medoid, (size_t)B) : st.scratch<int>((size_t)B);
+    double* sq = st.scratch<double>((size_t)B * R * R);
+    signed char* path = st.scratch<signed char>((size_t)B * R * N * N);
+    int* jlo = st.scratch<int>((size_t)B * R * N);
+    int* jhi = st.scratch<int>((size_t)B * R * N);
+    c->prims->dba_batch(B, R, N, ds, n_iterations, dc, dm, sq, path, jlo, jhi);
+    st.finish();
+    return 0;
+  });
+}
+
 // ---- RCCL ---------------------------------------------------------------------------------------
 int bayens_comm_unique_id(bayens_ctx* c, void* id128) {
   return guarded(c, [&]() {

@@ -107,6 +107,10 @@ struct HipPrims : Prims {
   void weighted_model_mean(int M, int R_max, const int* R, int P, const double* data, const double* w,
                            double* mu_out, double* var_out);
   void extract_diag(int B, int N, const double* cov, double* var);
+  // DTW barycentre averaging of every member's realisations (dba.hip); scratch: sq [B][R][R], path [B][R][N][N] bytes,
+  // jlo / jhi [B][R][N]
+  void dba_batch(int B, int R, int N, const double* series, int n_iterations, double* center, int* medoid, double* sq,
+                 signed char* path, int* jlo, int* jhi);
   // kind 0 = CRPS, 1 = KSD; score (nullable) receives the un-inverted scores
   void score_weights(int kind, int M, int P, int R_obs, const double* mean, const double* var, const double* obs,
                      double* w, double* score);

@@ -26,9 +26,10 @@ def _blank_array(process_model):
 
 class GPDTW1D:
     def __init__(self, name: str = "GPRegressor", target="mean", kernel: str = "matern32") -> None:
-        """target: 'mean' (mean over realisations - the documented stand-in for the reference's DTW
-        barycentre) or a callable (R,N) ndarray -> (N,) target.  kernel: 'matern32' is the reference kernel
-        (models.py:186); 'matern52' / 'rbf' are extensions."""
+        """target: 'mean' (mean over realisations - the documented stand-in for the reference's tslearn DTW
+        barycentre, which cannot be reproduced offline), 'dba' (DTW barycentre averaging with the semantics of the
+        reference's own ensembles/dtwa.py performDBA, 10 iterations, on the GPU) or a callable (R,N) ndarray -> (N,).
+        kernel: 'matern32' is the reference kernel (models.py:186); 'matern52' / 'rbf' are extensions."""
         self.name = name
         self.target = target
         self.kernel = kernel
@@ -42,8 +43,10 @@ class GPDTW1D:
             y_mean = np.asarray(self.target(realisation_set), dtype=np.float64).reshape(-1)
         elif self.target == "mean":
             y_mean = realisation_set.mean(axis=0)
+        elif self.target == "dba":
+            y_mean = None                 # filled in batch by fit_collection (one device call per group)
         else:
-            raise ValueError("target must be 'mean' or a callable")
+            raise ValueError("target must be 'mean', 'dba' or a callable")
         y_var = np.var(realisation_set, axis=0)
         X = np.ascontiguousarray(realisation_set.T)
         return X, y_mean, y_var
@@ -60,7 +63,10 @@ class GPDTW1D:
         dists = [None] * len(process_models)
         for shape, idxs in groups.items():
             X = np.stack([pro[i][0] for i in idxs])
-            y = np.stack([pro[i][1] for i in idxs])
+            if self.target == "dba":
+                y, _ = ctx.dba_batch(np.ascontiguousarray(np.swapaxes(X, 1, 2)), 10)
+            else:
+                y = np.stack([pro[i][1] for i in idxs])
             nu = np.stack([pro[i][2] for i in idxs])
             out = ctx.gp_fit_batch(X, y, nu, n_optim_nits, kernel=_lib.KERNEL_IDS[self.kernel])
             for j, i in enumerate(idxs):

@@ -153,6 +153,12 @@ int bayens_inverse_square_weights(bayens_ctx* ctx, int loc, int M, int R_max, co
 int bayens_multi_model_mean(bayens_ctx* ctx, int loc, int M, int R_max, const int* R, int P, const double* data,
                             double* mu_out, double* var_out);
 
+/* The DTW-barycentre front-end of GPDTW1D with the semantics of the reference's own DBA, ensembles/dtwa.py
+ * (performDBA :6-20: medoid start, n_iterations DBA updates), for B members at once: series [B][R][N] (R <= 50
+ * realisations of equal length), center [B][N], medoid [B] (index of the starting series, may be NULL). */
+int bayens_dba_batch(bayens_ctx* ctx, int loc, int B, int R, int N, const double* series, int n_iterations,
+                     double* center, int* medoid);
+
 /* ---- multi-GPU: RCCL all-gather of per-member rows ------------------------ */
 int bayens_comm_unique_id(bayens_ctx* ctx, void* id128);            /* 128-byte ncclUniqueId, rank 0 */
 int bayens_comm_init(bayens_ctx* ctx, int rank, int nranks, const void* id128);
