@@ -350,7 +350,7 @@ __global__ void adam_kernel(int ntiles, const double* gpart, double* ustate, dou
 // 64x64 diagonal block: Cholesky + inverse of the factor, one workgroup (4 waves) per member.
 // The block lives in LDS and is processed as 4x4 sub-blocks of 16x16:
 //   P1  the 16x16 diagonal sub-block is factored AND inverted in registers by 16 lanes of wave 0
-//       (lane i owns row i; pivots/columns travel by v_readlane; 1/L_ii comes from a Newton-refined v_rsq_f64,
+//       (lane i owns row i; pivots/columns travel by DPP row broadcast; 1/L_ii comes from a Newton-refined v_rsq_f64,
 //       so there is no fp64 divide or sqrt sequence on the serial chain)
 //   P2  panel below:   P <- P inv(L_dd)^T          fp64 MFMA 16x16x4, one 16-row block per wave
 //   P3  trailing part: S_rc -= P_r P_c^T           fp64 MFMA, lower block pairs dealt over the waves
@@ -359,10 +359,24 @@ __global__ void adam_kernel(int ntiles, const double* gpart, double* ustate, dou
 // ------------------------------------------------------------------------------------------------
 constexpr int LS = 66;   // LDS row stride (doubles) of the 64x64 images
 
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+// broadcast of lane k (0..15) of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+).  The 16x16
+// diagonal sub-block is replicated in all four rows of the wave, so this is the "value of lane k" for every lane,
+// it stays in VGPRs (v_readlane would put 2 x 136 values through the SGPR file and spill it into VGPR lanes).
+template <int K>
+__device__ __forceinline__ double bcast16_k(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int k) {
+  switch (k) {
+    case 0: return bcast16_k<0>(v);   case 1: return bcast16_k<1>(v);   case 2: return bcast16_k<2>(v);
+    case 3: return bcast16_k<3>(v);   case 4: return bcast16_k<4>(v);   case 5: return bcast16_k<5>(v);
+    case 6: return bcast16_k<6>(v);   case 7: return bcast16_k<7>(v);   case 8: return bcast16_k<8>(v);
+    case 9: return bcast16_k<9>(v);   case 10: return bcast16_k<10>(v); case 11: return bcast16_k<11>(v);
+    case 12: return bcast16_k<12>(v); case 13: return bcast16_k<13>(v); case 14: return bcast16_k<14>(v);
+    default: return bcast16_k<15>(v);
+  }
 }
 
 __device__ __forceinline__ double rsqrt_refined(double d) {
