@@ -151,6 +151,12 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
   const int N = fp.N, R = fp.R;
   const int G = std::max(1, std::min(std::min(c->ngroups, (int)c->gstreams.size()), B));
   BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
+  if (G == 1) {                                      // one group: no host thread, run on the first group stream
+    FitWorkspace w = ws_view(c, 0, B);
+    gp_fit(*c->gprims[0], w, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
+    BAYENS_HIP(hipStreamSynchronize(c->gstreams[0]));
+    return;
+  }
   std::vector<std::thread> th;
   std::vector<HipError> errs(G, HipError{0, ""});
   for (int g = 0; g < G; ++g) {
@@ -596,7 +602,7 @@ int bayens_barycentre(bayens_ctx* c, int loc, int M, int P, const double* w, con
     const double* dv = st.in(var, (size_t)M * P);
     double* dmu = st.out(mu_out, (size_t)P);
     double* dvar = st.out(var_out, (size_t)P);
-    int* dbad = st.scratch<int>(1);
+    int* dbad = reinterpret_cast<int*>(c->small_scratch(1));     // persistent: no allocation on the latency path
     c->prims->barycentre(M, P, dw, dm, dv, tol, init_var, dmu, dvar, dbad);
     int hbad = 0;
     BAYENS_HIP(hipMemcpyAsync(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
