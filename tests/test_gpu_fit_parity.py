@@ -123,6 +123,8 @@ def test_full_size_properties(ctx):
     # one member against the oracle at full size
     mo, co, ho = go.gp_fit(X[0], y[0], nu[0], T)
     assert relerr(out["mu"][0], mo) < REL_TOL and relerr(out["cov"][0], co) < REL_TOL and relerr(out["hyp"][0], ho) < REL_TOL
+    # (measured 1e-13: BASELINE's 1e-5 is the contract, this is the regression guard)
+    assert relerr(out["mu"][0], mo) < 1e-9 and relerr(out["cov"][0], co) < 1e-9
 
 
 def test_member_groups_do_not_change_the_result(ctx):
@@ -158,3 +160,23 @@ def test_bench_contract_line(ctx):
     assert d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 78.6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("M,N,R,T", [(2, 1, 3, 1), (2, 2, 3, 2), (1, 3, 2, 2), (2, 63, 3, 2), (2, 64, 3, 2), (2, 65, 3, 2),
+                                     (1, 127, 50, 1), (1, 129, 4, 2), (1, 255, 6, 1), (1, 257, 6, 1), (3, 320, 7, 1),
+                                     (1, 1000, 8, 1), (1, 1980, 8, 1), (33, 100, 4, 1)])
+def test_edge_sizes(ctx, M, N, R, T):
+    """N = 1, around the 64-row leaf, the 256-wide panel and the 128 tile; the monthly horizon 1980; M not a
+    multiple of 8; many realisations."""
+    data, obs = go.synthetic_ensemble(M, N, R=R, seed=N * 7 + R)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T)
+    assert not out["info"].any()
+    for m in range(min(M, 2)):
+        mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T)
+        Lc, ld = go.mvn_factor(co)
+        assert relerr(out["mu"][m], mo) < 1e-10 and relerr(out["cov"][m], co) < 1e-10
+        assert relerr(out["chol"][m], Lc) < 1e-10 and relerr(out["hyp"][m], ho) < 1e-10
+        assert abs(out["logdet"][m] - ld) < 1e-9 * max(1.0, abs(ld))
+    ll = ctx.loglik_rows_basis(out["basis"], out["logdet"], obs)
+    assert relerr(ll, ctx.loglik_rows(out["mu"], out["chol"], out["logdet"], obs)) < 1e-12
