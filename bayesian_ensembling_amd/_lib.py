@@ -50,6 +50,7 @@ def load():
     lib.bayens_version.restype = C.c_char_p
     lib.bayens_last_error.restype = C.c_char_p
     lib.bayens_last_error.argtypes = [_vp]
+    lib.bayens_device_count.argtypes = [_ip]
     lib.bayens_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
     lib.bayens_ctx_destroy.argtypes = [_vp]
     lib.bayens_device_info.argtypes = [_vp, C.c_char_p, C.c_int, _ip, C.POINTER(C.c_size_t)]
@@ -452,6 +453,12 @@ class Context:
         return Bm
 
 
+def device_count():
+    n = C.c_int(0)
+    load().bayens_device_count(C.byref(n))
+    return n.value
+
+
 _default_ctx = None
 
 
@@ -459,5 +466,6 @@ def default_context():
     """Process-wide context on the device LOCAL_RANK selects (one process per GPU)."""
     global _default_ctx
     if _default_ctx is None:
-        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+        n = max(device_count(), 1)
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) % n)   # a launcher may expose one device per rank
     return _default_ctx

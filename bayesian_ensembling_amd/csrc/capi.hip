@@ -227,6 +227,14 @@ extern "C" {
 
 const char* bayens_version(void) { return "bayens 0.1 (gfx950, fp64 MFMA)"; }
 
+int bayens_device_count(int* count) {
+  if (!count) return BAYENS_E_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *count = e == hipSuccess ? n : 0;
+  return e == hipSuccess ? 0 : BAYENS_E_NOGPU;
+}
+
 int bayens_ctx_create(int device, bayens_ctx** out) {
   if (!out) return BAYENS_E_ARG;
   *out = nullptr;

@@ -85,7 +85,10 @@ def main():
         # first is the one the whole process uses, and RCCL only initialises on the runtime it was built against.
         import torch.distributed as dist
     from bayesian_ensembling_amd import _lib, parallel
-    ctx = _lib.Context(local_rank)          # raises when libbayens / the GPU is missing: no fallback
+    n_dev = _lib.device_count()
+    if n_dev <= 0:
+        raise SystemExit("no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)")
+    ctx = _lib.Context(local_rank % n_dev)  # (a launcher may expose a single device to every rank)
     ctx.set_groups(args.groups)
     host = None
     if world > 1 or force_comm:

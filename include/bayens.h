@@ -39,6 +39,7 @@ enum {
 };
 
 /* ---- context, memory and timing plumbing -------------------------------------------------- */
+int bayens_device_count(int* count);                 /* visible HIP devices (does not initialise a context) */
 int bayens_ctx_create(int device, bayens_ctx** out);
 int bayens_ctx_destroy(bayens_ctx* ctx);
 const char* bayens_last_error(bayens_ctx* ctx);
