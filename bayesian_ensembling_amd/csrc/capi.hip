@@ -128,6 +128,7 @@ void ensure_ws(bayens_ctx* c, int nb, int Np) {
   const size_t vsz = (size_t)nb * Np * sizeof(double);
   w.theta1 = (double*)dalloc(vsz); w.mvec = (double*)dalloc(vsz); w.avec = (double*)dalloc(vsz);
   w.y = (double*)dalloc(vsz); w.nu = (double*)dalloc(vsz); w.muvec = (double*)dalloc(vsz);
+  w.uvec = (double*)dalloc(vsz);
   w.ustate = (double*)dalloc((size_t)nb * 8 * sizeof(double));
   w.info = (int*)dalloc((size_t)nb * sizeof(int));
 }
@@ -139,7 +140,7 @@ FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) {
   for (Mat* m : {&v.K0, &v.Lb, &v.Lam, &v.Cb, &v.T1, &v.T2}) m->p += (long)b0 * m->stride;
   const long is = v.inv_stride();
   v.invL += b0 * is; v.invC += b0 * is;
-  for (double** p : {&v.theta1, &v.mvec, &v.avec, &v.y, &v.nu, &v.muvec}) *p += (long)b0 * v.Np;
+  for (double** p : {&v.theta1, &v.mvec, &v.avec, &v.y, &v.nu, &v.muvec, &v.uvec}) *p += (long)b0 * v.Np;
   v.ustate += (long)b0 * 8;
   v.info += b0;
   return v;

@@ -118,32 +118,29 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
     P.mark("Lam update");
-    // natural-gradient step:  Lam <- (1-g) Lam + g (I + L^T D L),  theta1 <- (1-g) theta1 + g L^T D y
+    // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
-    P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 1.0 - fp.gamma, ws.Lam,
-           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, fp.gamma);
-    P.theta_update(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, ws.theta1);
+    P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 0.0, ws.T2, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
+    P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1);     // Lam, Cb = tril(Lam), T1 = G (full)
+    P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
     P.mark("potrf Lam");
-    P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
-    P.mark("L S solves");
-    // [L; theta1^T] C^-T C^-1 = [L S; m^T]: the variational mean m = Lam^-1 theta1 rides through the two
-    // solves that produce L S for the Adam step (models.py:210) as one extra row block of the right-hand side
-    // (the theta1 row replaces the last padded row of L when the member has padding, else it is appended)
-    P.copy(nb, Np, ws.Lb, ws.T1);
+    P.mark("G S solves");
+    // [G; theta1^T] C^-T C^-1 = [G S; m^T].  G S is all the Adam step (models.py:210) needs of S: for i >= j
+    //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
+    // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.  The variational mean
+    // m = S theta1 rides through the same two solves as one extra row (the last padded row when there is padding).
     const bool in_pad = Np > N;
     const int mrows = in_pad ? Np : Np + LEAF;
     Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
     P.aug_set(nb, Np, trow, ws.theta1, in_pad ? 0 : LEAF - 1);
-    trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);            // [L; theta1^T] C^-T
+    trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);            // [G; theta1^T] C^-T
     trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);     // ... C^-1
     P.aug_get(nb, Np, trow, ws.mvec);                                 // m
-    P.mark("Lbar, Phi");
+    P.mark("Phi");
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
-    P.form_lbar(nb, Np, ws.T1, ws.avec, ws.mvec, ws.nu);              // Lbar = tril(D (a m^T + L S))
-    P.gemm(nb, Np, Np, Np, 1.0, ws.Lb, ws.T1, 0.0, ws.T2,
-           GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI | GEMM_ZERO_SKIPPED, 0.0);   // Phi(L^T Lbar): a clean
-    // lower-triangular right-hand side (the solve below reads whole row panels of it)
+    P.lt_dvec(nb, Np, ws.Lb, ws.avec, ws.nu, 1.0, 0.0, ws.uvec);      // u = L^T D a
+    P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2);               // Phi(L^T Lbar), clean lower triangle
     P.mark("Phi L^-1");
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
     P.mark("W^T L^-1");
@@ -220,12 +217,12 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
 }
 
 double fit_flops(int N, int R, int n_iters) {
-  // per iteration: chol K 1/3, L^T D L 1/3, chol Lam 1/3, L C^-T 1, (.) C^-1 1, L^T Lbar 1/3,
-  //                Phi L^-1 1/3, W^T L^-1 1  => 14/3 N^3 ; kernel matrix 2 N^2 R
+  // per iteration: chol K 1/3, G = L^T D L 1/3, chol Lam 1/3, G C^-T 1, (.) C^-1 1,
+  //                Phi L^-1 1/3, W^T L^-1 1  => 13/3 N^3 ; kernel matrix 2 N^2 R
   // prediction: chol K 1/3, K0 L^-T 1, (.) C^-T 1, two symmetric rank-N updates 1 + 1 => 13/3 N^3,
   //             chol(cov) 1/3
   double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
-  return n_iters * (14.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0;
+  return n_iters * (13.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0;
 }
 
 }  // namespace bayens

@@ -27,6 +27,7 @@ struct FitWorkspace {
   double* y = nullptr;             // padded y_mean
   double* nu = nullptr;            // padded y_var (1 in the padded part)
   double* muvec = nullptr;
+  double* uvec = nullptr;          // L^T D (L m - y)
   double* ustate = nullptr;        // [nb][8]
   int* info = nullptr;             // [nb]
   long inv_stride() const { return (long)Np * LEAF; }

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   // strip (16 per lane) are all loaded before the first store of that strip: with a runtime ldc the compiler
   // cannot reorder a load past an earlier store, and one exposed memory round trip per element (64 per lane)
   // cost ~27 us per tile; batched, it is one round trip per strip.
-  const bool phi = g.flags & GEMM_EPI_PHI;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double cv[4][4];
@@ -192,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         double v = g.alpha * acc[i][j][r];
         if (g.beta != 0.0) v += g.beta * cv[j][r];
         if (row == col) v += g.diag_add;
-        if (phi) v = row < col ? 0.0 : (row == col ? 0.5 * v : v);
         C[(long)row * g.ldc + col] = v;
       }
     }
@@ -411,7 +409,7 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   }
   const bool ta = flags & GEMM_TA, tb = flags & GEMM_TB;
   dim3 grid(g.total), block(256);
-  const int special = GEMM_KTRIM_TN_LOWER | GEMM_EPI_PHI | GEMM_ZERO_SKIPPED;
+  const int special = GEMM_KTRIM_TN_LOWER | GEMM_ZERO_SKIPPED;
   int fam = ta ? FAM_GEMM_TN : (tb ? FAM_GEMM_NT : FAM_GEMM_NN);
   if (n == 64 && k == 64 && !ta && !(flags & special)) {
     fam = FAM_PANEL64;

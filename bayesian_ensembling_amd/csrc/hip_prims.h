@@ -62,14 +62,15 @@ struct HipPrims : Prims {
   void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
             Mat K0, Mat Lb) override;
   void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
-  void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
-                    double* theta1) override;
+  void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta,
+               double* out) override;
+  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override;
+  void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) override;
   void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) override;
   void aug_get(int nb, int n, Mat rows, double* vec) override;
   void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) override;
   void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override;
   void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
-  void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override;
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
                  double lr) override;
   void gemv_n(int nb, int n, Mat A, const double* x, double* y) override;

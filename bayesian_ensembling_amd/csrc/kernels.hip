@@ -127,16 +127,57 @@ __global__ void scale_rows_kernel(int n, Mat src, const double* nu, Mat dst) {
   }
 }
 
-__global__ void form_lbar_kernel(int n, Mat X, const double* a, const double* mvec, const double* nu) {
+// Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
+__global__ void form_phi_kernel(int n, Mat GS, const double* u, const double* mvec, Mat Phi) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  double* x = X.p + b * X.stride;
+  const double* g = GS.p + b * GS.stride;
+  double* p = Phi.p + b * Phi.stride;
   const double mj = mvec[(long)b * n + j];
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    double* p = x + (long)i * X.ld + j;
-    *p = j <= i ? (a[(long)b * n + i] * mj + *p) / nu[(long)b * n + i] : 0.0;
+    double v = 0.0;
+    if (j <= i) {
+      v = u[(long)b * n + i] * mj + g[(long)i * GS.ld + j];
+      if (j == i) v *= 0.5;
+    }
+    p[(long)i * Phi.ld + j] = v;
+  }
+}
+
+// natural-gradient precision update (prims.h lam_update): one workgroup per lower 64x64 block (bi >= bj) updates
+// Lam, seeds Cb (lower; the mirrored block of Cb is cleared) and mirrors G into the full symmetric Gfull.
+__global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
+  __shared__ double tile[64][65];
+  const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const double* g = G.p + b * G.stride;
+  double* lam = Lam.p + b * Lam.stride;
+  double* cb = Cb.p + b * Cb.stride;
+  double* gf = Gfull.p + b * Gfull.stride;
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    const int i = bi * 64 + r, j = bj * 64 + c;
+    const double gv = g[(long)i * G.ld + j];
+    tile[r][c] = gv;
+    gf[(long)i * Gfull.ld + j] = gv;                      // the diagonal block of G is complete (both triangles)
+    if (j <= i) {
+      const double v = (1.0 - gamma) * lam[(long)i * Lam.ld + j] + gamma * (gv + (i == j ? 1.0 : 0.0));
+      lam[(long)i * Lam.ld + j] = v;
+      cb[(long)i * Cb.ld + j] = v;
+    } else {
+      cb[(long)i * Cb.ld + j] = 0.0;                      // strict upper part inside a diagonal block
+    }
+  }
+  if (bi == bj) return;
+  __syncthreads();
+  for (int q = 0; q < 16; ++q) {                           // mirrored block (bj, bi): G^T into Gfull, zeros into Cb
+    const int r = r0 + 4 * q;
+    const long off = (long)(bj * 64 + r) * Gfull.ld + bi * 64 + c;
+    gf[off] = tile[c][r];
+    cb[(long)(bj * 64 + r) * Cb.ld + bi * 64 + c] = 0.0;
   }
 }
 
@@ -536,10 +577,10 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
 // ------------------------------------------------------------------------------------------------
 // matrix-vector kernels
 // ------------------------------------------------------------------------------------------------
-// theta1 = (1-gamma) theta1 + gamma L^T (y/nu): one workgroup per 64 columns; lanes = columns (512-byte
-// coalesced row segments), the 4 waves split the rows i >= j0 (L is lower triangular).
-__global__ __launch_bounds__(256) void theta_update_kernel(int n, Mat L, const double* y, const double* nu,
-                                                           double gamma, double* theta1) {
+// out = beta out + alpha L^T (v/nu): one workgroup per 64 columns; lanes = columns (512-byte coalesced row
+// segments), the 4 waves split the rows i >= j0 (L is lower triangular).
+__global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const double* y, const double* nu, double alpha,
+                                                      double beta, double* theta1) {
   __shared__ double part[4][64];
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -552,7 +593,7 @@ __global__ __launch_bounds__(256) void theta_update_kernel(int n, Mat L, const d
   if (w == 0) {
     const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
     double* t = theta1 + (long)b * n + j0 + c;
-    *t = (1.0 - gamma) * (*t) + gamma * tot;
+    *t = (beta != 0.0 ? beta * (*t) : 0.0) + alpha * tot;
   }
 }
 
@@ -1116,8 +1157,12 @@ void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat ds
   hipLaunchKernelGGL(scale_rows_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, nu, dst);
   LAUNCH_CHECK();
 }
-void HipPrims::theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma, double* theta1) {
-  hipLaunchKernelGGL(theta_update_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, y, nu, gamma, theta1);
+void HipPrims::lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta, double* out) {
+  hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, v, nu, alpha, beta, out);
+  LAUNCH_CHECK();
+}
+void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
+  hipLaunchKernelGGL(lam_update_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, G, gamma, Lam, Cb, Gfull);
   LAUNCH_CHECK();
 }
 void HipPrims::aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) {
@@ -1149,8 +1194,8 @@ void HipPrims::resid(int nb, int n, Mat L, const double* mvec, const double* y, 
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
   LAUNCH_CHECK();
 }
-void HipPrims::form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) {
-  hipLaunchKernelGGL(form_lbar_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, X, a, mvec, nu);
+void HipPrims::form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) {
+  hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi);
   LAUNCH_CHECK();
 }
 void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) {

@@ -30,7 +30,6 @@ enum : int {
   GEMM_TB = 2,             // B is stored n x k (use B^T)
   GEMM_TRI_OUT = 4,        // C square: skip 64x64 blocks strictly above the diagonal (not written)
   GEMM_KTRIM_TN_LOWER = 8, // with TA, !TB: A and B are lower triangular => k starts at max(i0, j0)
-  GEMM_EPI_PHI = 16,       // epilogue: zero where i<j, halve where i==j   (Cholesky-backward Phi)
   GEMM_ZERO_SKIPPED = 32,  // with TRI_OUT: the skipped 64x64 blocks are written with zeros instead of left alone
 };
 
@@ -69,9 +68,16 @@ struct Prims {
                     double jitter, Mat K0, Mat Lb) = 0;
 
   virtual void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
-  // theta1 = (1-gamma) theta1 + gamma * L^T (y / nu)
-  virtual void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma,
-                            double* theta1) = 0;
+  // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)
+  virtual void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta,
+                       double* out) = 0;
+  // natural-gradient precision update from G = L^T D L (lower 64-blocks of G valid):
+  //   Lam <- (1-gamma) Lam + gamma (I + G) on the lower triangle;  Cb <- tril(Lam) with zeros above;
+  //   Gfull <- G mirrored to a full symmetric matrix
+  virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) = 0;
+  // Phi(L^T Lbar) without forming Lbar: for i >= j, (L^T Lbar)_ij = u_i m_j + (G S)_ij with u = L^T D (L m - y)
+  //   Phi_ij = u_i m_j + GS_ij (i > j), half of it on the diagonal, 0 above
+  virtual void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) = 0;
   // a row of an n-column right-hand side that carries a vector through the same triangular solves
   // (x^T C^-T C^-1 = (C^-T C^-1 x)^T): rows[0][:] = vec and the `zero_rows` rows after it are cleared.
   // The row is either the first of a 64-row block appended below the matrix (zero_rows = 63) or, when the
@@ -86,8 +92,6 @@ struct Prims {
   virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) = 0;
   virtual void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) = 0;
   virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
-  // X_ij <- (i >= j) ? (a_i m_j + X_ij) / nu_i : 0
-  virtual void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) = 0;
   // g = <Kbt, dK/dtheta> over the real N x N part (Kbt = Kbar^T; dK symmetric), then one Adam step on
   // the unconstrained hypers.  ustate per member: [u_var, u_ls, m_var, m_ls, v_var, v_ls, t, pad]
   virtual void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt,

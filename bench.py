@@ -28,7 +28,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet)
 
 def fit_flops(N, R, T):
     n3, n2r = float(N) ** 3, 2.0 * N * N * R
-    return T * (14.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0
+    return T * (13.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0
 
 
 def make_inputs(M, N, R, R_obs, seed):
@@ -189,7 +189,7 @@ def main():
                                "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
                 "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
                 "note": "HIP events around every launch of the kernel in one fit batch, one stream (no overlap); "
-                        "traffic = HBM bytes per launch from profiles/*_pmc_traffic.json (all gemm_f64_mfma layouts)"}
+                        "traffic = HBM bytes per launch of this kernel from the rocprofv3 --pmc passes in profiles/*_pmc_traffic.json"}
         extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
                  "fit_algorithmic_tflops": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12, 3),
                  "fit_frac_of_f64_peak": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),

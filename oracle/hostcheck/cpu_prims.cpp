@@ -45,7 +45,6 @@ struct CpuPrims : Prims {
           }
           double v = alpha * s + (beta != 0.0 ? beta * c[(size_t)i * C.ld + j] : 0.0);
           if (i == j) v += diag_add;
-          if (flags & GEMM_EPI_PHI) { if (i < j) v = 0; else if (i == j) v *= 0.5; }
           out[(size_t)i * n + j] = v;
         }
       for (int i = 0; i < m; ++i)
@@ -178,13 +177,36 @@ struct CpuPrims : Prims {
         for (int j = 0; j < n; ++j) dst.p[b * dst.stride + (size_t)i * dst.ld + j] = src.p[b * src.stride + (size_t)i * src.ld + j] * s;
       }
   }
-  void theta_update(int nb, int n, Mat L, const double* y, const double* nu, double gamma, double* theta1) override {
+  void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta, double* out) override {
     for (int b = 0; b < nb; ++b)
       for (int j = 0; j < n; ++j) {
         double s = 0;
-        for (int i = j; i < n; ++i) s += L.p[b * L.stride + (size_t)i * L.ld + j] * (y[(size_t)b * n + i] / nu[(size_t)b * n + i]);
-        theta1[(size_t)b * n + j] = (1 - gamma) * theta1[(size_t)b * n + j] + gamma * s;
+        for (int i = j; i < n; ++i) s += L.p[b * L.stride + (size_t)i * L.ld + j] * (v[(size_t)b * n + i] / nu[(size_t)b * n + i]);
+        out[(size_t)b * n + j] = (beta != 0.0 ? beta * out[(size_t)b * n + j] : 0.0) + alpha * s;
       }
+  }
+  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+          const double g = G.p[b * G.stride + (size_t)i * G.ld + j];
+          double& lam = Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j];
+          lam = (1 - gamma) * lam + gamma * (g + (i == j ? 1.0 : 0.0));
+          Cb.p[b * Cb.stride + (size_t)i * Cb.ld + j] = lam;
+          if (j < i) Cb.p[b * Cb.stride + (size_t)j * Cb.ld + i] = 0.0;
+          Gfull.p[b * Gfull.stride + (size_t)i * Gfull.ld + j] = g;
+          Gfull.p[b * Gfull.stride + (size_t)j * Gfull.ld + i] = g;
+        }
+  }
+  void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          double v = 0.0;
+          if (j <= i) v = u[(size_t)b * n + i] * mvec[(size_t)b * n + j] + GS.p[b * GS.stride + (size_t)i * GS.ld + j];
+          if (j == i) v *= 0.5;
+          Phi.p[b * Phi.stride + (size_t)i * Phi.ld + j] = v;
+        }
   }
   void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) override {
     for (int b = 0; b < nb; ++b)
@@ -217,14 +239,6 @@ struct CpuPrims : Prims {
         for (int k = 0; k <= i; ++k) s += L.p[b * L.stride + (size_t)i * L.ld + k] * mvec[(size_t)b * n + k];
         a[(size_t)b * n + i] = s - y[(size_t)b * n + i];
       }
-  }
-  void form_lbar(int nb, int n, Mat X, const double* a, const double* mvec, const double* nu) override {
-    for (int b = 0; b < nb; ++b)
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-          double& x = X.p[b * X.stride + (size_t)i * X.ld + j];
-          x = j <= i ? (a[(size_t)b * n + i] * mvec[(size_t)b * n + j] + x) / nu[(size_t)b * n + i] : 0.0;
-        }
   }
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) override {
     (void)Np;
@@ -333,6 +347,7 @@ struct HostWs {
     ws.invL = alloc((size_t)nb * Np * LEAF); ws.invC = alloc((size_t)nb * Np * LEAF);
     ws.theta1 = alloc((size_t)nb * Np); ws.mvec = alloc((size_t)nb * Np); ws.avec = alloc((size_t)nb * Np);
     ws.y = alloc((size_t)nb * Np); ws.nu = alloc((size_t)nb * Np); ws.muvec = alloc((size_t)nb * Np);
+    ws.uvec = alloc((size_t)nb * Np);
     ws.ustate = alloc((size_t)nb * 8);
     info.assign(nb, 0); ws.info = info.data();
   }
