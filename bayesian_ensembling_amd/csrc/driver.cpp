@@ -154,18 +154,22 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
   P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
-  P.mark("predict: K0 L^-T");
-  P.copy(nb, Np, ws.K0, ws.T1);
-  trsm_rlt(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1);                 // A^T = K0 L^-T
+  // With K0 = L L^T - J I (J the jitter):  A^T = K0 L^-T = L - J L^-T  and  K0 - A^T A = J I - J^2 L^-T L^-1,
+  // so the full solve K0 L^-T and the rank-N update A^T A shrink to the triangular inverse (a lower-rhs solve on I,
+  // N^3/3) and the lower x lower product L^-T L^-1 (N^3/3):  cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T C^-T)(A^T C^-T)^T.
+  P.mark("predict: L^-1, A^T");
+  P.identity(nb, Np, ws.T2);
+  trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);           // L^-1 (lower)
+  P.at_from_linv(nb, Np, ws.Lb, ws.T2, fp.jitter, ws.T1);             // A^T = L - J L^-T
   P.gemv_n(nb, Np, ws.T1, ws.mvec, ws.muvec);                         // mu = A^T m
   P.extract_vec(nb, N, Np, ws.muvec, mu);
   P.mark("predict: A^T C^-T");
-  P.copy(nb, Np, ws.T1, ws.T2);
-  trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2);                 // A^T C^-T
-  P.mark("predict: cov syrk x2");
-  P.cov_init(nb, Np, ws.K0, ws.nu, ws.Lam);                           // Lam reused: K0 + diag(nu)
-  P.gemm(nb, Np, Np, Np, -1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
-  P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
+  trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);                 // A^T C^-T (in place)
+  P.mark("predict: cov products");
+  P.diag_init(nb, Np, ws.nu, fp.jitter, ws.Lam);                      // Lam reused: diag(nu + J)
+  P.gemm(nb, Np, Np, Np, -fp.jitter * fp.jitter, ws.T2, ws.T2, 1.0, ws.Lam,
+         GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
+  P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
   P.extract(nb, N, ws.Lam, cov, 1);
   P.mark("chol(cov)");
   if (chol || logdet || basis) {
@@ -219,10 +223,9 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
 double fit_flops(int N, int R, int n_iters) {
   // per iteration: chol K 1/3, G = L^T D L 1/3, chol Lam 1/3, G C^-T 1, (.) C^-1 1,
   //                Phi L^-1 1/3, W^T L^-1 1  => 13/3 N^3 ; kernel matrix 2 N^2 R
-  // prediction: chol K 1/3, K0 L^-T 1, (.) C^-T 1, two symmetric rank-N updates 1 + 1 => 13/3 N^3,
-  //             chol(cov) 1/3
+  // prediction: chol K 1/3, L^-1 1/3, A^T C^-T 1, L^-T L^-1 1/3, rank-N update 1 => 3 N^3, chol(cov) 1/3
   double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
-  return n_iters * (13.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0;
+  return n_iters * (13.0 / 3.0 * n3 + n2r) + (3.0 * n3 + n2r) + n3 / 3.0;
 }
 
 }  // namespace bayens

@@ -74,7 +74,9 @@ struct HipPrims : Prims {
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
                  double lr) override;
   void gemv_n(int nb, int n, Mat A, const double* x, double* y) override;
-  void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) override;
+  void identity(int nb, int n, Mat A) override;
+  void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) override;
+  void diag_init(int nb, int n, const double* nu, double add, Mat dst) override;
   void extract(int nb, int N, Mat src, double* dst, int mode) override;
   void extract_vec(int nb, int N, int Np, const double* src, double* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;

@@ -181,15 +181,40 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   }
 }
 
-__global__ void cov_init_kernel(int n, Mat K0, const double* nu, Mat dst) {
+// At = L - jitter * Linv^T (prims.h at_from_linv): output tile (bi, bj) needs L's tile (bi, bj) (lower part) and
+// the transpose of Linv's tile (bj, bi) (lower part), which goes through LDS
+__global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Linv, double jitter, Mat At) {
+  __shared__ double tile[64][65];
+  const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const double* l = L.p + b * L.stride;
+  const double* li = Linv.p + b * Linv.stride;
+  double* at = At.p + b * At.stride;
+  if (bj >= bi) {                    // upper (or diagonal) block: Linv tile (bj, bi) exists
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      const int gi = bj * 64 + r, gj = bi * 64 + c;
+      tile[r][c] = gj <= gi ? li[(long)gi * Linv.ld + gj] : 0.0;
+    }
+    __syncthreads();
+  }
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    const int i = bi * 64 + r, j = bj * 64 + c;
+    const double lv = j <= i ? l[(long)i * L.ld + j] : 0.0;
+    const double lit = bj >= bi ? tile[c][r] : 0.0;        // (Linv^T)_ij = Linv_ji
+    at[(long)i * At.ld + j] = lv - jitter * lit;
+  }
+}
+
+__global__ void diag_init_kernel(int n, const double* nu, double add, Mat dst) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const double* s = K0.p + b * K0.stride;
   double* d = dst.p + b * dst.stride;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    d[(long)i * dst.ld + j] = s[(long)i * K0.ld + j] + (i == j ? nu[(long)b * n + i] : 0.0);
+    d[(long)i * dst.ld + j] = i == j ? nu[(long)b * n + i] + add : 0.0;
   }
 }
 
@@ -1211,8 +1236,16 @@ void HipPrims::gemv_n(int nb, int n, Mat A, const double* x, double* y) {
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, x, (const double*)nullptr, y, 0);
   LAUNCH_CHECK();
 }
-void HipPrims::cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) {
-  hipLaunchKernelGGL(cov_init_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, K0, nu, dst);
+void HipPrims::identity(int nb, int n, Mat A) {
+  hipLaunchKernelGGL(fill_identity_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, A);
+  LAUNCH_CHECK();
+}
+void HipPrims::at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) {
+  hipLaunchKernelGGL(at_from_linv_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, L, Linv, jitter, At);
+  LAUNCH_CHECK();
+}
+void HipPrims::diag_init(int nb, int n, const double* nu, double add, Mat dst) {
+  hipLaunchKernelGGL(diag_init_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, nu, add, dst);
   LAUNCH_CHECK();
 }
 void HipPrims::extract(int nb, int N, Mat src, double* dst, int mode) {

@@ -97,7 +97,10 @@ struct Prims {
   virtual void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt,
                          double* ustate, double lr) = 0;
   virtual void gemv_n(int nb, int n, Mat A, const double* x, double* y) = 0;    // y = A x
-  virtual void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) = 0;  // dst = K0 + diag(nu)
+  virtual void identity(int nb, int n, Mat A) = 0;                              // A = I
+  // At = L - jitter * Linv^T  (= K0 L^-T, because K0 = L L^T - jitter I); L, Linv lower triangular
+  virtual void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) = 0;
+  virtual void diag_init(int nb, int n, const double* nu, double add, Mat dst) = 0;   // dst = diag(nu + add)
   // compact copy-out of the real N x N part: mode 0 as is, 1 symmetric from the lower triangle,
   // 2 lower triangle with zeros above
   virtual void extract(int nb, int N, Mat src, double* dst, int mode) = 0;

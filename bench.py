@@ -28,7 +28,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet)
 
 def fit_flops(N, R, T):
     n3, n2r = float(N) ** 3, 2.0 * N * N * R
-    return T * (13.0 / 3.0 * n3 + n2r) + (13.0 / 3.0 * n3 + n2r) + n3 / 3.0
+    return T * (13.0 / 3.0 * n3 + n2r) + (3.0 * n3 + n2r) + n3 / 3.0
 
 
 def make_inputs(M, N, R, R_obs, seed):

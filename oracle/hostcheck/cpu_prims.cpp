@@ -273,11 +273,24 @@ struct CpuPrims : Prims {
         y[(size_t)b * n + i] = s;
       }
   }
-  void cov_init(int nb, int n, Mat K0, const double* nu, Mat dst) override {
+  void identity(int nb, int n, Mat A) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j)
-          dst.p[b * dst.stride + (size_t)i * dst.ld + j] = K0.p[b * K0.stride + (size_t)i * K0.ld + j] + (i == j ? nu[(size_t)b * n + i] : 0.0);
+        for (int j = 0; j < n; ++j) A.p[b * A.stride + (size_t)i * A.ld + j] = i == j ? 1.0 : 0.0;
+  }
+  void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const double l = j <= i ? L.p[b * L.stride + (size_t)i * L.ld + j] : 0.0;
+          const double lit = j >= i ? Linv.p[b * Linv.stride + (size_t)j * Linv.ld + i] : 0.0;   // (Linv^T)_ij
+          At.p[b * At.stride + (size_t)i * At.ld + j] = l - jitter * lit;
+        }
+  }
+  void diag_init(int nb, int n, const double* nu, double add, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) dst.p[b * dst.stride + (size_t)i * dst.ld + j] = i == j ? nu[(size_t)b * n + i] + add : 0.0;
   }
   void extract(int nb, int N, Mat src, double* dst, int mode) override {
     for (int b = 0; b < nb; ++b)

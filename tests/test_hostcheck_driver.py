@@ -82,7 +82,7 @@ def test_flop_model(hostcheck):
     hostcheck.hostcheck_fit_flops.restype = ctypes.c_double
     f = hostcheck.hostcheck_fit_flops(2000, 8, 2)
     n3 = 2000.0 ** 3
-    assert abs(f - (2 * (13 / 3 * n3 + 2 * 2000 * 2000 * 8) + 13 / 3 * n3 + 2 * 2000 * 2000 * 8 + n3 / 3)) < 1.0
+    assert abs(f - (2 * (13 / 3 * n3 + 2 * 2000 * 2000 * 8) + 3 * n3 + 2 * 2000 * 2000 * 8 + n3 / 3)) < 1.0
 
 
 def test_polar_iteration_gives_the_w2_trace_term(hostcheck):
