@@ -69,6 +69,10 @@ static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stri
     }
     return;
   }
+  if (n == 2 * LEAF && extra == 0) {
+    P.potrf_leaf2(nb, A, inv, inv_stride, base, info);
+    return;
+  }
   int n1 = split_point(n), n2 = n - n1;
   potrf_rec(P, nb, n1, A, inv, inv_stride, info, base, 0);
   // [L21; E1] = [A21; E1] L11^-T
@@ -114,7 +118,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   for (int it = 0; it < fp.n_iters; ++it) {
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.mark("kmat");
-    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
+    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
     P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
     P.mark("Lam update");
@@ -152,7 +156,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
-  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.K0, ws.Lb);
+  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
   // With K0 = L L^T - J I (J the jitter):  A^T = K0 L^-T = L - J L^-T  and  K0 - A^T A = J I - J^2 L^-T L^-1,
   // so the full solve K0 L^-T and the rank-N update A^T A shrink to the triangular inverse (a lower-rhs solve on I,

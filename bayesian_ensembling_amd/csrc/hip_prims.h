@@ -54,13 +54,14 @@ struct HipPrims : Prims {
             double diag_add) override;
   void trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) override;
   void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
+  void potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override;
   void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
                   const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) override;
   void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
-            Mat K0, Mat Lb) override;
+            Mat Lb) override;
   void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
   void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta,
                double* out) override;

@@ -322,8 +322,8 @@ __global__ void xprep_kernel(int N, int Np, int R, int R4, const double* X, cons
 // GRAD=false: write K0 and Lb.  GRAD=true: accumulate <Kbt, K0> and <Kbt, dK/dl> over the real part.
 template <bool GRAD>
 __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
-                                                   const double* ustate, int kernel, double jitter, Mat K0,
-                                                   Mat Lb, Mat Kbt, double* gpart) {
+                                                   const double* ustate, int kernel, double jitter, Mat Lb,
+                                                   Mat Kbt, double* gpart) {
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -332,6 +332,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   const double* xb = xs + (long)b * Np * R4;
   const double* sb = ssq + (long)b * Np;
   double gv = 0.0, gl = 0.0;
+  if (!GRAD && blockIdx.x > blockIdx.y) {   // tiles above the diagonal of the lower image: zeros, no kernel evaluation
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Lb.p[b * Lb.stride + (long)(i0 + lk + 4 * r) * Lb.ld + j0 + jt * 16 + lr] = 0.0;
+    return;
+  }
   for (int jt = 0; jt < 4; ++jt) {
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     for (int kk = 0; kk < R4; kk += 4) {
@@ -355,7 +362,6 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
         }
       } else {
         if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
-        K0.p[b * K0.stride + (long)i * K0.ld + j] = K;
         Lb.p[b * Lb.stride + (long)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
       }
     }
@@ -430,9 +436,9 @@ constexpr int LS = 66;   // LDS row stride (doubles) of the 64x64 images
 // it stays in VGPRs (v_readlane would put 2 x 136 values through the SGPR file and spill it into VGPR lanes).
 template <int K>
 __device__ __forceinline__ double bcast16_k(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  // one v_mov_b64_dpp: the 64-bit DPP move exists for exactly this control; every lane has a source lane, so the
+  // "old" operand is never taken
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false);
 }
 __device__ __forceinline__ double readlane_d(double v, int k) {
   switch (k) {
@@ -447,8 +453,7 @@ __device__ __forceinline__ double readlane_d(double v, int k) {
 
 __device__ __forceinline__ double rsqrt_refined(double d) {
   double r = __builtin_amdgcn_rsq(d);            // v_rsq_f64: ~2^-26 relative
-  r = r * (1.5 - 0.5 * d * r * r);               // Newton: quadratic convergence, two steps reach fp64
-  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);               // Newton: ~2^-51 after one step
   // one correction in fma form: r <- r + r * (1 - d r^2) / 2
   const double e = fma(-d * r, r, 1.0);
   return fma(0.5 * r, e, r);
@@ -483,40 +488,27 @@ __device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LS], int ar,
 // s_memtime at the phase boundaries into stamps[0..]
 #define LEAF_STAMP(k) do { if (stamps && b == 0 && tid == 0) stamps[k] = __builtin_readcyclecounter(); } while (0)
 
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
-                                                         int* info, unsigned long long* stamps) {
-  __shared__ double S[64][LS];     // the block -> its lower factor
-  __shared__ double Mi[64][LS];    // inverse of the factor
-  __shared__ double Tt[4][16][LS]; // per-wave 16x16 scratch for P4
-  const int b = blockIdx.x, tid = threadIdx.x;
+// factor + invert the 64x64 image in S (lower part loaded, strict upper part of the off-diagonal 16-blocks zero),
+// Mi zeroed; all 256 threads call, both images are complete and visible on return
+__device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], double (*Tt)[16][LS], int b, int tid,
+                                            int pivot_base, int* info, unsigned long long* stamps) {
   const int lane = tid & 63, wave = tid >> 6;
-  double* a = Ablk.p + b * Ablk.stride;
-  {
-    const int c = tid & 63, r0 = tid >> 6;
-    for (int q = 0; q < 16; ++q) {
-      const int r = r0 + 4 * q;
-      S[r][c] = c <= r ? a[(long)r * Ablk.ld + c] : 0.0;
-      Mi[r][c] = 0.0;
-    }
-  }
-  __syncthreads();
-  LEAF_STAMP(0);
-
   for (int bj = 0; bj < 4; ++bj) {
     const int d0 = 16 * bj;
     // ---- P1: factor + invert the 16x16 diagonal sub-block (wave 0, lanes 0..15 own rows) ----
     if (wave == 0) {
       double row[16], rinv[16], m[16];
       const int li = lane & 15;
+      int bad = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) row[j] = S[d0 + li][d0 + j];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double d = readlane_d(row[j], j);
-        if (!(d > 0.0)) {
-          if (lane == 0 && info[b] == 0) info[b] = pivot_base + d0 + j + 1;
-          d = 1.0;
-        }
+        // branch-free pivot check (one basic block for the whole column loop): remember the first bad pivot
+        const bool ok = d > 0.0;
+        bad = (!ok && bad == 0) ? d0 + j + 1 : bad;
+        d = ok ? d : 1.0;
         const double r = rsqrt_refined(d);
         rinv[j] = r;
         row[j] = li == j ? d * r : (li > j ? row[j] * r : 0.0);
@@ -526,7 +518,12 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
           const double lkj = readlane_d(row[j], k);
           row[k] = fma(-lij, lkj, row[k]);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts of later columns from being hoisted (VGPR pressure)
       }
+      // (opaque copies: without them the broadcasts below are merged with the factor loop's and 120 doubles stay
+      //  live across both loops - more than the VGPR file)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(row[j]));
       // inverse by columns: lane c owns column c; m[i] = (delta_ic - sum_{k<i} L_ik m_k) * rinv_i
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -534,7 +531,10 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
 #pragma unroll
         for (int k = 0; k < i; ++k) sacc = fma(-readlane_d(row[k], i), m[k], sacc);
         m[i] = sacc * rinv[i];
+        asm volatile("" : "+v"(m[i]));       // pin the row here (else the chain sinks into the store block below
+        __builtin_amdgcn_sched_barrier(0);   //  and all 120 broadcasts stay live)
       }
+      if (bad != 0 && lane == 0 && info[b] == 0) info[b] = pivot_base + bad;
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -586,7 +586,26 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
     __syncthreads();
   }
   LEAF_STAMP(13);
+}
 
+__global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
+                                                         int* info, unsigned long long* stamps) {
+  __shared__ double S[64][LS];     // the block -> its lower factor
+  __shared__ double Mi[64][LS];    // inverse of the factor
+  __shared__ double Tt[4][16][LS]; // per-wave 16x16 scratch for P4
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* a = Ablk.p + b * Ablk.stride;
+  {
+    const int c = tid & 63, r0 = tid >> 6;
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      S[r][c] = c <= r ? a[(long)r * Ablk.ld + c] : 0.0;
+      Mi[r][c] = 0.0;
+    }
+  }
+  __syncthreads();
+  LEAF_STAMP(0);
+  leaf_factor(S, Mi, Tt, b, tid, pivot_base, info, stamps);
   double* iv = inv + b * inv_stride;
   {
     const int c = tid & 63, r0 = tid >> 6;
@@ -597,6 +616,73 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
     }
   }
   LEAF_STAMP(14);
+}
+
+// Two leaves in one launch: the 128x128 diagonal block [A11 .; A21 A22] is factored by one workgroup -
+// leaf(A11), L21 = A21 inv(L11)^T, A22 -= L21 L21^T, leaf(A22) - with L21 held in LDS between the steps.
+// Replaces four launches (leaf, 64x64 panel solve, 64^3 update, leaf) at the bottom of the blocked Cholesky.
+__global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
+                                                          int* info) {
+  __shared__ double S[64][LS];
+  __shared__ double Mi[64][LS];
+  __shared__ double Tt[4][16][LS];   // P4 scratch of the leaves; between them the 64x64 image of A21 / L21
+  double (*T)[LS] = reinterpret_cast<double (*)[LS]>(&Tt[0][0][0]);
+  unsigned long long* stamps = nullptr;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = tid & 63, rq = tid >> 6;
+  const long ld = Ablk.ld;
+  double* a = Ablk.p + b * Ablk.stride;
+  double* iv = inv + b * inv_stride;
+  for (int q = 0; q < 16; ++q) {
+    const int r = rq + 4 * q;
+    S[r][c] = c <= r ? a[r * ld + c] : 0.0;
+    Mi[r][c] = 0.0;
+  }
+  __syncthreads();
+  leaf_factor(S, Mi, Tt, b, tid, pivot_base, info, stamps);
+  for (int q = 0; q < 16; ++q) {
+    const int r = rq + 4 * q;
+    a[r * ld + c] = c <= r ? S[r][c] : 0.0;
+    iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+    T[r][c] = a[(64 + r) * ld + c];
+  }
+  __syncthreads();
+  {   // L21 = A21 inv(L11)^T: wave w owns rows 16w..16w+15 (reads and writes only those rows of T)
+    v4d acc[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int K = 0; K <= J; ++K) acc[J] = tile_mma<true>(acc[J], T, 16 * wave, 16 * K, Mi, 16 * J, 16 * K, lane, 1.0);
+    }
+#pragma unroll
+    for (int J = 0; J < 4; ++J) tile_store(T, 16 * wave, 16 * J, lane, acc[J]);
+  }
+  __syncthreads();
+  for (int q = 0; q < 16; ++q) {
+    const int r = rq + 4 * q;
+    a[(64 + r) * ld + c] = T[r][c];
+    S[r][c] = c <= r ? a[(64 + r) * ld + 64 + c] : 0.0;
+    Mi[r][c] = 0.0;
+  }
+  __syncthreads();
+  {   // A22 -= L21 L21^T on the lower 16-block pairs
+    int p = 0;
+    for (int rb = 0; rb < 4; ++rb)
+      for (int cb = 0; cb <= rb; ++cb, ++p)
+        if ((p & 3) == wave) {
+          v4d acc = tile_load(S, 16 * rb, 16 * cb, lane);
+          for (int K = 0; K < 4; ++K) acc = tile_mma<true>(acc, T, 16 * rb, 16 * K, T, 16 * cb, 16 * K, lane, -1.0);
+          tile_store(S, 16 * rb, 16 * cb, lane, acc);
+        }
+  }
+  __syncthreads();
+  leaf_factor(S, Mi, Tt, b, tid, pivot_base + 64, info, stamps);
+  for (int q = 0; q < 16; ++q) {
+    const int r = rq + 4 * q;
+    a[(64 + r) * ld + 64 + c] = c <= r ? S[r][c] : 0.0;
+    iv[4096 + r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1150,6 +1236,10 @@ void HipPrims::potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pi
                      leaf_stamps);
   LAUNCH_CHECK();
 }
+void HipPrims::potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+  hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info);
+  LAUNCH_CHECK();
+}
 void HipPrims::copy(int nb, int n, Mat src, Mat dst) {
   hipLaunchKernelGGL(copy_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, dst, 0);
   LAUNCH_CHECK();
@@ -1170,12 +1260,12 @@ void HipPrims::init_state(int nb, int N, int Np, Mat Lam, double* theta1, double
   LAUNCH_CHECK();
 }
 void HipPrims::kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
-                    Mat K0, Mat Lb) {
+                    Mat Lb) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq);
   hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
-                     kernel, jitter, K0, Lb, Mat{nullptr, 0, 0}, (double*)nullptr);
+                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr);
   LAUNCH_CHECK();
 }
 void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) {
@@ -1228,7 +1318,7 @@ void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kern
   ensure_scratch(nb, Np, R4);
   // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
   hipLaunchKernelGGL((kmat_kernel<true>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate, kernel,
-                     0.0, Mat{nullptr, 0, 0}, Mat{nullptr, 0, 0}, Kbt, gpart);
+                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart);
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
   LAUNCH_CHECK();
 }

@@ -52,6 +52,15 @@ struct Prims {
   // inverse into inv (64x64 row-major per member, member stride inv_stride).  A non-positive pivot j
   // (0-based inside the block) records info[b] = pivot_base + j + 1 if info[b] was 0.
   virtual void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) = 0;
+  // two adjacent leaves (a 128x128 diagonal block): leaf, 64x64 panel solve, 64^3 update, leaf.  A back end may
+  // fuse the four steps; this composition is the definition.
+  virtual void potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+    potrf_leaf(nb, Ablk, inv, inv_stride, pivot_base, info);
+    trsm_panel(nb, LEAF, LEAF, Ablk, inv, inv_stride, Ablk.sub(LEAF, 0), 0);
+    gemm(nb, LEAF, LEAF, LEAF, -1.0, Ablk.sub(LEAF, 0), Ablk.sub(LEAF, 0), 1.0, Ablk.sub(LEAF, LEAF),
+         GEMM_TB | GEMM_TRI_OUT, 0.0);
+    potrf_leaf(nb, Ablk.sub(LEAF, LEAF), inv + LEAF * LEAF, inv_stride, pivot_base + LEAF, info);
+  }
 
   virtual void copy(int nb, int n, Mat src, Mat dst) = 0;        // full n x n copy
   virtual void tri_copy(int nb, int n, Mat src, Mat dst) = 0;    // dst = tril(src), zeros above
@@ -62,10 +71,11 @@ struct Prims {
                           const double* y_in, const double* nu_in, double* y_pad, double* nu_pad,
                           int* info) = 0;
 
-  // K0 (full, no jitter; identity in the padded part) and Lb = tril(K0) + jitter*I from the current
-  // hypers softplus(ustate[b][0..1]).  X is [nb][N][R] compact.
+  // Lb = tril(K0) + jitter*I (zeros above the diagonal; identity in the padded part) from the current hypers
+  // softplus(ustate[b][0..1]).  X is [nb][N][R] compact.  K0 itself is never stored: the prediction uses
+  // K0 = L L^T - jitter*I (driver.cpp) and the hyper-gradient re-evaluates the kernel (grad_adam).
   virtual void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel,
-                    double jitter, Mat K0, Mat Lb) = 0;
+                    double jitter, Mat Lb) = 0;
 
   virtual void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
   // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)

@@ -156,7 +156,7 @@ struct CpuPrims : Prims {
     return (-2.0 * g + si) + sj;
   }
   void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
-            Mat K0, Mat Lb) override {
+            Mat Lb) override {
     for (int b = 0; b < nb; ++b) {
       double var = softplus(ustate[b * 8 + 0]), ls = softplus(ustate[b * 8 + 1]);
       const double* Xb = X + (size_t)b * N * R;
@@ -165,7 +165,6 @@ struct CpuPrims : Prims {
           double K, d;
           if (i < N && j < N) kern(kernel, var, ls, r2_of(Xb, R, i, j, ls), K, d);
           else K = i == j ? 1.0 : 0.0;
-          K0.p[b * K0.stride + (size_t)i * K0.ld + j] = K;
           Lb.p[b * Lb.stride + (size_t)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
         }
     }
