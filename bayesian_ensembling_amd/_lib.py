@@ -90,6 +90,7 @@ def load():
                                      C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
     lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_bench_leaf.argtypes = [_vp, C.c_int, C.c_int, _dp, _vp]
+    lib.bayens_bench_potrf.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
@@ -437,6 +438,11 @@ class Context:
         st = np.zeros(16, dtype=np.uint64)
         self._check(self.lib.bayens_bench_leaf(self.h, nb, reps, C.byref(us), st.ctypes.data))
         return us.value, st
+
+    def bench_potrf(self, nb=32, n=2048, reps=10):
+        us = C.c_double()
+        self._check(self.lib.bayens_bench_potrf(self.h, nb, n, reps, C.byref(us)))
+        return us.value
 
     def test_potrf(self, A):
         A = np.array(A, dtype=np.float64, order="C", copy=True)

@@ -832,6 +832,38 @@ int bayens_bench_leaf(bayens_ctx* c, int nb, int reps, double* us_per_launch, un
   });
 }
 
+int bayens_bench_potrf(bayens_ctx* c, int nb, int n, int reps, double* us_per_factor) {
+  return guarded(c, [&]() {
+    if (n % LEAF || n <= 0 || reps <= 0) return fail(c, BAYENS_E_ARG, "bench_potrf: n must be a positive multiple of 64");
+    Stage st(c, BAYENS_DEVICE);
+    const size_t an = (size_t)nb * n * n;
+    double* dA = st.scratch<double>(an);
+    double* dS = st.scratch<double>(an);
+    double* inv = st.scratch<double>((size_t)nb * n * LEAF);
+    int* dinfo = st.scratch<int>(nb);
+    BAYENS_HIP(hipMemsetAsync(dinfo, 0, nb * sizeof(int), c->stream));
+    c->prims->fill_random(dA, an, 11);
+    Mat A{dA, n, (long)n * n}, S{dS, n, (long)n * n};
+    c->prims->gemm(nb, n, n, n, 1.0, A, A, 0.0, S, GEMM_TB, (double)n);   // S = A A^T + n I
+    auto timed = [&](bool factor) {
+      BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+      for (int r = 0; r < reps; ++r) {
+        c->prims->tri_copy(nb, n, S, A);
+        if (factor) potrf(*c->prims, nb, n, A, inv, (long)n * LEAF, dinfo);
+      }
+      BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+      BAYENS_HIP(hipEventSynchronize(c->t1));
+      float f = 0;
+      BAYENS_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+      return (double)f * 1e3 / reps;
+    };
+    timed(true);   // warm-up
+    const double with = timed(true), without = timed(false);
+    if (us_per_factor) *us_per_factor = with - without;
+    return 0;
+  });
+}
+
 int bayens_test_potrf(bayens_ctx* c, int nb, int n, double* A, int* info) {
   return guarded(c, [&]() {
     if (n % LEAF) return fail(c, BAYENS_E_ARG, "test_potrf: n must be a multiple of 64");

@@ -1,5 +1,6 @@
 // driver.cpp - see driver.h.  Pure host code: no HIP calls here, only Prims launches.
 #include "driver.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <vector>
@@ -82,8 +83,50 @@ static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stri
   potrf_rec(P, nb, n2, A.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, info, base + n1, extra);
 }
 
+// Top level: right-looking over POTRF_NB-wide block columns - factor the diagonal block (recursively, it is
+// small), solve the whole panel below it in one fused launch, then ONE rank-POTRF_NB update of the entire trailing
+// lower part.  The trailing updates are the largest GEMMs the factorisation admits (m x m x NB with m up to n-NB);
+// the fully recursive form spends the same flops in many mid-sized products that cannot fill 256 CUs with a
+// 32-member batch.
+static int potrf_block_width() {
+  static int nbw = [] {
+    const char* e = std::getenv("BAYENS_POTRF_NB");
+    int v = e ? std::atoi(e) : 256;
+    return (v >= LEAF && v % LEAF == 0) ? v : 256;
+  }();
+  return nbw;
+}
+
 void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows) {
-  potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+  const int NB = potrf_block_width();
+  if (n <= NB || NB > PANEL_MAX) {
+    potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+    return;
+  }
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int w = n - k0 < NB ? n - k0 : NB;
+    const int below = n - k0 - w;
+    double* invk = inv_at(inv, k0 / LEAF);
+    potrf_rec(P, nb, w, A.sub(k0, k0), invk, inv_stride, info, k0, below == 0 ? extra_rows : 0);
+    if (below == 0) break;
+    const int m = below + extra_rows;
+    trsm_rlt(P, nb, m, w, A.sub(k0, k0), invk, inv_stride, A.sub(k0 + w, k0));
+    // Look-ahead: the next block column is updated first, on the main stream; the rest of the trailing part is
+    // updated beside the next diagonal factorisation and panel solve (a few latency-bound workgroups per member),
+    // which touch only that next block column.
+    const int w2 = below < NB ? below : NB;
+    const int c1 = k0 + w;            // first row/column of the trailing part
+    P.side_join();                    // the previous step's trailing update wrote the blocks updated next
+    P.gemm(nb, m, w2, w, -1.0, A.sub(c1, k0), A.sub(c1, k0), 1.0, A.sub(c1, c1), GEMM_TB | GEMM_TRI_OUT, 0.0);
+    if (below > w2) {
+      const int c2 = c1 + w2;
+      P.side_begin();
+      P.gemm(nb, m - w2, below - w2, w, -1.0, A.sub(c2, k0), A.sub(c2, k0), 1.0, A.sub(c2, c2),
+             GEMM_TB | GEMM_TRI_OUT, 0.0);
+      P.side_end();
+    }
+  }
+  P.side_join();
 }
 
 // chol(cov) + logdet + the log-likelihood basis (L_c^-1 1, L_c^-1 mu), covariance (lower part valid) in `src`

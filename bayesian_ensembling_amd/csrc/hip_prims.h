@@ -44,11 +44,18 @@ struct HipPrims : Prims {
   double* gpart = nullptr;    // [nb][tiles][2]
   size_t xs_cap = 0, ssq_cap = 0, gpart_cap = 0;
   unsigned long long* leaf_stamps = nullptr;   // diagnostic only (bayens_bench_leaf)
+  // look-ahead stream of the blocked Cholesky (side_begin / side_end / side_join); created on first use
+  hipStream_t side_stream = nullptr, main_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool in_side = false, side_pending = false;
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
   ~HipPrims() override;
   void ensure_scratch(int nb, int Np, int R4);
   void mark(const char* phase) override;
+  void side_begin() override;
+  void side_end() override;
+  void side_join() override;
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
             double diag_add) override;

@@ -4,6 +4,8 @@
 // written out in SURVEY.md Appendix A.  These kernels are O(N^2) per member and HBM/latency-bound: they
 // are laid out for coalesced 512-byte wave accesses along the contiguous (column / time) axis.
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 
 #include "hip_prims.h"
 
@@ -430,6 +432,7 @@ __global__ void adam_kernel(int ntiles, const double* gpart, double* ustate, dou
 // 3 barriers per block column instead of 5 per scalar column.
 // ------------------------------------------------------------------------------------------------
 constexpr int LS = 66;   // LDS row stride (doubles) of the 64x64 images
+constexpr int LT = 18;   // row stride of the per-wave 16x16 scratch tiles
 
 // broadcast of lane k (0..15) of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+).  The 16x16
 // diagonal sub-block is replicated in all four rows of the wave, so this is the "value of lane k" for every lane,
@@ -459,20 +462,22 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   return fma(0.5 * r, e, r);
 }
 
-// 16x16 MFMA tile helpers on LDS images (row stride LS).  acc rows (lane>>4)+4r, col lane&15.
-__device__ __forceinline__ v4d tile_load(const double (*T)[LS], int r0, int c0, int lane) {
+// 16x16 MFMA tile helpers on LDS images (row stride deduced).  acc rows (lane>>4)+4r, col lane&15.
+template <int LA>
+__device__ __forceinline__ v4d tile_load(const double (*T)[LA], int r0, int c0, int lane) {
   v4d acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)];
   return acc;
 }
-__device__ __forceinline__ void tile_store(double (*T)[LS], int r0, int c0, int lane, v4d acc) {
+template <int LA>
+__device__ __forceinline__ void tile_store(double (*T)[LA], int r0, int c0, int lane, v4d acc) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)] = acc[r];
 }
 // acc += sgn * A(16x16 at (ar,ac)) * B, where B[k][j] = Bm[br + j][bc + k] (i.e. A * Bm^T) if BT else Bm[br + k][bc + j]
-template <bool BT>
-__device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LS], int ar, int ac, const double (*Bm)[LS], int br,
+template <bool BT, int LA, int LB>
+__device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LA], int ar, int ac, const double (*Bm)[LB], int br,
                                         int bc, int lane, double sgn) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -490,7 +495,7 @@ __device__ __forceinline__ v4d tile_mma(v4d acc, const double (*Am)[LS], int ar,
 
 // factor + invert the 64x64 image in S (lower part loaded, strict upper part of the off-diagonal 16-blocks zero),
 // Mi zeroed; all 256 threads call, both images are complete and visible on return
-__device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], double (*Tt)[16][LS], int b, int tid,
+__device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], double (*Tt)[16][LT], int b, int tid,
                                             int pivot_base, int* info, unsigned long long* stamps) {
   const int lane = tid & 63, wave = tid >> 6;
   for (int bj = 0; bj < 4; ++bj) {
@@ -592,8 +597,9 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
                                                          int* info, unsigned long long* stamps) {
   __shared__ double S[64][LS];     // the block -> its lower factor
   __shared__ double Mi[64][LS];    // inverse of the factor
-  __shared__ double Tt[4][16][LS]; // per-wave 16x16 scratch for P4
+  __shared__ double Tt[4][16][LT]; // per-wave 16x16 scratch for P4
   const int b = blockIdx.x, tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);   // a serial chain: win issue arbitration against co-resident throughput waves
   double* a = Ablk.p + b * Ablk.stride;
   {
     const int c = tid & 63, r0 = tid >> 6;
@@ -623,47 +629,48 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
 // Replaces four launches (leaf, 64x64 panel solve, 64^3 update, leaf) at the bottom of the blocked Cholesky.
 __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
                                                           int* info) {
-  __shared__ double S[64][LS];
-  __shared__ double Mi[64][LS];
-  __shared__ double Tt[4][16][LS];   // P4 scratch of the leaves; between them the 64x64 image of A21 / L21
-  double (*T)[LS] = reinterpret_cast<double (*)[LS]>(&Tt[0][0][0]);
+  // two 64x64 images rotate through the four steps (77 KB in all, so two workgroups - or one beside two GEMM
+  // workgroups - fit a CU):   leaf 1: S = U, Mi = V | panel: T = U, Mi = V | update: T = U, S = V | leaf 2: S = V, Mi = U
+  __shared__ double U[64][LS];
+  __shared__ double V[64][LS];
+  __shared__ double Tt[4][16][LT];
   unsigned long long* stamps = nullptr;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c = tid & 63, rq = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);   // a serial chain: win issue arbitration against co-resident throughput waves
   const long ld = Ablk.ld;
   double* a = Ablk.p + b * Ablk.stride;
   double* iv = inv + b * inv_stride;
   for (int q = 0; q < 16; ++q) {
     const int r = rq + 4 * q;
-    S[r][c] = c <= r ? a[r * ld + c] : 0.0;
-    Mi[r][c] = 0.0;
+    U[r][c] = c <= r ? a[r * ld + c] : 0.0;
+    V[r][c] = 0.0;
   }
   __syncthreads();
-  leaf_factor(S, Mi, Tt, b, tid, pivot_base, info, stamps);
-  for (int q = 0; q < 16; ++q) {
+  leaf_factor(U, V, Tt, b, tid, pivot_base, info, stamps);
+  for (int q = 0; q < 16; ++q) {   // L11, inv(L11) out; A21 in (each thread replaces only its own elements of U)
     const int r = rq + 4 * q;
-    a[r * ld + c] = c <= r ? S[r][c] : 0.0;
-    iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
-    T[r][c] = a[(64 + r) * ld + c];
+    a[r * ld + c] = c <= r ? U[r][c] : 0.0;
+    iv[r * 64 + c] = c <= r ? V[r][c] : 0.0;
+    U[r][c] = a[(64 + r) * ld + c];
   }
   __syncthreads();
-  {   // L21 = A21 inv(L11)^T: wave w owns rows 16w..16w+15 (reads and writes only those rows of T)
+  {   // L21 = A21 inv(L11)^T: wave w owns rows 16w..16w+15 (reads and writes only those rows of U)
     v4d acc[4];
 #pragma unroll
     for (int J = 0; J < 4; ++J) {
       acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
-      for (int K = 0; K <= J; ++K) acc[J] = tile_mma<true>(acc[J], T, 16 * wave, 16 * K, Mi, 16 * J, 16 * K, lane, 1.0);
+      for (int K = 0; K <= J; ++K) acc[J] = tile_mma<true>(acc[J], U, 16 * wave, 16 * K, V, 16 * J, 16 * K, lane, 1.0);
     }
 #pragma unroll
-    for (int J = 0; J < 4; ++J) tile_store(T, 16 * wave, 16 * J, lane, acc[J]);
+    for (int J = 0; J < 4; ++J) tile_store(U, 16 * wave, 16 * J, lane, acc[J]);
   }
   __syncthreads();
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 16; ++q) {   // L21 out; A22 (lower) into V, whose inverse image is no longer needed
     const int r = rq + 4 * q;
-    a[(64 + r) * ld + c] = T[r][c];
-    S[r][c] = c <= r ? a[(64 + r) * ld + 64 + c] : 0.0;
-    Mi[r][c] = 0.0;
+    a[(64 + r) * ld + c] = U[r][c];
+    V[r][c] = c <= r ? a[(64 + r) * ld + 64 + c] : 0.0;
   }
   __syncthreads();
   {   // A22 -= L21 L21^T on the lower 16-block pairs
@@ -671,17 +678,19 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv,
     for (int rb = 0; rb < 4; ++rb)
       for (int cb = 0; cb <= rb; ++cb, ++p)
         if ((p & 3) == wave) {
-          v4d acc = tile_load(S, 16 * rb, 16 * cb, lane);
-          for (int K = 0; K < 4; ++K) acc = tile_mma<true>(acc, T, 16 * rb, 16 * K, T, 16 * cb, 16 * K, lane, -1.0);
-          tile_store(S, 16 * rb, 16 * cb, lane, acc);
+          v4d acc = tile_load(V, 16 * rb, 16 * cb, lane);
+          for (int K = 0; K < 4; ++K) acc = tile_mma<true>(acc, U, 16 * rb, 16 * K, U, 16 * cb, 16 * K, lane, -1.0);
+          tile_store(V, 16 * rb, 16 * cb, lane, acc);
         }
   }
   __syncthreads();
-  leaf_factor(S, Mi, Tt, b, tid, pivot_base + 64, info, stamps);
+  for (int q = 0; q < 16; ++q) U[rq + 4 * q][c] = 0.0;
+  __syncthreads();
+  leaf_factor(V, U, Tt, b, tid, pivot_base + 64, info, stamps);
   for (int q = 0; q < 16; ++q) {
     const int r = rq + 4 * q;
-    a[(64 + r) * ld + 64 + c] = c <= r ? S[r][c] : 0.0;
-    iv[4096 + r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+    a[(64 + r) * ld + 64 + c] = c <= r ? V[r][c] : 0.0;
+    iv[4096 + r * 64 + c] = c <= r ? U[r][c] : 0.0;
   }
 }
 
@@ -1212,6 +1221,39 @@ HipPrims::~HipPrims() {
   if (gpart) (void)hipFree(gpart);
   for (auto& e : prof.events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (side_stream) (void)hipStreamDestroy(side_stream);
+}
+
+// The per-launch accounting (prof.enabled) wants kernels one after another on one stream: no side stream then.
+void HipPrims::side_begin() {
+  if (prof.enabled || in_side) return;
+  if (!side_stream) {
+    // A plain stream: on this platform a stream created with a non-default priority or with a CU mask
+    // (hipStreamCreateWithPriority / hipExtStreamCreateWithCUMask) ran every kernel ~1.5x slower (measured,
+    // DESIGN.md section 6); the latency-bound side of the overlap raises its wave priority instead (s_setprio).
+    BAYENS_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    BAYENS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    BAYENS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  BAYENS_HIP(hipEventRecord(ev_fork, stream));
+  BAYENS_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+  main_stream = stream;
+  stream = side_stream;
+  in_side = true;
+}
+void HipPrims::side_end() {
+  if (!in_side) return;
+  BAYENS_HIP(hipEventRecord(ev_join, stream));
+  stream = main_stream;
+  in_side = false;
+  side_pending = true;
+}
+void HipPrims::side_join() {
+  if (!side_pending) return;
+  BAYENS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+  side_pending = false;
 }
 
 void HipPrims::mark(const char* phase) {

@@ -51,6 +51,13 @@ struct Prims {
   // Cholesky of one 64x64 diagonal block per member, in place (lower; strict upper set to 0), plus its
   // inverse into inv (64x64 row-major per member, member stride inv_stride).  A non-positive pivot j
   // (0-based inside the block) records info[b] = pivot_base + j + 1 if info[b] was 0.
+  // Concurrency hints.  Work issued between side_begin() and side_end() starts after everything issued before
+  // side_begin() and may overlap whatever the caller issues after side_end(); side_join() makes everything issued
+  // after it wait for that side work.  Program order (these defaults) is always a valid schedule.
+  virtual void side_begin() {}
+  virtual void side_end() {}
+  virtual void side_join() {}
+
   virtual void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) = 0;
   // two adjacent leaves (a 128x128 diagonal block): leaf, 64x64 panel solve, 64^3 update, leaf.  A back end may
   // fuse the four steps; this composition is the definition.

@@ -177,6 +177,9 @@ int bayens_test_gemm(bayens_ctx* ctx, int nb, int m, int n, int k, double alpha,
 int bayens_bench_gemm(bayens_ctx* ctx, int nb, int m, int n, int k, int flags, int reps, double* ms_per_launch);
 /* times the 64x64 diagonal-block kernel (copy + leaf per rep) and returns s_memtime stamps of its phases */
 int bayens_bench_leaf(bayens_ctx* ctx, int nb, int reps, double* us_per_launch, unsigned long long* stamps16);
+/* Diagnostic: nb device-generated SPD matrices of order n (a multiple of 64); us_per_factor = time of one batched
+ * blocked Cholesky (the copy that restores the input between repetitions is timed separately and subtracted). */
+int bayens_bench_potrf(bayens_ctx* ctx, int nb, int n, int reps, double* us_per_factor);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
