@@ -65,6 +65,7 @@ def load():
     lib.bayens_set_groups.argtypes = [_vp, C.c_int]
     lib.bayens_profile_stages.argtypes = [_vp, C.c_char_p, C.c_int]
     lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
+    lib.bayens_profile_bytes.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -214,7 +215,9 @@ class Context:
     def profile_get(self, family=0):
         ms, fl, n = C.c_double(), C.c_double(), C.c_long()
         self._check(self.lib.bayens_profile_get(self.h, family, C.byref(ms), C.byref(fl), C.byref(n)))
-        return {"ms": ms.value, "flop": fl.value, "launches": n.value}
+        by = C.c_double()
+        self._check(self.lib.bayens_profile_bytes(self.h, family, C.byref(by)))
+        return {"ms": ms.value, "flop": fl.value, "launches": n.value, "bytes": by.value}
 
     # -- hot path (host arrays in, host arrays out) --------------------------------------------------
     def gp_fit_batch(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6,

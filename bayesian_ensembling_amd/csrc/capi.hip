@@ -339,9 +339,20 @@ int bayens_profile_enable(bayens_ctx* c, int on) {
       KernelProfile& p = hp->prof;
       for (auto& e : p.events) { p.pool.push_back(e.a); p.pool.push_back(e.b); }
       p.events.clear();
-      for (int f = 0; f < FAM_COUNT; ++f) { p.flop[f] = 0; p.launches[f] = 0; }
+      for (int f = 0; f < FAM_COUNT; ++f) { p.flop[f] = 0; p.bytes[f] = 0; p.launches[f] = 0; }
       p.enabled = on != 0;
     }
+    return 0;
+  });
+}
+int bayens_profile_bytes(bayens_ctx* c, int family, double* bytes) {
+  return guarded(c, [&]() {
+    if (family < 0 || family >= FAM_COUNT || !bytes) return fail(c, BAYENS_E_ARG, "unknown kernel family");
+    std::vector<HipPrims*> all = c->gprims;
+    all.push_back(c->prims);
+    double b = 0;
+    for (HipPrims* hp : all) b += hp->prof.bytes[family];
+    *bytes = b;
     return 0;
   });
 }

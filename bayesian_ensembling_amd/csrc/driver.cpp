@@ -99,7 +99,7 @@ static int potrf_block_width() {
 
 void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows) {
   const int NB = potrf_block_width();
-  if (n <= NB || NB > PANEL_MAX) {
+  if (n <= NB) {
     potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
     return;
   }

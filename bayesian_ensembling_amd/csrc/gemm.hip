@@ -371,11 +371,21 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
   }
 }
 
+// elements of an m x n output that are computed: all, or the lower trapezoid i >= j (m >= n; n^2/2 for m = n)
+double out_elems(int m, int n, int flags) {
+  if (!(flags & GEMM_TRI_OUT) || m < n) return (double)m * n;
+  return (double)m * n - 0.5 * (double)n * n;
+}
 double algorithmic_flop(int nb, int m, int n, int k, int flags) {
-  double f = 2.0 * m * (double)n * k * nb;
-  if ((flags & GEMM_TRI_OUT) && (flags & GEMM_KTRIM_TN_LOWER)) return f / 6.0;
-  if (flags & GEMM_TRI_OUT) return f / 2.0;
-  return f;
+  if ((flags & GEMM_TRI_OUT) && (flags & GEMM_KTRIM_TN_LOWER)) return 2.0 * m * (double)n * k * nb / 6.0;
+  return 2.0 * k * out_elems(m, n, flags) * nb;
+}
+// operand bytes a launch has to move at least once: A and B read (half each when both are lower triangles),
+// the computed part of C written, and read when beta != 0
+double algorithmic_bytes(int nb, int m, int n, int k, int flags, double beta) {
+  const double tri = (flags & GEMM_KTRIM_TN_LOWER) ? 0.5 : 1.0;
+  const double c = out_elems(m, n, flags);
+  return 8.0 * nb * (tri * ((double)m * k + (double)n * k) + c * (beta != 0.0 ? 2.0 : 1.0));
 }
 
 }  // namespace
@@ -427,6 +437,8 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
     prof.events.push_back(KernelProfile::Ev{e0, e1, fam});
     const double f = algorithmic_flop(nb, m, n, k, flags);
     prof.flop[FAM_ALL] += f; prof.flop[fam] += f;
+    const double by = algorithmic_bytes(nb, m, n, k, flags, beta);
+    prof.bytes[FAM_ALL] += by; prof.bytes[fam] += by;
     prof.launches[FAM_ALL] += 1; prof.launches[fam] += 1;
   }
 }
@@ -459,6 +471,8 @@ void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long i
     prof.events.push_back(KernelProfile::Ev{e0, e1, FAM_TRSM_PANEL});
     const double f = (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
     prof.flop[FAM_ALL] += f; prof.flop[FAM_TRSM_PANEL] += f;
+    const double by = 8.0 * nb * (2.0 * m * (double)n + 0.5 * (double)n * n);
+    prof.bytes[FAM_ALL] += by; prof.bytes[FAM_TRSM_PANEL] += by;
     prof.launches[FAM_ALL] += 1; prof.launches[FAM_TRSM_PANEL] += 1;
   }
 }

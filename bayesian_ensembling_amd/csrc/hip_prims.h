@@ -31,6 +31,7 @@ struct KernelProfile {
   std::vector<Ev> events;   // per launch
   std::vector<hipEvent_t> pool;
   double flop[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+  double bytes[FAM_COUNT] = {0, 0, 0, 0, 0, 0};   // algorithmic operand bytes (GEMM families; panel solves: B in+out, L)
   long launches[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
   std::vector<std::pair<std::string, hipEvent_t>> marks;   // stage profile of the driver
 };

@@ -181,7 +181,8 @@ def main():
         group_tflops = p_all["flop"] / (p_all["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "bayens::gemm_f64_mfma<false, true>", "achieved": round(gemm_tflops, 3),
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / F64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "launches_per_fit_batch": p["launches"],
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
+                "launches_per_fit_batch": p["launches"],
                 "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
                 "kernel_ms_per_fit_batch": round(p["ms"], 3),
                 "gemm_group": {"kernels": "gemm_f64_mfma<*>, gemm_panel64, trsm_panel_kernel",

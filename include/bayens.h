@@ -58,6 +58,9 @@ int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
  * 5 = trsm_panel_kernel.  Returns summed device ms, algorithmic flop, launches. */
 int bayens_profile_enable(bayens_ctx* ctx, int on);
 int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
+/* algorithmic operand bytes of the same launches (operands read once, computed part of C written, and read when
+ * accumulating): the figure HBM traffic from the PMC counters is compared with */
+int bayens_profile_bytes(bayens_ctx* ctx, int family, double* bytes);
 
 /* text table "stage  ms" of the fit stages recorded (HIP events) while profiling was enabled, one stream */
 int bayens_profile_stages(bayens_ctx* ctx, char* buf, int buf_len);

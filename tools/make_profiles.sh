@@ -1,0 +1,23 @@
+#!/bin/bash
+# Regenerates the measurement artifacts of one round on the GPU box (run through gpurun from the repo root):
+#   tools/make_profiles.sh r01      -> gpurun_out/<tag>_*  (copy the ones to keep into profiles/)
+# Separate rocprofv3 passes: kernel trace, then one PMC counter per pass (never combined with other trace domains).
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+BAYENS_PRINT_STAGES=1 timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_stage_profile.txt || exit 1
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pf.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pw.log 2>&1 || exit 4
+cd $R
+KT=$(find $OUT/${TAG}_kt -name "*.db" | head -1); PF=$(find $OUT/${TAG}_pf -name "*.db" | head -1); PW=$(find $OUT/${TAG}_pw -name "*.db" | head -1)
+python3 tools/rocpd_stats.py $KT $OUT/${TAG}_kernel_stats_final.txt > /dev/null
+python3 tools/rocpd_pmc.py $PF FETCH_SIZE $OUT/${TAG}_pmc_fetch_size.txt > /dev/null
+python3 tools/rocpd_pmc.py $PW WRITE_SIZE $OUT/${TAG}_pmc_write_size.txt > /dev/null
+python3 tools/pmc_traffic.py $PF $PW $OUT/${TAG}_pmc_traffic.json > /dev/null
+rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw
+head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
