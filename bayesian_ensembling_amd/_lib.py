@@ -221,7 +221,7 @@ class Context:
 
     # -- hot path (host arrays in, host arrays out) --------------------------------------------------
     def gp_fit_batch(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6,
-                     want_chol=True):
+                     want_chol=True, want_loss=False):
         X = _f64(X)
         B, N, R = X.shape
         y_mean = _f64(y_mean).reshape(B, N)
@@ -233,14 +233,16 @@ class Context:
         hyp = np.empty((B, 2))
         basis = np.empty((B, 2, N)) if want_chol else None
         info = np.zeros(B, dtype=np.int32)
+        loss = np.empty((B, (int(n_iters) + 24) // 25)) if want_loss and n_iters > 0 else None
         rc = self.lib.bayens_gp_fit_batch(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
-                                          _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
+                                          _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
         if rc != 0:
             err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
             err.info = info
             raise err
-        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis}
+        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis,
+                "loss": loss}
 
     def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
                          kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None):

@@ -167,7 +167,9 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
       try {
         BAYENS_HIP(hipSetDevice(c->device));
         FitWorkspace w = ws_view(c, b0, b1 - b0);
-        gp_fit(*c->gprims[g], w, fp, dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
+        FitParams fg = fp;
+        if (fg.loss_trace) fg.loss_trace += (size_t)b0 * fg.loss_stride;
+        gp_fit(*c->gprims[g], w, fg, dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
                dmu + (size_t)b0 * N, dcov + (size_t)b0 * N * N, dchol ? dchol + (size_t)b0 * N * N : nullptr,
                dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr,
                dbasis ? dbasis + (size_t)b0 * 2 * N : nullptr);
@@ -418,7 +420,6 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
-    if (loss_trace) return fail(c, BAYENS_E_ARG, "gp_fit_batch: loss_trace is not produced by this version (pass NULL)");
     const int Np = pad_to_leaf(N);
     ensure_ws(c, B, Np);
     Stage st(c, loc);
@@ -432,6 +433,8 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     double* dhyp = st.out(hyp, (size_t)B * 2);
     double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
     FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+    fp.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+    fp.loss_trace = fp.loss_stride > 0 ? st.out(loss_trace, (size_t)B * fp.loss_stride) : nullptr;
     fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
     std::vector<int> hinfo(B, 0);
     BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));

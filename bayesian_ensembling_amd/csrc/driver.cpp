@@ -146,6 +146,31 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
   if (basis) P.basis_rows_get(nb, N, Np, rows, basis);
 }
 
+// -ELBO (the training loss the reference samples every 25 iterations, models.py:211-215) at the hypers whose factor
+// L is in ws.Lb, with the (m, C) of the last natural-gradient step: GPflow VGP.elbo with the heteroskedastic
+// Gaussian expectations of models.py:142-149,
+//   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + KL,
+//   KL = ( |m|^2 - N - log det S + tr S ) / 2,   S = C^-T C^-1.
+// (L S L^T)_tt is the squared norm of row t of L C^-T (one full solve), tr S = ||C^-1||_F^2 (the triangular
+// inverse).  Scratch: T1, T2, avec, uvec, muvec.  The reference evaluates the loss after the Adam step, i.e. at the
+// NEXT iteration's hypers: the caller invokes this right after that iteration's (or the prediction's) Cholesky of
+// K, before Lam/C are advanced, so no extra kernel matrix or factorisation is needed.
+static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot) {
+  const int nb = ws.nb, Np = ws.Np, N = fp.N;
+  const long is = ws.inv_stride();
+  P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                      // a = L m - y
+  P.copy(nb, Np, ws.Lb, ws.T1);
+  trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);                  // L C^-T
+  P.row_sqsum(nb, Np, ws.T1, ws.uvec);
+  P.identity(nb, Np, ws.T2);
+  trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);            // C^-1 (lower)
+  double* logdetC = ws.muvec;
+  double* trS = ws.muvec + nb;
+  P.logdet(nb, N, ws.Cb, logdetC);
+  P.dot_all(nb, Np, ws.T2, ws.T2, trS);
+  P.elbo_combine(nb, N, Np, ws.avec, ws.uvec, ws.nu, ws.mvec, ws.Cb, logdetC, trS, fp.loss_trace, fp.loss_stride, slot);
+}
+
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
             const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp,
             double* basis) {
@@ -164,6 +189,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
     P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
     P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY);
     P.mark("Lam update");
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
@@ -201,6 +227,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
   P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+  if (fp.loss_trace && fp.n_iters > 0 && (fp.n_iters - 1) % LOSS_EVERY == 0)
+    neg_elbo(P, ws, fp, (fp.n_iters - 1) / LOSS_EVERY);
   // With K0 = L L^T - J I (J the jitter):  A^T = K0 L^-T = L - J L^-T  and  K0 - A^T A = J I - J^2 L^-T L^-1,
   // so the full solve K0 L^-T and the rank-N update A^T A shrink to the triangular inverse (a lower-rhs solve on I,
   // N^3/3) and the lower x lower product L^-T L^-1 (N^3/3):  cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T C^-T)(A^T C^-T)^T.

@@ -49,7 +49,11 @@ void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv
 struct FitParams {
   int N, R, kernel, n_iters;
   double gamma, lr, jitter;
+  // optional: -ELBO after the iterations it = 0, 25, 50, ... (models.py:211-215), device [nb][loss_stride]
+  double* loss_trace = nullptr;
+  int loss_stride = 0;
 };
+constexpr int LOSS_EVERY = 25;   // models.py:211
 
 // Runs the whole fit on resident inputs.  X [nb][N][R], y_in/nu_in [nb][N] (compact, device).
 // Outputs (device, compact): mu [nb][N], cov [nb][N][N], chol (nullable), logdet (nullable, [nb]),

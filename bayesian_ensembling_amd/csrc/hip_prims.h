@@ -83,6 +83,9 @@ struct HipPrims : Prims {
   void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
                  double lr) override;
   void gemv_n(int nb, int n, Mat A, const double* x, double* y) override;
+  void row_sqsum(int nb, int n, Mat A, double* out) override;
+  void elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu, const double* mvec,
+                    Mat C, const double* logdetC, const double* trS, double* trace, int stride, int slot) override;
   void identity(int nb, int n, Mat A) override;
   void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) override;
   void diag_init(int nb, int n, const double* nu, double add, Mat dst) override;

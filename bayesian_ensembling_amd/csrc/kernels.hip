@@ -732,6 +732,45 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const doub
   if (lane == 0) out[(long)b * n + i] = s - (sub ? sub[(long)b * n + i] : 0.0);
 }
 
+// out_i = sum_k A_ik^2; one wave per row
+__global__ __launch_bounds__(256) void row_sqsum_kernel(int n, Mat A, double* out) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const double* a = A.p + b * A.stride + (long)i * A.ld;
+  double s = 0.0;
+  for (int k = lane; k < n; k += 64) s += a[k] * a[k];
+  s = wave_sum(s);
+  if (lane == 0) out[(long)b * n + i] = s;
+}
+
+// prims.h elbo_combine: one workgroup per member, fixed-order reduction
+__global__ __launch_bounds__(256) void elbo_combine_kernel(int N, int Np, const double* a, const double* f,
+                                                           const double* nu, const double* mvec, Mat C,
+                                                           const double* logdetC, const double* trS, double* trace,
+                                                           int stride, int slot) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long o = (long)b * Np;
+  double s = 0.0;
+  for (int t = tid; t < N; t += 256) {
+    const double v = nu[o + t], at = a[o + t], mt = mvec[o + t];
+    s += 0.5 * 1.8378770664093453 + 0.5 * log(v) + 0.5 * (at * at + f[o + t]) / v + 0.5 * mt * mt;
+  }
+  for (int t = N + tid; t < Np; t += 256) {       // the padded block of C^-1 is diag(1 / C_tt): not part of tr S
+    const double ctt = C.p[b * C.stride + (long)t * C.ld + t];
+    s -= 0.5 / (ctt * ctt);
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const double data_and_mm = (red[0] + red[1]) + (red[2] + red[3]);
+    trace[(long)b * stride + slot] = data_and_mm + 0.5 * (-(double)N + 2.0 * logdetC[b] + trS[b]);
+  }
+}
+
 // the 64-row block appended to a right-hand side (prims.h aug_set / aug_get)
 __global__ void aug_set_kernel(int n, Mat rows, const double* vec, int zero_rows) {
   const int b = blockIdx.y;
@@ -1366,6 +1405,17 @@ void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kern
 }
 void HipPrims::gemv_n(int nb, int n, Mat A, const double* x, double* y) {
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, x, (const double*)nullptr, y, 0);
+  LAUNCH_CHECK();
+}
+void HipPrims::row_sqsum(int nb, int n, Mat A, double* out) {
+  hipLaunchKernelGGL(row_sqsum_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, out);
+  LAUNCH_CHECK();
+}
+void HipPrims::elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu,
+                            const double* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
+                            int stride, int slot) {
+  hipLaunchKernelGGL(elbo_combine_kernel, dim3(nb), dim3(256), 0, stream, N, Np, a, f, nu, mvec, C, logdetC, trS,
+                     trace, stride, slot);
   LAUNCH_CHECK();
 }
 void HipPrims::identity(int nb, int n, Mat A) {

@@ -113,6 +113,17 @@ struct Prims {
   // the unconstrained hypers.  ustate per member: [u_var, u_ls, m_var, m_ls, v_var, v_ls, t, pad]
   virtual void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt,
                          double* ustate, double lr) = 0;
+  // out_i = sum_k A_ik^2 (all n columns)
+  virtual void row_sqsum(int nb, int n, Mat A, double* out) = 0;
+  // -ELBO of the whitened VGP with the heteroskedastic Gaussian likelihood from its pieces (models.py:142-149,
+  // GPflow VGP.elbo):  sum_{t<N} [ log(2 pi)/2 + log(nu_t)/2 + (a_t^2 + f_t) / (2 nu_t) ]
+  //                    + ( sum_{t<N} m_t^2 - N + 2 logdetC + (trS - sum_{t>=N} C_tt^-2) ) / 2
+  // a = L m - y, f_t = (L S L^T)_tt, logdetC[b] = sum_{i<N} log C_ii, trS[b] = ||C^-1||_F^2 over the padded
+  // matrix (the padded block of C is diagonal - Lam's padding is a multiple of I, not I - and is subtracted).
+  // Written to trace[b * stride + slot].
+  virtual void elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu,
+                            const double* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
+                            int stride, int slot) = 0;
   virtual void gemv_n(int nb, int n, Mat A, const double* x, double* y) = 0;    // y = A x
   virtual void identity(int nb, int n, Mat A) = 0;                              // A = I
   // At = L - jitter * Linv^T  (= K0 L^-T, because K0 = L L^T - jitter I); L, Linv lower triangular

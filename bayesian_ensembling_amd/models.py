@@ -54,7 +54,9 @@ class GPDTW1D:
     def fit_collection(self, process_models, n_optim_nits: int = 500, compile_objective: bool = False,
                        progress_bar: bool = True):
         """All members at once: one bayens_gp_fit_batch call per distinct realisation count."""
-        del compile_objective, progress_bar   # accepted for signature compatibility (tf.function / tqdm knobs)
+        del compile_objective   # accepted for signature compatibility (a tf.function knob)
+        # progress_bar: the reference shows the loss sampled every 25 iterations in a tqdm bar (models.py:211-215);
+        # here the same samples are kept on each Distribution as `.losses` (and skipped when progress_bar=False)
         ctx = _lib.default_context()
         pro = [self._prologue(pm) for pm in process_models]
         groups = {}
@@ -68,13 +70,15 @@ class GPDTW1D:
             else:
                 y = np.stack([pro[i][1] for i in idxs])
             nu = np.stack([pro[i][2] for i in idxs])
-            out = ctx.gp_fit_batch(X, y, nu, n_optim_nits, kernel=_lib.KERNEL_IDS[self.kernel])
+            out = ctx.gp_fit_batch(X, y, nu, n_optim_nits, kernel=_lib.KERNEL_IDS[self.kernel],
+                                   want_loss=bool(progress_bar))
             for j, i in enumerate(idxs):
                 dists[i] = Distribution(mu=out["mu"][j], covariance=out["cov"][j],
                                         dim_array=_blank_array(process_models[i]),
                                         dist_type=dx.MultivariateNormalFullCovariance,
                                         _factor=(out["chol"][j], float(out["logdet"][j]), out["basis"][j]))
                 dists[i].hyperparameters = {"variance": float(out["hyp"][j, 0]), "lengthscale": float(out["hyp"][j, 1])}
+                dists[i].losses = None if out["loss"] is None else out["loss"][j].copy()
         return dists
 
     def fit(self, model, n_optim_nits: int = 500, compile_objective: bool = False, progress_bar: bool = True):

@@ -87,7 +87,10 @@ int bayens_set_groups(bayens_ctx* ctx, int n_groups);
  *   hyp [B][2] final (variance, lengthscale), info [B] 0 or 1-based failing pivot,
  *   ll_basis [B][2][N] = (L_c^-1 1, L_c^-1 mu): the two vectors a later log_prob at a constant vector needs
  *   (weights.py:98-100); they fall out of the bordered Cholesky of cov at no extra pass.
- *   loss_trace must be NULL in this version (models.py:211-215 only feeds a progress bar). */
+ *   loss_trace [B][ceil(n_iters/25)]: the training loss (-ELBO) the reference samples after the iterations
+ *   0, 25, 50, ... (models.py:211-215: evaluated after that iteration's Adam step, i.e. at the updated
+ *   hyper-parameters with the variational parameters of that iteration's natural-gradient step).  Costs one full
+ *   triangular solve and one triangular inverse per sample; pass NULL to skip it. */
 int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         const double* X, const double* y_mean, const double* y_var,
                         int kernel, int n_iters, double gamma, double lr, double jitter,

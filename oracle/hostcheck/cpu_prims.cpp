@@ -272,6 +272,26 @@ struct CpuPrims : Prims {
         y[(size_t)b * n + i] = s;
       }
   }
+  void row_sqsum(int nb, int n, Mat A, double* out) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) { double v = A.p[b * A.stride + (size_t)i * A.ld + k]; s += v * v; }
+        out[(size_t)b * n + i] = s;
+      }
+  }
+  void elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu, const double* mvec,
+                    Mat C, const double* logdetC, const double* trS, double* trace, int stride, int slot) override {
+    for (int b = 0; b < nb; ++b) {
+      double s = 0;
+      for (int t = 0; t < N; ++t) {
+        size_t o = (size_t)b * Np + t;
+        s += 0.5 * 1.8378770664093453 + 0.5 * std::log(nu[o]) + 0.5 * (a[o] * a[o] + f[o]) / nu[o] + 0.5 * mvec[o] * mvec[o];
+      }
+      for (int t = N; t < Np; ++t) { double c = C.p[b * C.stride + (size_t)t * C.ld + t]; s -= 0.5 / (c * c); }
+      trace[(size_t)b * stride + slot] = s + 0.5 * (-(double)N + 2.0 * logdetC[b] + trS[b]);
+    }
+  }
   void identity(int nb, int n, Mat A) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
@@ -371,10 +391,13 @@ extern "C" {
 
 int hostcheck_gp_fit(int B, int N, int R, const double* X, const double* y_mean, const double* y_var,
                      int kernel, int n_iters, double gamma, double lr, double jitter, double* mu,
-                     double* cov, double* chol, double* logdet, double* hyp, int* info, double* basis) {
+                     double* cov, double* chol, double* logdet, double* hyp, int* info, double* basis,
+                     double* loss_trace) {
   CpuPrims P;
   HostWs h(B, pad_to_leaf(N));
   FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+  fp.loss_trace = loss_trace;
+  fp.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
   gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp, basis);
   for (int b = 0; b < B; ++b) info[b] = h.info[b];
   return 0;

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayesian_ensembling_amd import _lib as L  # noqa: E402
 from oracle import gp_oracle as go  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Robustness sweep on the GPU: odd sizes against the oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayesian_ensembling_amd import _lib as L
 from oracle import gp_oracle as go
 ctx = L.Context(0)

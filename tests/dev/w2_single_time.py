@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayesian_ensembling_amd import _lib as L
 from bayesian_ensembling_amd.synthetic import synthetic_ensemble
 ctx = L.Context(0)
@@ -12,7 +12,7 @@ t = time.time(); w, D = ctx.w2_single(out["mu"], chol=out["chol"]); dt = time.ti
 print(f"w2_single M={M} N={N}: {dt:.2f} s wall (host-staged), {M*(M-1)//2} pairs, sum w = {w.sum():.15f}")
 print("w", np.round(w, 5))
 if M <= 4:
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import gp_oracle as go
     t = time.time(); w_ref, D_ref = go.w2_weights_single(list(out["mu"]), list(out["cov"])); print("oracle %.1f s" % (time.time() - t))
     print("relerr w %.2e  D %.2e" % (np.max(np.abs(w - w_ref) / w_ref), np.max(np.abs(D - D_ref)) / np.max(D_ref)))

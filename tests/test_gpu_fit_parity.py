@@ -127,6 +127,27 @@ def test_full_size_properties(ctx):
     assert relerr(out["mu"][0], mo) < 1e-9 and relerr(out["cov"][0], co) < 1e-9
 
 
+@pytest.mark.parametrize("M,N,T", [(2, 86, 1), (3, 70, 27), (1, 128, 51), (2, 200, 26)])
+def test_loss_trace_is_the_references_training_loss(ctx, M, N, T):
+    """loss_trace = -ELBO sampled after iterations 0, 25, 50 (models.py:211-215), and asking for it changes nothing."""
+    data, _ = go.synthetic_ensemble(M, N, R=4, seed=5)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T, want_loss=True)
+    plain = ctx.gp_fit_batch(X, y, nu, T)
+    assert plain["loss"] is None and out["loss"].shape == (M, (T + 24) // 25)
+    for k in ("mu", "cov", "chol", "logdet", "hyp"):
+        assert np.array_equal(out[k], plain[k]), k
+    with threadpool_limits(1):
+        for m in range(M):
+            ref = go.gp_fit(X[m], y[m], nu[m], T, loss_every=25)[3]
+            assert np.allclose(out["loss"][m], ref, rtol=1e-9, atol=0), (out["loss"][m], ref)
+    ctx.set_groups(2)
+    try:
+        assert np.array_equal(ctx.gp_fit_batch(X, y, nu, T, want_loss=True)["loss"], out["loss"])
+    finally:
+        ctx.set_groups(1)
+
+
 def test_member_groups_do_not_change_the_result(ctx):
     data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
     X, y, nu = member_inputs(data)

@@ -157,6 +157,14 @@ def _collection(n_models, obs_n_reals, N=24, R=3, seed=0):
 def test_weightings_api(ctx, n_models, obs_n_reals):
     mc, obs = _collection(n_models, obs_n_reals)
     mc.fit(model=es.GPDTW1D(), compile_objective=True, n_optim_nits=2, progress_bar=False)
+    assert all(m.distribution.losses is None for m in mc.models)       # no progress display, no loss samples
+    if n_models == 2 and obs_n_reals == 1:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                            # refitting warns, as in the reference
+            mc.fit(model=es.GPDTW1D(), n_optim_nits=27)                # progress_bar defaults to True (models.py:169)
+        assert all(m.distribution.losses.shape == (2,) and np.isfinite(m.distribution.losses).all() for m in mc.models)
+        mc.fit(model=es.GPDTW1D(), compile_objective=True, n_optim_nits=2, progress_bar=False)
     for weighting in [es.LogLikelihoodWeight(), es.ModelSimilarityWeight()]:
         if weighting.name == "LogLikelihoodWeight":
             weights = weighting(mc, obs, standardisation_constant=0.001)

@@ -22,10 +22,12 @@ def hc_fit(lib, X, y, nu, T, kernel=0):
     mu, cov, chol = np.zeros((B, N)), np.zeros((B, N, N)), np.zeros((B, N, N))
     ld, hyp, info = np.zeros(B), np.zeros((B, 2)), np.zeros(B, dtype=np.int32)
     basis = np.zeros((B, 2, N))
+    loss = np.full((B, max((T + 24) // 25, 1)), np.nan)
     lib.hostcheck_gp_fit(B, N, R, P(X), P(y), P(nu), kernel, T, ctypes.c_double(0.5), ctypes.c_double(0.01),
                          ctypes.c_double(1e-6), P(mu), P(cov), P(chol), P(ld), P(hyp), info.ctypes.data_as(ip),
-                         P(basis))
+                         P(basis), P(loss))
     hc_fit.basis = basis
+    hc_fit.loss = loss
     return mu, cov, chol, ld, hyp, info
 
 
@@ -45,6 +47,17 @@ def test_driver_matches_oracle(hostcheck, M, N, R, T, kernel):
         import scipy.linalg as sla
         assert relerr(hc_fit.basis[m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 1e-8
         assert relerr(hc_fit.basis[m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 1e-8
+
+
+@pytest.mark.parametrize("N,T", [(86, 1), (70, 27), (128, 51)])
+def test_loss_trace_matches_the_oracle_elbo(hostcheck, N, T):
+    """-ELBO after iterations 0, 25, 50 (models.py:211-215) against oracle neg_elbo."""
+    data, _ = go.synthetic_ensemble(1, N, R=4)
+    X, y, nu = member_inputs(data)
+    hc_fit(hostcheck, X, y, nu, T, 0)
+    ref = go.gp_fit(X[0], y[0], nu[0], T, loss_every=25)[3]
+    assert hc_fit.loss.shape[1] == len(ref) == (T + 24) // 25
+    assert np.allclose(hc_fit.loss[0], ref, rtol=1e-10, atol=0)
 
 
 def test_blocked_potrf_and_trsm(hostcheck):
