@@ -64,6 +64,7 @@ def load():
     lib.bayens_profile_enable.argtypes = [_vp, C.c_int]
     lib.bayens_set_groups.argtypes = [_vp, C.c_int]
     lib.bayens_profile_stages.argtypes = [_vp, C.c_char_p, C.c_int]
+    lib.bayens_profile_shapes.argtypes = [_vp, C.c_char_p, C.c_int]
     lib.bayens_profile_get.argtypes = [_vp, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
     lib.bayens_profile_bytes.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
@@ -210,6 +211,11 @@ class Context:
     def profile_stages(self):
         buf = C.create_string_buffer(8192)
         self._check(self.lib.bayens_profile_stages(self.h, buf, 8192))
+        return buf.value.decode()
+
+    def profile_shapes(self):
+        buf = C.create_string_buffer(65536)
+        self._check(self.lib.bayens_profile_shapes(self.h, buf, 65536))
         return buf.value.decode()
 
     def profile_get(self, family=0):

@@ -406,6 +406,36 @@ int bayens_profile_stages(bayens_ctx* c, char* buf, int buf_len) {
   });
 }
 
+int bayens_profile_shapes(bayens_ctx* c, char* buf, int buf_len) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipDeviceSynchronize());
+    struct Agg { int fam, m, n, k, flags; long calls; double ms, flop; };
+    std::vector<Agg> agg;
+    std::vector<HipPrims*> all = c->gprims;
+    all.push_back(c->prims);
+    for (HipPrims* hp : all)
+      for (auto& e : hp->prof.events) {
+        float f = 0;
+        BAYENS_HIP(hipEventElapsedTime(&f, e.a, e.b));
+        bool found = false;
+        for (auto& a : agg)
+          if (a.fam == e.fam && a.m == e.m && a.n == e.n && a.k == e.k && a.flags == e.flags) {
+            a.calls++; a.ms += f; a.flop += e.flop; found = true; break;
+          }
+        if (!found) agg.push_back(Agg{e.fam, e.m, e.n, e.k, e.flags, 1, f, e.flop});
+      }
+    std::string out = "fam     m     n     k flags calls        ms   TFLOP/s\n";
+    char line[160];
+    for (auto& a : agg) {
+      snprintf(line, sizeof line, "%3d %5d %5d %5d %5d %5ld %9.3f %9.2f\n", a.fam, a.m, a.n, a.k, a.flags, a.calls, a.ms,
+               a.flop / (a.ms * 1e-3) / 1e12);
+      out += line;
+    }
+    if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", out.c_str());
+    return 0;
+  });
+}
+
 int bayens_set_groups(bayens_ctx* c, int n_groups) {
   if (!c || n_groups < 1 || n_groups > 16) return BAYENS_E_ARG;
   c->ngroups = n_groups;

@@ -315,8 +315,29 @@ __device__ __forceinline__ void panel_mma(v4d (&acc)[4], const double (*As)[SLD]
   }
 }
 
+// the same product with the inverted diagonal block as B operand: op(M_j) is triangular, so the 4x16 sub-tiles of
+// Bs that are entirely zero are skipped (40 of 64 MFMAs remain).  UPPER: Bs[k][col] != 0 only for k <= col.
+template <bool UPPER>
+__device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const double (*As)[SLD], const double (*Bs)[SLD], int wave,
+                                              int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const double a = As[wave * 16 + lr][kk * 4 + lk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = UPPER ? (kk < 4 * j + 4) : (kk >= 4 * j);
+      if (live) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j], 0, 0, 0);
+    }
+  }
+}
+
 template <bool RLN>
 __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
+  // As: each wave's own 16 rows, only used to turn an accumulator (C layout) into an A operand; Bs: the staged
+  // L block or inverted diagonal block, shared by the four waves.  Finished blocks X_k stay in registers as
+  // (negated) A fragments, 16 doubles per lane and block, so a product only stages its L block; the next block's
+  // global load is issued before the current product's MFMAs.
   __shared__ __attribute__((aligned(16))) double As[SK][SLD];
   __shared__ __attribute__((aligned(16))) double Bs[SK][SLD];
   const int tiles_m = g.m / SK;
@@ -327,47 +348,77 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
   const double* L = g.L + batch * g.sL;
   const double* inv = g.inv + batch * g.sInv;
   double* B = g.B + batch * g.sB + (long)row0 * g.ldb;
-  v2d ra[8], rb[8];
+  const int nsub = g.nsub;
 
-  for (int s = 0; s < g.nsub; ++s) {
-    const int j = RLN ? g.nsub - 1 - s : s;
-    v4d acc[4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr];
-    // acc -= X_k op(L): RLT k < j with B-operand[kk][jj] = L[64j+jj][64k+kk]; RLN k > j with L[64k+kk][64j+jj]
-    for (int t = 0; t < s; ++t) {
-      const int k = RLN ? g.nsub - 1 - t : t;
-      stage64_load<false>(B + 64 * k, g.ldb, tid, ra);
-      if (RLN) stage64_load<false>(L + (long)(64 * k) * g.ldl + 64 * j, g.ldl, tid, rb);
-      else stage64_load<true>(L + (long)(64 * j) * g.ldl + 64 * k, g.ldl, tid, rb);
-      __syncthreads();                       // previous product finished with As / Bs
-      stage64_store<false>(As, tid, ra);
-      stage64_store<!RLN>(Bs, tid, rb);
-      __syncthreads();
-      panel_mma(acc, As, Bs, wave, lane, -1.0);
+  // tile (s, t): t < s the L block coupling finished block t to block s (in solve order), t == s the inverse
+  auto tile_load = [&](int s, int t, v2d (&reg)[8]) {
+    const int j = RLN ? nsub - 1 - s : s;
+    if (t == s) {
+      stage64_load<false>(inv + (long)j * 4096, 64, tid, reg);
+    } else {
+      const int k = RLN ? nsub - 1 - t : t;
+      // RLT: B-operand[kk][jj] = L[64j+jj][64k+kk] (transposed on the way into Bs); RLN: L[64k+kk][64j+jj]
+      if (RLN) stage64_load<false>(L + (long)(64 * k) * g.ldl + 64 * j, g.ldl, tid, reg);
+      else stage64_load<false>(L + (long)(64 * j) * g.ldl + 64 * k, g.ldl, tid, reg);
     }
-    // X_j = acc op(M_j): the accumulator goes to the wave's own rows of As
-    stage64_load<!RLN>(inv + (long)j * 4096, 64, tid, rb);
-    __syncthreads();
+  };
+
+  double xf[3][16];   // -X_k as A fragments: xf[t][kk] = -X_t[wave rows lr][4 kk + lk]
+  v2d rb[8];
+  tile_load(0, 0, rb);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+  for (int s = 0; s < 4; ++s) {
+    if (s < nsub) {
+      const int j = RLN ? nsub - 1 - s : s;
+      v4d acc[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = acc[jt][r];
-    stage64_store<!RLN>(Bs, tid, rb);
-    __syncthreads();
-    v4d x[4];
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0.0, 0.0, 0.0, 0.0};
-    panel_mma(x, As, Bs, wave, lane, 1.0);
+        for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int t = 0; t <= s; ++t) {
+        __syncthreads();                       // the previous product is done with Bs
+        if (t == s) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr] = x[jt][r];
-    // the next column block stages X_j through other threads of this workgroup: make the stores visible
-    __threadfence_block();
-    __syncthreads();
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = acc[jt][r];
+        }
+        stage64_store<!RLN>(Bs, tid, rb);
+        __syncthreads();
+        // next tile's global load flies while this product runs
+        if (t < s) tile_load(s, t + 1, rb);
+        else if (s + 1 < nsub) tile_load(s + 1, 0, rb);
+        if (t < s) {
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+              acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[t][kk], Bs[kk * 4 + lk][jt * 16 + lr], acc[jt], 0, 0, 0);
+        } else {
+          // X_j = acc op(M_j); RLT: Bs[k][col] = M_j[col][k] (upper triangular image); RLN: Bs[k][col] = M_j[k][col]
+          v4d x[4];
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0.0, 0.0, 0.0, 0.0};
+          panel_mma_tri<!RLN>(x, As, Bs, wave, lane);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr] = x[jt][r];
+          if (s < 3 && s + 1 < nsub) {
+            // the wave's own rows of As: finished block in, A fragments out (same wave wrote and reads)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = -x[jt][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) xf[s][kk] = As[wave * 16 + lr][kk * 4 + lk];
+          }
+        }
+      }
+    }
   }
 }
 
@@ -434,8 +485,8 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   BAYENS_HIP(hipGetLastError());
   if (prof.enabled) {
     BAYENS_HIP(hipEventRecord(e1, stream));
-    prof.events.push_back(KernelProfile::Ev{e0, e1, fam});
     const double f = algorithmic_flop(nb, m, n, k, flags);
+    prof.events.push_back(KernelProfile::Ev{e0, e1, fam, m, n, k, flags | (beta != 0.0 ? 256 : 0), f});
     prof.flop[FAM_ALL] += f; prof.flop[fam] += f;
     const double by = algorithmic_bytes(nb, m, n, k, flags, beta);
     prof.bytes[FAM_ALL] += by; prof.bytes[fam] += by;
@@ -468,8 +519,8 @@ void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long i
   BAYENS_HIP(hipGetLastError());
   if (prof.enabled) {
     BAYENS_HIP(hipEventRecord(e1, stream));
-    prof.events.push_back(KernelProfile::Ev{e0, e1, FAM_TRSM_PANEL});
     const double f = (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
+    prof.events.push_back(KernelProfile::Ev{e0, e1, FAM_TRSM_PANEL, m, n, n, mode, f});
     prof.flop[FAM_ALL] += f; prof.flop[FAM_TRSM_PANEL] += f;
     const double by = 8.0 * nb * (2.0 * m * (double)n + 0.5 * (double)n * n);
     prof.bytes[FAM_ALL] += by; prof.bytes[FAM_TRSM_PANEL] += by;

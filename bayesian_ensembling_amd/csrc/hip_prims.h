@@ -27,7 +27,7 @@ enum { FAM_ALL = 0, FAM_GEMM_NT = 1, FAM_GEMM_NN = 2, FAM_GEMM_TN = 3, FAM_PANEL
 
 struct KernelProfile {
   bool enabled = false;
-  struct Ev { hipEvent_t a, b; int fam; };
+  struct Ev { hipEvent_t a, b; int fam; int m, n, k, flags; double flop; };
   std::vector<Ev> events;   // per launch
   std::vector<hipEvent_t> pool;
   double flop[FAM_COUNT] = {0, 0, 0, 0, 0, 0};

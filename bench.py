@@ -165,6 +165,8 @@ def main():
         p = ctx.profile_get(1)            # the dominant kernel: gemm_f64_mfma<false,true> (A row-major, B^T)
         p_all = ctx.profile_get(0)
         stages = ctx.profile_stages()
+        if os.environ.get("BAYENS_PRINT_SHAPES"):
+            print(ctx.profile_shapes(), file=sys.stderr, flush=True)
         ctx.profile_enable(False)
         if os.environ.get("BAYENS_PRINT_STAGES"):
             print(stages, file=sys.stderr, flush=True)

@@ -62,6 +62,9 @@ int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, lo
  * accumulating): the figure HBM traffic from the PMC counters is compared with */
 int bayens_profile_bytes(bayens_ctx* ctx, int family, double* bytes);
 
+/* text table of the profiled GEMM-group launches aggregated by (family, m, n, k, flags): calls, ms, TFLOP/s.
+ * flags: the GEMM_* bits, +256 when the launch accumulates into C; for family 5 the solve mode (0 RLT, 1 RLN). */
+int bayens_profile_shapes(bayens_ctx* ctx, char* buf, int buf_len);
 /* text table "stage  ms" of the fit stages recorded (HIP events) while profiling was enabled, one stream */
 int bayens_profile_stages(bayens_ctx* ctx, char* buf, int buf_len);
 
