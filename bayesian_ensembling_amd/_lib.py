@@ -69,6 +69,7 @@ def load():
     lib.bayens_profile_bytes.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -227,20 +228,26 @@ class Context:
 
     # -- hot path (host arrays in, host arrays out) --------------------------------------------------
     def gp_fit_batch(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6,
-                     want_chol=True, want_loss=False):
-        X = _f64(X)
+                     want_chol=True, want_loss=False, dtype=np.float64):
+        """dtype float64 (the reference precision) or float32 (bayens_gp_fit_batch_f32: fp32 storage and products;
+        mu / cov / chol / basis come back as float32, logdet / hyp / loss stay float64)."""
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("dtype must be float64 or float32")
+        fn = self.lib.bayens_gp_fit_batch if dt == np.float64 else self.lib.bayens_gp_fit_batch_f32
+        X = np.ascontiguousarray(X, dtype=dt)
         B, N, R = X.shape
-        y_mean = _f64(y_mean).reshape(B, N)
-        y_var = _f64(y_var).reshape(B, N)
-        mu = np.empty((B, N))
-        cov = np.empty((B, N, N))
-        chol = np.empty((B, N, N)) if want_chol else None
+        y_mean = np.ascontiguousarray(y_mean, dtype=dt).reshape(B, N)
+        y_var = np.ascontiguousarray(y_var, dtype=dt).reshape(B, N)
+        mu = np.empty((B, N), dtype=dt)
+        cov = np.empty((B, N, N), dtype=dt)
+        chol = np.empty((B, N, N), dtype=dt) if want_chol else None
         logdet = np.empty(B) if want_chol else None
         hyp = np.empty((B, 2))
-        basis = np.empty((B, 2, N)) if want_chol else None
+        basis = np.empty((B, 2, N), dtype=dt) if want_chol else None
         info = np.zeros(B, dtype=np.int32)
         loss = np.empty((B, (int(n_iters) + 24) // 25)) if want_loss and n_iters > 0 else None
-        rc = self.lib.bayens_gp_fit_batch(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+        rc = fn(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
                                           _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
         if rc != 0:
@@ -251,9 +258,11 @@ class Context:
                 "loss": loss}
 
     def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
-                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None):
+                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, f32=False):
+        """Device-resident buffers; f32=True: X, y_mean, y_var, mu, cov, chol, basis are float32 buffers."""
         info = np.zeros(B, dtype=np.int32)
-        rc = self.lib.bayens_gp_fit_batch(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+        fn = self.lib.bayens_gp_fit_batch_f32 if f32 else self.lib.bayens_gp_fit_batch
+        rc = fn(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
                                           _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
         self._check(rc)

@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbayens.so")
 SOURCES = ["gemm.hip", "kernels.hip", "dba.hip", "capi.hip", "driver.cpp"]
+# the fp32 instance of the fit: the same sources compiled a second time with real = float (namespace bayens_f32)
+SOURCES_F32 = ["gemm.hip", "kernels.hip", "driver.cpp", "fit_f32.hip"]
 ARCH = "gfx950"
 
 
@@ -27,10 +29,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
-    for src in SOURCES:
-        obj = os.path.join(bdir, src + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+    for src, f32 in [(f, False) for f in SOURCES] + [(f, True) for f in SOURCES_F32]:
+        obj = os.path.join(bdir, src + (".f32.o" if f32 else ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + \
+              (["-DBAYENS_F32"] if f32 else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

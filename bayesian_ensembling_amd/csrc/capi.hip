@@ -11,6 +11,8 @@
 
 #include "../../include/bayens.h"
 #include "driver.h"
+#include "fit_f32.h"
+#include "fit_ws.h"
 #include "hip_prims.h"
 
 using namespace bayens;
@@ -58,8 +60,8 @@ struct bayens_ctx {
   std::string err;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   // fit workspace (grown on demand)
-  FitWorkspace ws;
-  std::vector<void*> ws_allocs;
+  DeviceWs dws;
+  void* f32 = nullptr;             // fp32 instance of the fit (fit_f32.hip), created on first use
   // member groups: the batch of a fit is split over `gstreams` HIP streams (one host thread each) so that the
   // low-parallelism steps of one group (64x64 diagonal blocks, narrow panels) overlap the big GEMMs of the others
   std::vector<hipStream_t> gstreams;
@@ -102,49 +104,9 @@ int guarded(bayens_ctx* c, F&& f) {
   }
 }
 
-void free_ws(bayens_ctx* c) {
-  for (void* p : c->ws_allocs) (void)hipFree(p);
-  c->ws_allocs.clear();
-  c->ws = FitWorkspace();
-}
-
-void ensure_ws(bayens_ctx* c, int nb, int Np) {
-  if (c->ws.nb >= nb && c->ws.Np == Np) { return; }
-  free_ws(c);
-  auto dalloc = [&](size_t bytes) {
-    void* p = nullptr;
-    BAYENS_HIP(hipMalloc(&p, bytes));
-    c->ws_allocs.push_back(p);
-    return p;
-  };
-  FitWorkspace& w = c->ws;
-  w.nb = nb; w.Np = Np;
-  const size_t msz = (size_t)nb * Np * Np * sizeof(double);
-  auto mat = [&]() { return Mat{(double*)dalloc(msz), Np, (long)Np * Np}; };
-  w.K0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T2 = mat();
-  w.T1 = Mat{(double*)dalloc((size_t)nb * (Np + LEAF) * Np * sizeof(double)), Np, (long)(Np + LEAF) * Np};
-  const size_t isz = (size_t)nb * Np * LEAF * sizeof(double);
-  w.invL = (double*)dalloc(isz); w.invC = (double*)dalloc(isz);
-  const size_t vsz = (size_t)nb * Np * sizeof(double);
-  w.theta1 = (double*)dalloc(vsz); w.mvec = (double*)dalloc(vsz); w.avec = (double*)dalloc(vsz);
-  w.y = (double*)dalloc(vsz); w.nu = (double*)dalloc(vsz); w.muvec = (double*)dalloc(vsz);
-  w.uvec = (double*)dalloc(vsz);
-  w.ustate = (double*)dalloc((size_t)nb * 8 * sizeof(double));
-  w.info = (int*)dalloc((size_t)nb * sizeof(int));
-}
-
-// a workspace view for members [b0, b0 + nb) of the allocated batch
-FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) {
-  FitWorkspace v = c->ws;
-  v.nb = nb;
-  for (Mat* m : {&v.K0, &v.Lb, &v.Lam, &v.Cb, &v.T1, &v.T2}) m->p += (long)b0 * m->stride;
-  const long is = v.inv_stride();
-  v.invL += b0 * is; v.invC += b0 * is;
-  for (double** p : {&v.theta1, &v.mvec, &v.avec, &v.y, &v.nu, &v.muvec, &v.uvec}) *p += (long)b0 * v.Np;
-  v.ustate += (long)b0 * 8;
-  v.info += b0;
-  return v;
-}
+void free_ws(bayens_ctx* c) { c->dws.release(); }
+void ensure_ws(bayens_ctx* c, int nb, int Np) { c->dws.ensure(nb, Np); }
+FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) { return c->dws.view(b0, nb); }
 
 // Runs the fit of B resident members split into groups, one HIP stream + host thread per group.
 void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
@@ -272,6 +234,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && c->rccl.CommDestroy) c->rccl.CommDestroy(c->comm);
   free_ws(c);
+  if (c->f32) bayens_f32_destroy(c->f32);
   if (c->sscratch) (void)hipFree(c->sscratch);
   for (auto* p : c->gprims) delete p;
   for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -467,11 +430,48 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     fp.loss_trace = fp.loss_stride > 0 ? st.out(loss_trace, (size_t)B * fp.loss_stride) : nullptr;
     fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
     std::vector<int> hinfo(B, 0);
-    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->dws.ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();
     int bad = 0;
     for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
     if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
+    return 0;
+  });
+}
+
+int bayens_gp_fit_batch_f32(bayens_ctx* c, int loc, int B, int N, int R, const float* X, const float* y_mean,
+                            const float* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
+                            float* mu, float* cov, float* cov_chol, double* logdet, double* hyp, double* loss_trace,
+                            int* info, float* ll_basis) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: unknown kernel id");
+    if (!c->f32) c->f32 = bayens_f32_create(c->stream);
+    Stage st(c, loc);
+    BayensF32Args a;
+    a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;
+    a.gamma = gamma; a.lr = lr; a.jitter = jitter;
+    a.X = st.in(X, (size_t)B * N * R);
+    a.y_mean = st.in(y_mean, (size_t)B * N);
+    a.y_var = st.in(y_var, (size_t)B * N);
+    a.mu = st.out(mu, (size_t)B * N);
+    a.cov = st.out(cov, (size_t)B * N * N);
+    a.chol = st.out(cov_chol, (size_t)B * N * N);
+    a.logdet = st.out(logdet, (size_t)B);
+    a.hyp = st.out(hyp, (size_t)B * 2);
+    const int ntrace = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+    a.loss_trace = ntrace > 0 ? st.out(loss_trace, (size_t)B * ntrace) : nullptr;
+    a.basis = st.out(ll_basis, (size_t)B * 2 * N);
+    std::vector<int> hinfo(B, 0);
+    a.info_host = hinfo.data();
+    std::string err;
+    const int rc = bayens_f32_fit(c->f32, a, &err);
+    if (rc != 0) return fail(c, rc > 0 ? rc : BAYENS_E_ARG, "gp_fit_batch_f32: " + err);
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch_f32: matrix not positive definite (see info[])");
     return 0;
   });
 }

@@ -5,7 +5,7 @@
 #include <cmath>
 #include <vector>
 
-namespace bayens {
+namespace BAYENS_NS {
 
 constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve takes
 
@@ -14,11 +14,11 @@ static inline int split_point(int n) {
   return (leaves / 2) * LEAF;   // >= LEAF whenever leaves >= 2
 }
 
-static inline const double* inv_at(const double* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
-static inline double* inv_at(double* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
+static inline const real* inv_at(const real* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
+static inline real* inv_at(real* inv, int leaf) { return inv + (long)leaf * LEAF * LEAF; }
 
 // X L^T = B.  L = [L11 0; L21 L22]  =>  X1 = B1 L11^-T ; B2 -= X1 L21^T ; X2 = B2 L22^-T
-void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B) {
+void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B) {
   if (m <= 0 || n <= 0) return;
   if (n <= PANEL_MAX) {   // the bottom levels of the recursion run fused: one pass over the m x n panel
     P.trsm_panel(nb, m, n, L, inv, inv_stride, B, 0);
@@ -31,7 +31,7 @@ void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv
 }
 
 // X L = B.  X2 = B2 L22^-1 ; B1 -= X2 L21 ; X1 = B1 L11^-1
-static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride,
+static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride,
                          Mat B, bool rhs_lower, int c0) {
   // B here is the column block [c0, c0+n) of the caller's right-hand side, all m rows.
   // With rhs_lower the rows < c0 of this column block are zero: start at row r0 = c0.
@@ -52,7 +52,7 @@ static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const double* in
   trsm_rln_rec(P, nb, m, n1, L, inv, inv_stride, B, rhs_lower, c0);
 }
 
-void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B,
+void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B,
               bool rhs_lower) {
   trsm_rln_rec(P, nb, m, n, L, inv, inv_stride, B, rhs_lower, 0);
 }
@@ -60,7 +60,7 @@ void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv
 // Blocked Cholesky with `extra` rows appended below the matrix (rows n .. n+extra-1 of the same buffer).  The
 // panel solves and trailing updates that factor A also carry the appended rows E to E L^-T (the bordered-matrix
 // identity), which is how L_c^-1 1 and L_c^-1 mu are obtained without a separate triangular solve.
-static void potrf_rec(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int base,
+static void potrf_rec(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int base,
                       int extra) {
   if (n == LEAF) {
     P.potrf_leaf(nb, A, inv, inv_stride, base, info);
@@ -97,7 +97,7 @@ static int potrf_block_width() {
   return nbw;
 }
 
-void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows) {
+void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows) {
   const int NB = potrf_block_width();
   if (n <= NB) {
     potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
@@ -106,7 +106,7 @@ void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* in
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int w = n - k0 < NB ? n - k0 : NB;
     const int below = n - k0 - w;
-    double* invk = inv_at(inv, k0 / LEAF);
+    real* invk = inv_at(inv, k0 / LEAF);
     potrf_rec(P, nb, w, A.sub(k0, k0), invk, inv_stride, info, k0, below == 0 ? extra_rows : 0);
     if (below == 0) break;
     const int m = below + extra_rows;
@@ -130,8 +130,8 @@ void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* in
 }
 
 // chol(cov) + logdet + the log-likelihood basis (L_c^-1 1, L_c^-1 mu), covariance (lower part valid) in `src`
-static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const double* mu_pad, double* chol,
-                              double* logdet, double* basis) {
+static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const real* mu_pad, real* chol,
+                              double* logdet, real* basis) {
   const int nb = ws.nb, Np = ws.Np;
   P.tri_copy(nb, Np, src, ws.T1);
   // bordering rows (1^T, mu^T): in the padding when the member has at least two padded rows (no extra rows to
@@ -152,7 +152,7 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
 //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + KL,
 //   KL = ( |m|^2 - N - log det S + tr S ) / 2,   S = C^-T C^-1.
 // (L S L^T)_tt is the squared norm of row t of L C^-T (one full solve), tr S = ||C^-1||_F^2 (the triangular
-// inverse).  Scratch: T1, T2, avec, uvec, muvec.  The reference evaluates the loss after the Adam step, i.e. at the
+// inverse).  Scratch: T1, T2, avec, uvec, dscratch.  The reference evaluates the loss after the Adam step, i.e. at the
 // NEXT iteration's hypers: the caller invokes this right after that iteration's (or the prediction's) Cholesky of
 // K, before Lam/C are advanced, so no extra kernel matrix or factorisation is needed.
 static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot) {
@@ -164,16 +164,16 @@ static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot) 
   P.row_sqsum(nb, Np, ws.T1, ws.uvec);
   P.identity(nb, Np, ws.T2);
   trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);            // C^-1 (lower)
-  double* logdetC = ws.muvec;
-  double* trS = ws.muvec + nb;
+  double* logdetC = ws.dscratch;
+  double* trS = ws.dscratch + nb;
   P.logdet(nb, N, ws.Cb, logdetC);
   P.dot_all(nb, Np, ws.T2, ws.T2, trS);
   P.elbo_combine(nb, N, Np, ws.avec, ws.uvec, ws.nu, ws.mvec, ws.Cb, logdetC, trS, fp.loss_trace, fp.loss_stride, slot);
 }
 
-void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
-            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp,
-            double* basis) {
+void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, const real* y_in,
+            const real* nu_in, real* mu, real* cov, real* chol, double* logdet, double* hyp,
+            real* basis) {
   const int nb = ws.nb, Np = ws.Np, N = fp.N;
   const long is = ws.inv_stride();
   P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info);
@@ -255,8 +255,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, co
   P.mark("end");
 }
 
-void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
-                double* basis) {
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* chol, double* logdet,
+                real* basis) {
   factor_with_basis(P, ws, N, ws.T2, mu_pad, chol, logdet, basis);
 }
 
@@ -303,4 +303,4 @@ double fit_flops(int N, int R, int n_iters) {
   return n_iters * (13.0 / 3.0 * n3 + n2r) + (3.0 * n3 + n2r) + n3 / 3.0;
 }
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

@@ -11,7 +11,7 @@
 #pragma once
 #include "prims.h"
 
-namespace bayens {
+namespace BAYENS_NS {
 
 inline int pad_to_leaf(int n) { return ((n + LEAF - 1) / LEAF) * LEAF; }
 
@@ -19,16 +19,17 @@ inline int pad_to_leaf(int n) { return ((n + LEAF - 1) / LEAF) * LEAF; }
 struct FitWorkspace {
   int nb = 0, Np = 0;
   Mat K0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each; T1 carries LEAF extra rows ([nb][Np+64][Np])
-  double* invL = nullptr;          // [nb][Np/64][64][64]
-  double* invC = nullptr;
-  double* theta1 = nullptr;        // [nb][Np]
-  double* mvec = nullptr;
-  double* avec = nullptr;
-  double* y = nullptr;             // padded y_mean
-  double* nu = nullptr;            // padded y_var (1 in the padded part)
-  double* muvec = nullptr;
-  double* uvec = nullptr;          // L^T D (L m - y)
+  real* invL = nullptr;          // [nb][Np/64][64][64]
+  real* invC = nullptr;
+  real* theta1 = nullptr;        // [nb][Np]
+  real* mvec = nullptr;
+  real* avec = nullptr;
+  real* y = nullptr;             // padded y_mean
+  real* nu = nullptr;            // padded y_var (1 in the padded part)
+  real* muvec = nullptr;
+  real* uvec = nullptr;          // L^T D (L m - y)
   double* ustate = nullptr;        // [nb][8]
+  double* dscratch = nullptr;      // [nb][4] double scalars (log-determinant / trace pieces of the loss)
   int* info = nullptr;             // [nb]
   long inv_stride() const { return (long)Np * LEAF; }
 };
@@ -37,13 +38,13 @@ struct FitWorkspace {
 // ([leaf][64][64] per member, leaf index relative to A's first row).  A's strictly-upper 64-blocks are
 // never touched (callers keep them zero).
 // extra_rows (0 or a multiple of 64) rows stored directly below A in the same buffer are carried to E L^-T.
-void potrf(Prims& P, int nb, int n, Mat A, double* inv, long inv_stride, int* info, int extra_rows = 0);
+void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows = 0);
 
 // B[m x n] <- B * L^-T  (solve X L^T = B), L n x n lower with inverted diagonal blocks in inv.
-void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B);
+void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B);
 // B[m x n] <- B * L^-1  (solve X L = B).  rhs_lower: B is n x n lower triangular (rows above the
 // diagonal block of each column block are zero and are skipped; the result is lower triangular).
-void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B,
+void trsm_rln(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B,
               bool rhs_lower);
 
 struct FitParams {
@@ -59,13 +60,13 @@ constexpr int LOSS_EVERY = 25;   // models.py:211
 // Outputs (device, compact): mu [nb][N], cov [nb][N][N], chol (nullable), logdet (nullable, [nb]),
 // hyp (nullable, [nb][2]), basis (nullable, [nb][2][N]: L_c^-1 1 and L_c^-1 mu, the two vectors every
 // constant-vector log-likelihood of the posterior needs).  info: ws.info (device).
-void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const double* X, const double* y_in,
-            const double* nu_in, double* mu, double* cov, double* chol, double* logdet, double* hyp,
-            double* basis);
+void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, const real* y_in,
+            const real* nu_in, real* mu, real* cov, real* chol, double* logdet, double* hyp,
+            real* basis);
 
 // chol/logdet/basis of caller-supplied covariances already placed (padded, full) in ws.T2; mu_pad [nb][Np].
-void mvn_factor(Prims& P, FitWorkspace& ws, int N, const double* mu_pad, double* chol, double* logdet,
-                double* basis);
+void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* chol, double* logdet,
+                real* basis);
 
 // Nuclear norms ||L_j^T L_i||_* for nb pairs sharing L_i (Li: stride-0 Mat) - the trace term of the Gaussian
 // W2 distance of ensembles/wasserstein.py:41-45: tr (S_i^1/2 S_j S_i^1/2)^1/2 = sum of singular values of L_j^T L_i.
@@ -79,4 +80,4 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
 // Algorithmic flop of one member fit (2 flop per FMA, triangular structure exploited).
 double fit_flops(int N, int R, int n_iters);
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

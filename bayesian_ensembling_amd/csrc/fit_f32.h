@@ -1,0 +1,27 @@
+// fit_f32.h - the bridge between the C ABI (capi.hip, fp64 build of the primitives) and the fp32 build of the same
+// driver and kernels (fit_f32.hip, compiled with -DBAYENS_F32 into namespace bayens_f32).  Plain types only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+struct BayensF32Args {
+  int B, N, R, kernel, n_iters;
+  double gamma, lr, jitter;
+  const float* X;        // device [B][N][R]
+  const float* y_mean;   // device [B][N]
+  const float* y_var;    // device [B][N]
+  float* mu;             // device [B][N]
+  float* cov;            // device [B][N][N]
+  float* chol;           // device, nullable
+  double* logdet;        // device [B], nullable
+  double* hyp;           // device [B][2], nullable
+  double* loss_trace;    // device [B][ceil(n_iters/25)], nullable
+  float* basis;          // device [B][2][N], nullable
+  int* info_host;        // host [B]
+};
+
+void* bayens_f32_create(hipStream_t stream);
+void bayens_f32_destroy(void* state);
+// returns 0 or a HIP error code / negative argument error; message in *err
+int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err);

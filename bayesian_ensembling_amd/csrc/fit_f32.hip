@@ -1,0 +1,47 @@
+// fit_f32.hip - fp32 instance of the fit (BASELINE.json config 3).  This translation unit, gemm.hip, kernels.hip and
+// driver.cpp are compiled a second time with -DBAYENS_F32: `real` = float, namespace bayens_f32, the 16x16x4 MFMA
+// in its fp32 form (same operand layout, twice the rate, half the bytes in every O(N^2) pass).  What stays fp64 in
+// this mode: the hyper-parameters and Adam state, the squared distances of the kernel matrix (X~X~^T on the fp64
+// MFMA - r^2 = |x|^2 + |y|^2 - 2 x.y cancels), the 64x64 diagonal-block Cholesky + inverse (LDS images and MFMA in
+// fp64, loaded from / stored to fp32), and every reduction (log-determinants, traces, gradient sums, the loss).
+#ifndef BAYENS_F32
+#error "compile with -DBAYENS_F32"
+#endif
+#include "fit_f32.h"
+
+#include <vector>
+
+#include "fit_ws.h"
+
+namespace bayens_f32 {
+struct State {
+  hipStream_t stream;
+  HipPrims prims;
+  DeviceWs dws;
+  explicit State(hipStream_t s) : stream(s), prims(s) {}
+};
+}  // namespace bayens_f32
+
+using namespace bayens_f32;
+
+void* bayens_f32_create(hipStream_t stream) { return new State(stream); }
+void bayens_f32_destroy(void* state) { delete static_cast<State*>(state); }
+
+int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
+  State* st = static_cast<State*>(state);
+  try {
+    const int Np = pad_to_leaf(a.N);
+    st->dws.ensure(a.B, Np);
+    FitWorkspace w = st->dws.view(0, a.B);
+    FitParams fp{a.N, a.R, a.kernel, a.n_iters, a.gamma, a.lr, a.jitter};
+    fp.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+    fp.loss_trace = fp.loss_stride > 0 ? a.loss_trace : nullptr;
+    gp_fit(st->prims, w, fp, a.X, a.y_mean, a.y_var, a.mu, a.cov, a.chol, a.logdet, a.hyp, a.basis);
+    BAYENS_HIP(hipMemcpyAsync(a.info_host, w.info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
+    BAYENS_HIP(hipStreamSynchronize(st->stream));
+    return 0;
+  } catch (const HipError& e) {
+    if (err) *err = e.what;
+    return e.code > 0 ? e.code : -1;
+  }
+}

@@ -16,19 +16,30 @@
 //   Block ids are dealt so that each XCD (own L2) walks a contiguous range of tiles of few members.
 #include "hip_prims.h"
 
-namespace bayens {
+namespace BAYENS_NS {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
+typedef real v4d __attribute__((ext_vector_type(4)));   // one 16x16 accumulator tile per lane (fp64 or fp32 `real`)
+typedef real v2d __attribute__((ext_vector_type(2)));
+
+// The 16x16x4 MFMA exists for both precisions with the same A/B operand layout (lane l: A[l&15][l>>4],
+// B[l>>4][l&15]); the fp32 form issues in 32 cycles instead of 64.  Only the accumulator layout differs:
+// fp64 keeps rows (l>>4) + 4r in register r, fp32 rows 4(l>>4) + r.
+#ifdef BAYENS_F32
+#define BAYENS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+__device__ __forceinline__ int acc_row(int lk, int r) { return 4 * lk + r; }
+#else
+#define BAYENS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+__device__ __forceinline__ int acc_row(int lk, int r) { return lk + 4 * r; }
+#endif
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 2;
 
 struct GemmArgs {
-  const double* A;
-  const double* B;
-  double* C;
+  const real* A;
+  const real* B;
+  real* C;
   long sA, sB, sC;
   int lda, ldb, ldc;
   int m, n, k;
@@ -41,7 +52,7 @@ struct GemmArgs {
 // thread takes 4 x (2 consecutive k) of rows r, r+32, r+64, r+96; TR=false: memory is [k][row] -> each
 // thread takes 4 x (2 consecutive rows) of k-rows kr, kr+4, kr+8, kr+12.
 template <bool TR>
-__device__ __forceinline__ void stage_load(const double* base, int ld, int row0, int nrows,
+__device__ __forceinline__ void stage_load(const real* base, int ld, int row0, int nrows,
                                            int k0, int tid, v2d (&reg)[4]) {
   if (TR) {
     const int kp = tid & 7, r = tid >> 3;
@@ -62,7 +73,7 @@ __device__ __forceinline__ void stage_load(const double* base, int ld, int row0,
 }
 
 template <bool TR>
-__device__ __forceinline__ void stage_store(double (*tile)[LDT], int tid, const v2d (&reg)[4]) {
+__device__ __forceinline__ void stage_store(real (*tile)[LDT], int tid, const v2d (&reg)[4]) {
   if (TR) {
     const int kp = tid & 7, r = tid >> 3;
 #pragma unroll
@@ -79,8 +90,8 @@ __device__ __forceinline__ void stage_store(double (*tile)[LDT], int tid, const 
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double As[2][BK][LDT];
-  __shared__ __attribute__((aligned(16))) double Bs[2][BK][LDT];
+  __shared__ __attribute__((aligned(16))) real As[2][BK][LDT];
+  __shared__ __attribute__((aligned(16))) real Bs[2][BK][LDT];
 
   // XCD-aware dealing: consecutive hardware block ids go round-robin over the 8 XCDs; give every XCD a
   // contiguous chunk of the (member, tile) space so that its L2 sees few members' panels.
@@ -107,14 +118,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     // 64x64 blocks strictly above the block diagonal are not computed but must read as zeros later
     const int r64 = row0 + wm * 64, c64 = col0 + wn * 64;
     if (c64 > r64 && r64 < g.m && c64 < g.n) {
-      double* Cz = g.C + batch * g.sC + (long)r64 * g.ldc + c64;
+      real* Cz = g.C + batch * g.sC + (long)r64 * g.ldc + c64;
       for (int e = lane; e < 64 * 64; e += 64) Cz[(long)(e >> 6) * g.ldc + (e & 63)] = 0.0;
     }
   }
   if ((g.flags & GEMM_TRI_OUT) && col0 > row0) return;   // whole tile above the block diagonal
-  const double* A = g.A + batch * g.sA;
-  const double* B = g.B + batch * g.sB;
-  double* C = g.C + batch * g.sC;
+  const real* A = g.A + batch * g.sA;
+  const real* B = g.B + batch * g.sB;
+  real* C = g.C + batch * g.sC;
 
   bool active = (row0 + wm * 64 < g.m) && (col0 + wn * 64 < g.n);
   if ((g.flags & GEMM_TRI_OUT) && (col0 + wn * 64 > row0 + wm * 64)) active = false;
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0, 0, 0, 0};
 
   v2d ra[4], rb[4];
   if (nk > 0) {
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     if (active) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        double a[4], b[4];
+        real a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = As[buf][kk * 4 + lk][wm * 64 + i * 16 + lr];
 #pragma unroll
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = BAYENS_MFMA16(a[i], b[j], acc[i][j]);
       }
     }
     if (s + 1 < nk) {
@@ -174,20 +185,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   // cost ~27 us per tile; batched, it is one round trip per strip.
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    double cv[4][4];
+    real cv[4][4];
     if (g.beta != 0.0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cv[j][r] = C[(long)(row0 + wm * 64 + i * 16 + lk + 4 * r) * g.ldc + col0 + wn * 64 + j * 16 + lr];
+          cv[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = col0 + wn * 64 + j * 16 + lr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + wm * 64 + i * 16 + lk + 4 * r;
+        const int row = row0 + wm * 64 + i * 16 + acc_row(lk, r);
         double v = g.alpha * acc[i][j][r];
         if (g.beta != 0.0) v += g.beta * cv[j][r];
         if (row == col) v += g.diag_add;
@@ -209,15 +220,15 @@ constexpr int SK = 64, SLD = 66;
 
 template <bool TB>
 __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double As[SK][SLD];   // [row][k]
-  __shared__ __attribute__((aligned(16))) double Bs[SK][SLD];   // [k][col]
+  __shared__ __attribute__((aligned(16))) real As[SK][SLD];   // [row][k]
+  __shared__ __attribute__((aligned(16))) real Bs[SK][SLD];   // [k][col]
   const int tiles_m = g.m / SK;
   const int batch = blockIdx.x / tiles_m;
   const int row0 = (blockIdx.x - batch * tiles_m) * SK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const double* A = g.A + batch * g.sA + (long)row0 * g.lda;
-  const double* B = g.B + batch * g.sB;
-  double* C = g.C + batch * g.sC + (long)row0 * g.ldc;
+  const real* A = g.A + batch * g.sA + (long)row0 * g.lda;
+  const real* B = g.B + batch * g.sB;
+  real* C = g.C + batch * g.sC + (long)row0 * g.ldc;
   {
     const int c2 = tid & 31, r = tid >> 5;
     v2d va[8], vb[8];
@@ -241,14 +252,14 @@ __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < 4; ++j) acc[j] = v4d{0, 0, 0, 0};
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
-    const double a = As[wave * 16 + lr][kk * 4 + lk];
+    const real a = As[wave * 16 + lr][kk * 4 + lk];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double b = Bs[kk * 4 + lk][j * 16 + lr];
-      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+      const real b = Bs[kk * 4 + lk][j * 16 + lr];
+      acc[j] = BAYENS_MFMA16(a, b, acc[j]);
     }
   }
 #pragma unroll
@@ -256,8 +267,8 @@ __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
     const int col = j * 16 + lr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = wave * 16 + lk + 4 * r;
-      double* cp = C + (long)row * g.ldc + col;
+      const int row = wave * 16 + acc_row(lk, r);
+      real* cp = C + (long)row * g.ldc + col;
       double v = g.alpha * acc[j][r];
       if (g.beta != 0.0) v += g.beta * (*cp);
       if (row0 + row == col) v += g.diag_add;
@@ -275,22 +286,22 @@ __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
 // One launch and one HBM pass over the panel replace the 2*nsub-1 launches of the recursion's bottom levels.
 // ------------------------------------------------------------------------------------------------
 struct PanelArgs {
-  const double* L;     // n x n lower block
-  const double* inv;   // inverted 64x64 diagonal blocks of that block, [nsub][64][64]
-  double* B;           // m x n panel, in place
+  const real* L;     // n x n lower block
+  const real* inv;   // inverted 64x64 diagonal blocks of that block, [nsub][64][64]
+  real* B;           // m x n panel, in place
   long sL, sInv, sB;
   int ldl, ldb, m, nsub;
 };
 
 template <bool TR>
-__device__ __forceinline__ void stage64_load(const double* src, int ld, int tid, v2d (&reg)[8]) {
+__device__ __forceinline__ void stage64_load(const real* src, int ld, int tid, v2d (&reg)[8]) {
   const int c2 = tid & 31, r = tid >> 5;
 #pragma unroll
   for (int p = 0; p < 8; ++p) reg[p] = *reinterpret_cast<const v2d*>(src + (long)(r + 8 * p) * ld + 2 * c2);
 }
 // TR=false: tile[row][col] = src[row][col]; TR=true: tile[col][row] = src[row][col]
 template <bool TR>
-__device__ __forceinline__ void stage64_store(double (*tile)[SLD], int tid, const v2d (&reg)[8]) {
+__device__ __forceinline__ void stage64_store(real (*tile)[SLD], int tid, const v2d (&reg)[8]) {
   const int c2 = tid & 31, r = tid >> 5;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -304,30 +315,30 @@ __device__ __forceinline__ void stage64_store(double (*tile)[SLD], int tid, cons
 }
 
 // acc[jt] += sgn * As[wave rows][:] * Bs[:][16 jt ..]   (Bs is the k-major image B[k][col])
-__device__ __forceinline__ void panel_mma(v4d (&acc)[4], const double (*As)[SLD], const double (*Bs)[SLD], int wave,
+__device__ __forceinline__ void panel_mma(v4d (&acc)[4], const real (*As)[SLD], const real (*Bs)[SLD], int wave,
                                           int lane, double sgn) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
-    const double a = sgn * As[wave * 16 + lr][kk * 4 + lk];
+    const real a = (real)sgn * As[wave * 16 + lr][kk * 4 + lk];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
   }
 }
 
 // the same product with the inverted diagonal block as B operand: op(M_j) is triangular, so the 4x16 sub-tiles of
 // Bs that are entirely zero are skipped (40 of 64 MFMAs remain).  UPPER: Bs[k][col] != 0 only for k <= col.
 template <bool UPPER>
-__device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const double (*As)[SLD], const double (*Bs)[SLD], int wave,
+__device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const real (*As)[SLD], const real (*Bs)[SLD], int wave,
                                               int lane) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
-    const double a = As[wave * 16 + lr][kk * 4 + lk];
+    const real a = As[wave * 16 + lr][kk * 4 + lk];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool live = UPPER ? (kk < 4 * j + 4) : (kk >= 4 * j);
-      if (live) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j], 0, 0, 0);
+      if (live) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
     }
   }
 }
@@ -338,16 +349,16 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
   // L block or inverted diagonal block, shared by the four waves.  Finished blocks X_k stay in registers as
   // (negated) A fragments, 16 doubles per lane and block, so a product only stages its L block; the next block's
   // global load is issued before the current product's MFMAs.
-  __shared__ __attribute__((aligned(16))) double As[SK][SLD];
-  __shared__ __attribute__((aligned(16))) double Bs[SK][SLD];
+  __shared__ __attribute__((aligned(16))) real As[SK][SLD];
+  __shared__ __attribute__((aligned(16))) real Bs[SK][SLD];
   const int tiles_m = g.m / SK;
   const int batch = blockIdx.x / tiles_m;
   const int row0 = (blockIdx.x - batch * tiles_m) * SK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const double* L = g.L + batch * g.sL;
-  const double* inv = g.inv + batch * g.sInv;
-  double* B = g.B + batch * g.sB + (long)row0 * g.ldb;
+  const real* L = g.L + batch * g.sL;
+  const real* inv = g.inv + batch * g.sInv;
+  real* B = g.B + batch * g.sB + (long)row0 * g.ldb;
   const int nsub = g.nsub;
 
   // tile (s, t): t < s the L block coupling finished block t to block s (in solve order), t == s the inverse
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
     }
   };
 
-  double xf[3][16];   // -X_k as A fragments: xf[t][kk] = -X_t[wave rows lr][4 kk + lk]
+  real xf[3][16];   // -X_k as A fragments: xf[t][kk] = -X_t[wave rows lr][4 kk + lk]
   v2d rb[8];
   tile_load(0, 0, rb);
 #pragma unroll
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr];
+        for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + acc_row(lk, r)) * g.ldb + 64 * j + jt * 16 + lr];
 #pragma unroll
       for (int t = 0; t <= s; ++t) {
         __syncthreads();                       // the previous product is done with Bs
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
 #pragma unroll
           for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = acc[jt][r];
+            for (int r = 0; r < 4; ++r) As[wave * 16 + acc_row(lk, r)][jt * 16 + lr] = acc[jt][r];
         }
         stage64_store<!RLN>(Bs, tid, rb);
         __syncthreads();
@@ -394,23 +405,23 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
           for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
-              acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[t][kk], Bs[kk * 4 + lk][jt * 16 + lr], acc[jt], 0, 0, 0);
+              acc[jt] = BAYENS_MFMA16(xf[t][kk], Bs[kk * 4 + lk][jt * 16 + lr], acc[jt]);
         } else {
           // X_j = acc op(M_j); RLT: Bs[k][col] = M_j[col][k] (upper triangular image); RLN: Bs[k][col] = M_j[k][col]
           v4d x[4];
 #pragma unroll
-          for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0.0, 0.0, 0.0, 0.0};
+          for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0, 0, 0, 0};
           panel_mma_tri<!RLN>(x, As, Bs, wave, lane);
 #pragma unroll
           for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) B[(long)(wave * 16 + lk + 4 * r) * g.ldb + 64 * j + jt * 16 + lr] = x[jt][r];
+            for (int r = 0; r < 4; ++r) B[(long)(wave * 16 + acc_row(lk, r)) * g.ldb + 64 * j + jt * 16 + lr] = x[jt][r];
           if (s < 3 && s + 1 < nsub) {
             // the wave's own rows of As: finished block in, A fragments out (same wave wrote and reads)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) As[wave * 16 + lk + 4 * r][jt * 16 + lr] = -x[jt][r];
+              for (int r = 0; r < 4; ++r) As[wave * 16 + acc_row(lk, r)][jt * 16 + lr] = -x[jt][r];
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -436,7 +447,7 @@ double algorithmic_flop(int nb, int m, int n, int k, int flags) {
 double algorithmic_bytes(int nb, int m, int n, int k, int flags, double beta) {
   const double tri = (flags & GEMM_KTRIM_TN_LOWER) ? 0.5 : 1.0;
   const double c = out_elems(m, n, flags);
-  return 8.0 * nb * (tri * ((double)m * k + (double)n * k) + c * (beta != 0.0 ? 2.0 : 1.0));
+  return (double)sizeof(real) * nb * (tri * ((double)m * k + (double)n * k) + c * (beta != 0.0 ? 2.0 : 1.0));
 }
 
 }  // namespace
@@ -494,7 +505,7 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   }
 }
 
-void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) {
+void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B, int mode) {
   if (nb <= 0 || m <= 0 || n <= 0) return;
   if ((m % 64) || (n % 64) || n > 256 || (L.ld & 1) || (B.ld & 1))
     throw HipError{-1, "trsm_panel: m, n must be multiples of 64, n <= 256"};
@@ -522,10 +533,10 @@ void HipPrims::trsm_panel(int nb, int m, int n, Mat L, const double* inv, long i
     const double f = (double)nb * m * (double)n * n;      // triangular solve: m n^2 flop
     prof.events.push_back(KernelProfile::Ev{e0, e1, FAM_TRSM_PANEL, m, n, n, mode, f});
     prof.flop[FAM_ALL] += f; prof.flop[FAM_TRSM_PANEL] += f;
-    const double by = 8.0 * nb * (2.0 * m * (double)n + 0.5 * (double)n * n);
+    const double by = (double)sizeof(real) * nb * (2.0 * m * (double)n + 0.5 * (double)n * n);
     prof.bytes[FAM_ALL] += by; prof.bytes[FAM_TRSM_PANEL] += by;
     prof.launches[FAM_ALL] += 1; prof.launches[FAM_TRSM_PANEL] += 1;
   }
 }
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

@@ -8,7 +8,7 @@
 
 #include "prims.h"
 
-namespace bayens {
+namespace BAYENS_NS {
 
 struct HipError {
   int code;
@@ -19,7 +19,7 @@ struct HipError {
   do {                                                                                        \
     hipError_t e__ = (expr);                                                                  \
     if (e__ != hipSuccess)                                                                    \
-      throw ::bayens::HipError{(int)e__, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
+      throw ::BAYENS_NS::HipError{(int)e__, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
   } while (0)
 
 // kernel families of the per-launch accounting (bayens_profile_get): one per kernel symbol of the GEMM group
@@ -60,37 +60,37 @@ struct HipPrims : Prims {
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
             double diag_add) override;
-  void trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) override;
-  void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
-  void potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) override;
+  void trsm_panel(int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B, int mode) override;
+  void potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
+  void potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override;
-  void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
-                  const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) override;
-  void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
+  void init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
+                  const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info) override;
+  void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
             Mat Lb) override;
-  void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) override;
-  void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta,
-               double* out) override;
+  void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) override;
+  void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
+               real* out) override;
   void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override;
-  void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) override;
-  void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) override;
-  void aug_get(int nb, int n, Mat rows, double* vec) override;
-  void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) override;
-  void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) override;
-  void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) override;
-  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate,
+  void form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi) override;
+  void aug_set(int nb, int n, Mat rows, const real* vec, int zero_rows) override;
+  void aug_get(int nb, int n, Mat rows, real* vec) override;
+  void basis_rows_set(int nb, int N, int Np, Mat rows, const real* mu_pad, int in_padding) override;
+  void basis_rows_get(int nb, int N, int Np, Mat rows, real* basis) override;
+  void resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) override;
+  void grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate,
                  double lr) override;
-  void gemv_n(int nb, int n, Mat A, const double* x, double* y) override;
-  void row_sqsum(int nb, int n, Mat A, double* out) override;
-  void elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu, const double* mvec,
+  void gemv_n(int nb, int n, Mat A, const real* x, real* y) override;
+  void row_sqsum(int nb, int n, Mat A, real* out) override;
+  void elbo_combine(int nb, int N, int Np, const real* a, const real* f, const real* nu, const real* mvec,
                     Mat C, const double* logdetC, const double* trS, double* trace, int stride, int slot) override;
   void identity(int nb, int n, Mat A) override;
   void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) override;
-  void diag_init(int nb, int n, const double* nu, double add, Mat dst) override;
-  void extract(int nb, int N, Mat src, double* dst, int mode) override;
-  void extract_vec(int nb, int N, int Np, const double* src, double* dst) override;
+  void diag_init(int nb, int n, const real* nu, double add, Mat dst) override;
+  void extract(int nb, int N, Mat src, real* dst, int mode) override;
+  void extract_vec(int nb, int N, int Np, const real* src, real* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;
   void frob_normalise(int nb, int n, Mat M, Mat X) override;
@@ -134,4 +134,4 @@ struct HipPrims : Prims {
   void multi_model_mean(int M, int R_max, const int* R, int P, const double* data, double* mu_out, double* var_out);
 };
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

@@ -9,7 +9,7 @@
 
 #include "hip_prims.h"
 
-namespace bayens {
+namespace BAYENS_NS {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -58,8 +58,8 @@ __global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const double* s = src.p + b * src.stride;
-  double* d = dst.p + b * dst.stride;
+  const real* s = src.p + b * src.stride;
+  real* d = dst.p + b * dst.stride;
 #pragma unroll 4
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
@@ -73,8 +73,8 @@ __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
   const int b = blockIdx.z;
   const int bi = blockIdx.y, bj = blockIdx.x;   // output tile (bi, bj) = input tile (bj, bi)^T
   const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-  const double* w = W.p + b * W.stride;
-  double* wt = Wt.p + b * Wt.stride;
+  const real* w = W.p + b * W.stride;
+  real* wt = Wt.p + b * Wt.stride;
   if (bj < bi) {   // strictly below the diagonal of the output: zeros
     for (int q = 0; q < 16; ++q) wt[(long)(bi * 64 + r0 + 4 * q) * Wt.ld + bj * 64 + c] = 0.0;
     return;
@@ -95,15 +95,15 @@ __global__ void fill_identity_kernel(int n, Mat A) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  double* a = A.p + b * A.stride;
+  real* a = A.p + b * A.stride;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
     a[(long)i * A.ld + j] = i == j ? 1.0 : 0.0;
   }
 }
 
-__global__ void init_vec_kernel(int nb, int N, int Np, double* theta1, double* mvec, double* ustate,
-                                const double* y_in, const double* nu_in, double* y_pad, double* nu_pad,
+__global__ void init_vec_kernel(int nb, int N, int Np, real* theta1, real* mvec, double* ustate,
+                                const real* y_in, const real* nu_in, real* y_pad, real* nu_pad,
                                 int* info) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,12 +117,12 @@ __global__ void init_vec_kernel(int nb, int N, int Np, double* theta1, double* m
   if (i == 0) info[b] = 0;
 }
 
-__global__ void scale_rows_kernel(int n, Mat src, const double* nu, Mat dst) {
+__global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const double* s = src.p + b * src.stride;
-  double* d = dst.p + b * dst.stride;
+  const real* s = src.p + b * src.stride;
+  real* d = dst.p + b * dst.stride;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
     d[(long)i * dst.ld + j] = s[(long)i * src.ld + j] * (1.0 / sqrt(nu[(long)b * n + i]));
@@ -130,12 +130,12 @@ __global__ void scale_rows_kernel(int n, Mat src, const double* nu, Mat dst) {
 }
 
 // Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
-__global__ void form_phi_kernel(int n, Mat GS, const double* u, const double* mvec, Mat Phi) {
+__global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, Mat Phi) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const double* g = GS.p + b * GS.stride;
-  double* p = Phi.p + b * Phi.stride;
+  const real* g = GS.p + b * GS.stride;
+  real* p = Phi.p + b * Phi.stride;
   const double mj = mvec[(long)b * n + j];
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi) return;
   const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-  const double* g = G.p + b * G.stride;
-  double* lam = Lam.p + b * Lam.stride;
-  double* cb = Cb.p + b * Cb.stride;
-  double* gf = Gfull.p + b * Gfull.stride;
+  const real* g = G.p + b * G.stride;
+  real* lam = Lam.p + b * Lam.stride;
+  real* cb = Cb.p + b * Cb.stride;
+  real* gf = Gfull.p + b * Gfull.stride;
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
     const int i = bi * 64 + r, j = bj * 64 + c;
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Lin
   __shared__ double tile[64][65];
   const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
   const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-  const double* l = L.p + b * L.stride;
-  const double* li = Linv.p + b * Linv.stride;
-  double* at = At.p + b * At.stride;
+  const real* l = L.p + b * L.stride;
+  const real* li = Linv.p + b * Linv.stride;
+  real* at = At.p + b * At.stride;
   if (bj >= bi) {                    // upper (or diagonal) block: Linv tile (bj, bi) exists
     for (int q = 0; q < 16; ++q) {
       const int r = r0 + 4 * q;
@@ -209,23 +209,23 @@ __global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Lin
   }
 }
 
-__global__ void diag_init_kernel(int n, const double* nu, double add, Mat dst) {
+__global__ void diag_init_kernel(int n, const real* nu, double add, Mat dst) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  double* d = dst.p + b * dst.stride;
+  real* d = dst.p + b * dst.stride;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
     d[(long)i * dst.ld + j] = i == j ? nu[(long)b * n + i] + add : 0.0;
   }
 }
 
-__global__ void extract_kernel(int N, Mat src, double* dst, int mode) {
+__global__ void extract_kernel(int N, Mat src, real* dst, int mode) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const double* s = src.p + b * src.stride;
-  double* d = dst + (long)b * N * N;
+  const real* s = src.p + b * src.stride;
+  real* d = dst + (long)b * N * N;
   if (j >= N) return;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
@@ -243,7 +243,7 @@ __global__ void pad_in_kernel(int N, int Np, const double* src, Mat dst) {
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const double* s = src + (long)b * N * N;
-  double* d = dst.p + b * dst.stride;
+  real* d = dst.p + b * dst.stride;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
     double v = (i < N && j < N) ? s[(long)i * N + j] : (i == j ? 1.0 : 0.0);
@@ -269,7 +269,7 @@ __global__ void pad_vec_kernel(int N, int Np, const double* src, double* dst) {
   if (i < Np) dst[(long)b * Np + i] = i < N ? src[(long)b * N + i] : 0.0;
 }
 
-__global__ void extract_vec_kernel(int N, int Np, const double* src, double* dst) {
+__global__ void extract_vec_kernel(int N, int Np, const real* src, real* dst) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) dst[(long)b * N + i] = src[(long)b * Np + i];
@@ -278,7 +278,7 @@ __global__ void extract_vec_kernel(int N, int Np, const double* src, double* dst
 __global__ void logdet_kernel(int N, Mat Lc, double* out) {
   __shared__ double part[4];
   const int b = blockIdx.x;
-  const double* l = Lc.p + b * Lc.stride;
+  const real* l = Lc.p + b * Lc.stride;
   double s = 0.0;
   for (int i = threadIdx.x; i < N; i += 256) s += log(l[(long)i * Lc.ld + i]);
   s = wave_sum(s);
@@ -305,7 +305,7 @@ __global__ void extract_diag_kernel(int N, const double* cov, double* var) {
 // kernel matrix (GPflow Matern32.K as used at models.py:186-189,198,217): r2 = -2 X~X~^T + s_i + s_j with
 // the X~X~^T contraction on the fp64 matrix cores; the epilogue (sqrt/exp) runs on the 4 results per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ void xprep_kernel(int N, int Np, int R, int R4, const double* X, const double* ustate,
+__global__ void xprep_kernel(int N, int Np, int R, int R4, const real* X, const double* ustate,
                              double* xs, double* ssq) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -593,14 +593,14 @@ __device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], d
   LEAF_STAMP(13);
 }
 
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
+__global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, real* inv, long inv_stride, int pivot_base,
                                                          int* info, unsigned long long* stamps) {
   __shared__ double S[64][LS];     // the block -> its lower factor
   __shared__ double Mi[64][LS];    // inverse of the factor
   __shared__ double Tt[4][16][LT]; // per-wave 16x16 scratch for P4
   const int b = blockIdx.x, tid = threadIdx.x;
   __builtin_amdgcn_s_setprio(3);   // a serial chain: win issue arbitration against co-resident throughput waves
-  double* a = Ablk.p + b * Ablk.stride;
+  real* a = Ablk.p + b * Ablk.stride;
   {
     const int c = tid & 63, r0 = tid >> 6;
     for (int q = 0; q < 16; ++q) {
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
   __syncthreads();
   LEAF_STAMP(0);
   leaf_factor(S, Mi, Tt, b, tid, pivot_base, info, stamps);
-  double* iv = inv + b * inv_stride;
+  real* iv = inv + b * inv_stride;
   {
     const int c = tid & 63, r0 = tid >> 6;
     for (int q = 0; q < 16; ++q) {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, double* inv, 
 // Two leaves in one launch: the 128x128 diagonal block [A11 .; A21 A22] is factored by one workgroup -
 // leaf(A11), L21 = A21 inv(L11)^T, A22 -= L21 L21^T, leaf(A22) - with L21 held in LDS between the steps.
 // Replaces four launches (leaf, 64x64 panel solve, 64^3 update, leaf) at the bottom of the blocked Cholesky.
-__global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv, long inv_stride, int pivot_base,
+__global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, real* inv, long inv_stride, int pivot_base,
                                                           int* info) {
   // two 64x64 images rotate through the four steps (77 KB in all, so two workgroups - or one beside two GEMM
   // workgroups - fit a CU):   leaf 1: S = U, Mi = V | panel: T = U, Mi = V | update: T = U, S = V | leaf 2: S = V, Mi = U
@@ -640,8 +640,8 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv,
   const int c = tid & 63, rq = tid >> 6;
   __builtin_amdgcn_s_setprio(3);   // a serial chain: win issue arbitration against co-resident throughput waves
   const long ld = Ablk.ld;
-  double* a = Ablk.p + b * Ablk.stride;
-  double* iv = inv + b * inv_stride;
+  real* a = Ablk.p + b * Ablk.stride;
+  real* iv = inv + b * inv_stride;
   for (int q = 0; q < 16; ++q) {
     const int r = rq + 4 * q;
     U[r][c] = c <= r ? a[r * ld + c] : 0.0;
@@ -699,12 +699,12 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, double* inv,
 // ------------------------------------------------------------------------------------------------
 // out = beta out + alpha L^T (v/nu): one workgroup per 64 columns; lanes = columns (512-byte coalesced row
 // segments), the 4 waves split the rows i >= j0 (L is lower triangular).
-__global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const double* y, const double* nu, double alpha,
-                                                      double beta, double* theta1) {
+__global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* y, const real* nu, double alpha,
+                                                      double beta, real* theta1) {
   __shared__ double part[4][64];
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double* l = L.p + b * L.stride;
+  const real* l = L.p + b * L.stride;
   double s = 0.0;
   for (int i = j0 + w; i < n; i += 4)
     s += l[(long)i * L.ld + j0 + c] * (y[(long)b * n + i] / nu[(long)b * n + i]);
@@ -712,19 +712,19 @@ __global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const double
   __syncthreads();
   if (w == 0) {
     const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-    double* t = theta1 + (long)b * n + j0 + c;
+    real* t = theta1 + (long)b * n + j0 + c;
     *t = (beta != 0.0 ? beta * (*t) : 0.0) + alpha * tot;
   }
 }
 
 // out_i = sum_{k < klim(i)} A_ik x_k - (sub ? sub_i : 0); one wave per row, lanes stride k.
-__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const double* x, const double* sub,
-                                                        double* out, int lower) {
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const real* x, const real* sub,
+                                                        real* out, int lower) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
-  const double* a = A.p + b * A.stride + (long)i * A.ld;
+  const real* a = A.p + b * A.stride + (long)i * A.ld;
   const int klim = lower ? i + 1 : n;
   double s = 0.0;
   for (int k = lane; k < klim; k += 64) s += a[k] * x[(long)b * n + k];
@@ -733,12 +733,12 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, Mat A, const doub
 }
 
 // out_i = sum_k A_ik^2; one wave per row
-__global__ __launch_bounds__(256) void row_sqsum_kernel(int n, Mat A, double* out) {
+__global__ __launch_bounds__(256) void row_sqsum_kernel(int n, Mat A, real* out) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
-  const double* a = A.p + b * A.stride + (long)i * A.ld;
+  const real* a = A.p + b * A.stride + (long)i * A.ld;
   double s = 0.0;
   for (int k = lane; k < n; k += 64) s += a[k] * a[k];
   s = wave_sum(s);
@@ -746,8 +746,8 @@ __global__ __launch_bounds__(256) void row_sqsum_kernel(int n, Mat A, double* ou
 }
 
 // prims.h elbo_combine: one workgroup per member, fixed-order reduction
-__global__ __launch_bounds__(256) void elbo_combine_kernel(int N, int Np, const double* a, const double* f,
-                                                           const double* nu, const double* mvec, Mat C,
+__global__ __launch_bounds__(256) void elbo_combine_kernel(int N, int Np, const real* a, const real* f,
+                                                           const real* nu, const real* mvec, Mat C,
                                                            const double* logdetC, const double* trS, double* trace,
                                                            int stride, int slot) {
   __shared__ double red[4];
@@ -772,16 +772,16 @@ __global__ __launch_bounds__(256) void elbo_combine_kernel(int N, int Np, const 
 }
 
 // the 64-row block appended to a right-hand side (prims.h aug_set / aug_get)
-__global__ void aug_set_kernel(int n, Mat rows, const double* vec, int zero_rows) {
+__global__ void aug_set_kernel(int n, Mat rows, const real* vec, int zero_rows) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  double* r = rows.p + b * rows.stride;
+  real* r = rows.p + b * rows.stride;
   r[j] = vec[(long)b * n + j];
   for (int q = 1; q <= zero_rows; ++q) r[(long)q * rows.ld + j] = 0.0;
 }
 
-__global__ void aug_get_kernel(int n, Mat rows, double* vec) {
+__global__ void aug_get_kernel(int n, Mat rows, real* vec) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j < n) vec[(long)b * n + j] = rows.p[b * rows.stride + j];
@@ -851,11 +851,11 @@ __global__ __launch_bounds__(256) void trsv_fwd2_kernel(int N, const double* cho
 }
 
 // rows appended to the covariance factorisation (prims.h basis_rows_set / _get)
-__global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const double* mu_pad, int in_padding) {
+__global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const real* mu_pad, int in_padding) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= Np) return;
-  double* r = rows.p + b * rows.stride;
+  real* r = rows.p + b * rows.stride;
   double v0 = j < N ? 1.0 : 0.0, v1 = j < N ? mu_pad[(long)b * Np + j] : 0.0;
   if (in_padding) {            // rows N and N+1 of the matrix itself: huge pivots keep them positive definite
     if (j == N) v0 = 1e30;
@@ -867,11 +867,11 @@ __global__ void basis_rows_set_kernel(int N, int Np, Mat rows, const double* mu_
     for (int q = 2; q < 64; ++q) r[(long)q * rows.ld + j] = 0.0;
 }
 
-__global__ void basis_rows_get_kernel(int N, Mat rows, double* basis) {
+__global__ void basis_rows_get_kernel(int N, Mat rows, real* basis) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
-  const double* r = rows.p + b * rows.stride;
+  const real* r = rows.p + b * rows.stride;
   basis[((long)b * 2) * N + j] = r[j];
   basis[((long)b * 2 + 1) * N + j] = r[(long)rows.ld + j];
 }
@@ -1055,12 +1055,12 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(int mode, Mat A, Mat B
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  double* pa = A.p + b * A.stride;
-  const double* pb = B.p ? B.p + b * B.stride : nullptr;
+  real* pa = A.p + b * A.stride;
+  const real* pb = B.p ? B.p + b * B.stride : nullptr;
   double s0 = 0.0, s1 = 0.0;
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    double* x = pa + (long)i * A.ld + j;
+    real* x = pa + (long)i * A.ld + j;
     if (mode == 0) { s0 += (*x) * (*x); }
     else if (mode == 1) {
       const double nv = a * (*x) + bcoef * pb[(long)i * B.ld + j];
@@ -1312,12 +1312,12 @@ void HipPrims::ensure_scratch(int nb, int Np, int R4) {
   if (need_g > gpart_cap) { if (gpart) BAYENS_HIP(hipFree(gpart)); BAYENS_HIP(hipMalloc(&gpart, need_g)); gpart_cap = need_g; }
 }
 
-void HipPrims::potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+void HipPrims::potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) {
   hipLaunchKernelGGL(potrf_leaf_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info,
                      leaf_stamps);
   LAUNCH_CHECK();
 }
-void HipPrims::potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+void HipPrims::potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) {
   hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info);
   LAUNCH_CHECK();
 }
@@ -1333,14 +1333,14 @@ void HipPrims::transpose_lower(int nb, int n, Mat W, Mat Wt) {
   hipLaunchKernelGGL(transpose_lower_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, W, Wt);
   LAUNCH_CHECK();
 }
-void HipPrims::init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
-                          const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) {
+void HipPrims::init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
+                          const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info) {
   hipLaunchKernelGGL(fill_identity_kernel, tile_grid(Np, nb), dim3(256), 0, stream, Np, Lam);
   hipLaunchKernelGGL(init_vec_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, nb, N, Np, theta1, mvec,
                      ustate, y_in, nu_in, y_pad, nu_pad, info);
   LAUNCH_CHECK();
 }
-void HipPrims::kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
+void HipPrims::kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
                     Mat Lb) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
@@ -1349,11 +1349,11 @@ void HipPrims::kmat(int nb, int N, int Np, int R, const double* X, const double*
                      kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr);
   LAUNCH_CHECK();
 }
-void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) {
+void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) {
   hipLaunchKernelGGL(scale_rows_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, nu, dst);
   LAUNCH_CHECK();
 }
-void HipPrims::lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta, double* out) {
+void HipPrims::lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta, real* out) {
   hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, v, nu, alpha, beta, out);
   LAUNCH_CHECK();
 }
@@ -1361,20 +1361,20 @@ void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, M
   hipLaunchKernelGGL(lam_update_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, G, gamma, Lam, Cb, Gfull);
   LAUNCH_CHECK();
 }
-void HipPrims::aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) {
+void HipPrims::aug_set(int nb, int n, Mat rows, const real* vec, int zero_rows) {
   hipLaunchKernelGGL(aug_set_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec, zero_rows);
   LAUNCH_CHECK();
 }
-void HipPrims::aug_get(int nb, int n, Mat rows, double* vec) {
+void HipPrims::aug_get(int nb, int n, Mat rows, real* vec) {
   hipLaunchKernelGGL(aug_get_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, stream, n, rows, vec);
   LAUNCH_CHECK();
 }
-void HipPrims::basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) {
+void HipPrims::basis_rows_set(int nb, int N, int Np, Mat rows, const real* mu_pad, int in_padding) {
   hipLaunchKernelGGL(basis_rows_set_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, rows, mu_pad,
                      in_padding);
   LAUNCH_CHECK();
 }
-void HipPrims::basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) {
+void HipPrims::basis_rows_get(int nb, int N, int Np, Mat rows, real* basis) {
   (void)Np;
   hipLaunchKernelGGL(basis_rows_get_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, rows, basis);
   LAUNCH_CHECK();
@@ -1386,15 +1386,15 @@ void HipPrims::loglik_rows_basis(int B, int N, int R_obs, const double* basis, c
                      ll_mean);
   LAUNCH_CHECK();
 }
-void HipPrims::resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) {
+void HipPrims::resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) {
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
   LAUNCH_CHECK();
 }
-void HipPrims::form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) {
+void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi) {
   hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi);
   LAUNCH_CHECK();
 }
-void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) {
+void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
@@ -1403,16 +1403,16 @@ void HipPrims::grad_adam(int nb, int N, int Np, int R, const double* X, int kern
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
   LAUNCH_CHECK();
 }
-void HipPrims::gemv_n(int nb, int n, Mat A, const double* x, double* y) {
-  hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, x, (const double*)nullptr, y, 0);
+void HipPrims::gemv_n(int nb, int n, Mat A, const real* x, real* y) {
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, x, (const real*)nullptr, y, 0);
   LAUNCH_CHECK();
 }
-void HipPrims::row_sqsum(int nb, int n, Mat A, double* out) {
+void HipPrims::row_sqsum(int nb, int n, Mat A, real* out) {
   hipLaunchKernelGGL(row_sqsum_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, A, out);
   LAUNCH_CHECK();
 }
-void HipPrims::elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu,
-                            const double* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
+void HipPrims::elbo_combine(int nb, int N, int Np, const real* a, const real* f, const real* nu,
+                            const real* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
                             int stride, int slot) {
   hipLaunchKernelGGL(elbo_combine_kernel, dim3(nb), dim3(256), 0, stream, N, Np, a, f, nu, mvec, C, logdetC, trS,
                      trace, stride, slot);
@@ -1426,15 +1426,15 @@ void HipPrims::at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat A
   hipLaunchKernelGGL(at_from_linv_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, L, Linv, jitter, At);
   LAUNCH_CHECK();
 }
-void HipPrims::diag_init(int nb, int n, const double* nu, double add, Mat dst) {
+void HipPrims::diag_init(int nb, int n, const real* nu, double add, Mat dst) {
   hipLaunchKernelGGL(diag_init_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, nu, add, dst);
   LAUNCH_CHECK();
 }
-void HipPrims::extract(int nb, int N, Mat src, double* dst, int mode) {
+void HipPrims::extract(int nb, int N, Mat src, real* dst, int mode) {
   hipLaunchKernelGGL(extract_kernel, tile_grid_up(N, nb), dim3(256), 0, stream, N, src, dst, mode);
   LAUNCH_CHECK();
 }
-void HipPrims::extract_vec(int nb, int N, int Np, const double* src, double* dst) {
+void HipPrims::extract_vec(int nb, int N, int Np, const real* src, real* dst) {
   hipLaunchKernelGGL(extract_vec_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
   LAUNCH_CHECK();
 }
@@ -1556,4 +1556,4 @@ void HipPrims::extract_diag(int B, int N, const double* cov, double* var) {
   LAUNCH_CHECK();
 }
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

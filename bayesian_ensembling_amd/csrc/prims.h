@@ -1,6 +1,9 @@
 // prims.h - the batched device primitives the host-side driver sequences.
 //
-// Everything is fp64, row-major, batched over `nb` independent ensemble members.  A `Mat` is a
+// Everything is `real` (fp64 - the reference precision - by default; this header, the driver and the kernels are
+// compiled a second time with -DBAYENS_F32 into namespace bayens_f32 for the fp32 mode), row-major, batched over
+// `nb` independent ensemble members.  Scalars that steer the optimiser (hyper-parameters, Adam moments), reductions
+// (log-determinants, traces, the loss) and the kernel-matrix distances stay double in both modes.  A `Mat` is a
 // strided view: element (b, i, j) lives at p[b*stride + i*ld + j].  All matrix dimensions handed to
 // the primitives are multiples of LEAF (64): the driver pads every member to Np = ceil(N/64)*64 with
 // an identity block, which keeps the padded part decoupled from the real part through every
@@ -13,12 +16,20 @@
 #include <cstddef>
 #include <cstdint>
 
-namespace bayens {
+#ifdef BAYENS_F32
+#define BAYENS_NS bayens_f32
+namespace bayens_f32 { typedef float real; }
+#else
+#define BAYENS_NS bayens
+namespace bayens { typedef double real; }
+#endif
+
+namespace BAYENS_NS {
 
 constexpr int LEAF = 64;   // diagonal-block size of the blocked factorisations / solves
 
 struct Mat {
-  double* p;
+  real* p;
   int ld;
   long stride;
   Mat sub(int i, int j) const { return Mat{p + (long)i * ld + j, ld, stride}; }
@@ -46,7 +57,7 @@ struct Prims {
   // Whole triangular solve of a narrow diagonal block in one launch: B[m x n] <- B L^-T (mode 0) or B L^-1
   // (mode 1), n in {64, 128, 192, 256}, L the n x n lower block whose inverted 64x64 diagonal blocks are in inv.
   // Rows are independent, so every workgroup carries its 64 rows through all column blocks (one pass over B).
-  virtual void trsm_panel(int nb, int m, int n, Mat L, const double* inv, long inv_stride, Mat B, int mode) = 0;
+  virtual void trsm_panel(int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B, int mode) = 0;
 
   // Cholesky of one 64x64 diagonal block per member, in place (lower; strict upper set to 0), plus its
   // inverse into inv (64x64 row-major per member, member stride inv_stride).  A non-positive pivot j
@@ -58,10 +69,10 @@ struct Prims {
   virtual void side_end() {}
   virtual void side_join() {}
 
-  virtual void potrf_leaf(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) = 0;
+  virtual void potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) = 0;
   // two adjacent leaves (a 128x128 diagonal block): leaf, 64x64 panel solve, 64^3 update, leaf.  A back end may
   // fuse the four steps; this composition is the definition.
-  virtual void potrf_leaf2(int nb, Mat Ablk, double* inv, long inv_stride, int pivot_base, int* info) {
+  virtual void potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) {
     potrf_leaf(nb, Ablk, inv, inv_stride, pivot_base, info);
     trsm_panel(nb, LEAF, LEAF, Ablk, inv, inv_stride, Ablk.sub(LEAF, 0), 0);
     gemm(nb, LEAF, LEAF, LEAF, -1.0, Ablk.sub(LEAF, 0), Ablk.sub(LEAF, 0), 1.0, Ablk.sub(LEAF, LEAF),
@@ -74,65 +85,65 @@ struct Prims {
   virtual void transpose_lower(int nb, int n, Mat W, Mat Wt) = 0;  // Wt = tril(W)^T (zeros below diag)
 
   // state initialisation: Lam = I (n x n); theta1 = m = 0; u = softplus^-1(1); adam = 0; y/nu padded
-  virtual void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
-                          const double* y_in, const double* nu_in, double* y_pad, double* nu_pad,
+  virtual void init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
+                          const real* y_in, const real* nu_in, real* y_pad, real* nu_pad,
                           int* info) = 0;
 
   // Lb = tril(K0) + jitter*I (zeros above the diagonal; identity in the padded part) from the current hypers
   // softplus(ustate[b][0..1]).  X is [nb][N][R] compact.  K0 itself is never stored: the prediction uses
   // K0 = L L^T - jitter*I (driver.cpp) and the hyper-gradient re-evaluates the kernel (grad_adam).
-  virtual void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel,
+  virtual void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel,
                     double jitter, Mat Lb) = 0;
 
-  virtual void scale_rows_rsqrt(int nb, int n, Mat src, const double* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
+  virtual void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
   // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)
-  virtual void lt_dvec(int nb, int n, Mat L, const double* v, const double* nu, double alpha, double beta,
-                       double* out) = 0;
+  virtual void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
+                       real* out) = 0;
   // natural-gradient precision update from G = L^T D L (lower 64-blocks of G valid):
   //   Lam <- (1-gamma) Lam + gamma (I + G) on the lower triangle;  Cb <- tril(Lam) with zeros above;
   //   Gfull <- G mirrored to a full symmetric matrix
   virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) = 0;
   // Phi(L^T Lbar) without forming Lbar: for i >= j, (L^T Lbar)_ij = u_i m_j + (G S)_ij with u = L^T D (L m - y)
   //   Phi_ij = u_i m_j + GS_ij (i > j), half of it on the diagonal, 0 above
-  virtual void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi) = 0;
+  virtual void form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi) = 0;
   // a row of an n-column right-hand side that carries a vector through the same triangular solves
   // (x^T C^-T C^-1 = (C^-T C^-1 x)^T): rows[0][:] = vec and the `zero_rows` rows after it are cleared.
   // The row is either the first of a 64-row block appended below the matrix (zero_rows = 63) or, when the
   // member has padding (Np > N), the last padded row (zero_rows = 0): padded rows are decoupled from the real
   // block, so whatever they carry never reaches the real part of any later product.
-  virtual void aug_set(int nb, int n, Mat rows, const double* vec, int zero_rows) = 0;
-  virtual void aug_get(int nb, int n, Mat rows, double* vec) = 0;         // vec = rows[0][:]
+  virtual void aug_set(int nb, int n, Mat rows, const real* vec, int zero_rows) = 0;
+  virtual void aug_get(int nb, int n, Mat rows, real* vec) = 0;           // vec = rows[0][:]
   // the two bordering rows of the covariance factorisation: row 0 = 1 (columns < N, else 0), row 1 = mu_pad.
   // in_padding = 0: rows of an appended 64-row block (rows 2..63 zeroed).  in_padding = 1: `rows` are rows N and
   // N+1 of the padded matrix itself; they also get a huge diagonal entry (1e30) so that their pivots stay
   // positive - it only touches the padded part, which is excluded from chol / logdet / basis outputs.
-  virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const double* mu_pad, int in_padding) = 0;
-  virtual void basis_rows_get(int nb, int N, int Np, Mat rows, double* basis) = 0;
-  virtual void resid(int nb, int n, Mat L, const double* mvec, const double* y, double* a) = 0;  // a = L m - y
+  virtual void basis_rows_set(int nb, int N, int Np, Mat rows, const real* mu_pad, int in_padding) = 0;
+  virtual void basis_rows_get(int nb, int N, int Np, Mat rows, real* basis) = 0;
+  virtual void resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) = 0;  // a = L m - y
   // g = <Kbt, dK/dtheta> over the real N x N part (Kbt = Kbar^T; dK symmetric), then one Adam step on
   // the unconstrained hypers.  ustate per member: [u_var, u_ls, m_var, m_ls, v_var, v_ls, t, pad]
-  virtual void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt,
+  virtual void grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt,
                          double* ustate, double lr) = 0;
   // out_i = sum_k A_ik^2 (all n columns)
-  virtual void row_sqsum(int nb, int n, Mat A, double* out) = 0;
+  virtual void row_sqsum(int nb, int n, Mat A, real* out) = 0;
   // -ELBO of the whitened VGP with the heteroskedastic Gaussian likelihood from its pieces (models.py:142-149,
   // GPflow VGP.elbo):  sum_{t<N} [ log(2 pi)/2 + log(nu_t)/2 + (a_t^2 + f_t) / (2 nu_t) ]
   //                    + ( sum_{t<N} m_t^2 - N + 2 logdetC + (trS - sum_{t>=N} C_tt^-2) ) / 2
   // a = L m - y, f_t = (L S L^T)_tt, logdetC[b] = sum_{i<N} log C_ii, trS[b] = ||C^-1||_F^2 over the padded
   // matrix (the padded block of C is diagonal - Lam's padding is a multiple of I, not I - and is subtracted).
   // Written to trace[b * stride + slot].
-  virtual void elbo_combine(int nb, int N, int Np, const double* a, const double* f, const double* nu,
-                            const double* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
+  virtual void elbo_combine(int nb, int N, int Np, const real* a, const real* f, const real* nu,
+                            const real* mvec, Mat C, const double* logdetC, const double* trS, double* trace,
                             int stride, int slot) = 0;
-  virtual void gemv_n(int nb, int n, Mat A, const double* x, double* y) = 0;    // y = A x
+  virtual void gemv_n(int nb, int n, Mat A, const real* x, real* y) = 0;        // y = A x
   virtual void identity(int nb, int n, Mat A) = 0;                              // A = I
   // At = L - jitter * Linv^T  (= K0 L^-T, because K0 = L L^T - jitter I); L, Linv lower triangular
   virtual void at_from_linv(int nb, int n, Mat L, Mat Linv, double jitter, Mat At) = 0;
-  virtual void diag_init(int nb, int n, const double* nu, double add, Mat dst) = 0;   // dst = diag(nu + add)
+  virtual void diag_init(int nb, int n, const real* nu, double add, Mat dst) = 0;   // dst = diag(nu + add)
   // compact copy-out of the real N x N part: mode 0 as is, 1 symmetric from the lower triangle,
   // 2 lower triangle with zeros above
-  virtual void extract(int nb, int N, Mat src, double* dst, int mode) = 0;
-  virtual void extract_vec(int nb, int N, int Np, const double* src, double* dst) = 0;
+  virtual void extract(int nb, int N, Mat src, real* dst, int mode) = 0;
+  virtual void extract_vec(int nb, int N, int Np, const real* src, real* dst) = 0;
   virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii
   virtual void hyp_out(int nb, const double* ustate, double* hyp) = 0;  // softplus(u) -> (variance, lengthscale)
 
@@ -147,4 +158,4 @@ struct Prims {
   virtual void read_back(const double* dev, double* host, int n) = 0;
 };
 
-}  // namespace bayens
+}  // namespace BAYENS_NS

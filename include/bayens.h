@@ -100,6 +100,16 @@ int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         double* mu, double* cov, double* cov_chol, double* logdet,
                         double* hyp, double* loss_trace, int* info, double* ll_basis);
 
+/* The same fit in fp32 (BASELINE.json config 3; SURVEY 8(b) "dtype enum"): float arrays in and out, fp32 storage
+ * and fp32 MFMA products throughout.  Kept in fp64: the hyper-parameters and Adam state (hyp), the squared
+ * distances inside the kernel matrix, the 64x64 diagonal-block factorisations, and every reduction (logdet,
+ * loss_trace).  Parity bar: 1e-3 relative against the fp64 oracle (BASELINE.json). */
+int bayens_gp_fit_batch_f32(bayens_ctx* ctx, int loc, int B, int N, int R,
+                            const float* X, const float* y_mean, const float* y_var,
+                            int kernel, int n_iters, double gamma, double lr, double jitter,
+                            float* mu, float* cov, float* cov_chol, double* logdet,
+                            double* hyp, double* loss_trace, int* info, float* ll_basis);
+
 /* Distribution.__post_init__ for a caller-supplied full covariance (ensembles/data.py:38-39):
  * chol [B][N][N] lower, logdet [B]; with mu [B][N] given, ll_basis [B][2][N] as above (both may be NULL). */
 int bayens_mvn_factor_batch(bayens_ctx* ctx, int loc, int B, int N, const double* cov, const double* mu,

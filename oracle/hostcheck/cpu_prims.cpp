@@ -381,6 +381,7 @@ struct HostWs {
     ws.y = alloc((size_t)nb * Np); ws.nu = alloc((size_t)nb * Np); ws.muvec = alloc((size_t)nb * Np);
     ws.uvec = alloc((size_t)nb * Np);
     ws.ustate = alloc((size_t)nb * 8);
+    ws.dscratch = alloc((size_t)nb * 4);
     info.assign(nb, 0); ws.info = info.data();
   }
 };

@@ -148,6 +148,45 @@ def test_loss_trace_is_the_references_training_loss(ctx, M, N, T):
         ctx.set_groups(1)
 
 
+F32_TOL = 1e-3      # BASELINE.json: 1e-3 relative for fp32
+
+
+@pytest.mark.parametrize("M,N,R,T,kernel", [
+    (2, 86, 5, 2, 0), (3, 24, 3, 2, 0), (2, 200, 8, 2, 1),      # config 3 names Matern-5/2 (kernel id 1)
+    (1, 64, 2, 1, 0), (2, 7, 3, 2, 0), (1, 130, 4, 27, 0), (1, 1000, 8, 2, 1)])
+def test_fp32_fit_against_the_fp64_oracle(ctx, M, N, R, T, kernel):
+    """bayens_gp_fit_batch_f32 (fp32 storage and MFMA products) vs the float64 oracle: 1e-3 relative."""
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=11)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T, kernel=kernel, dtype=np.float32, want_loss=True)
+    assert not out["info"].any()
+    assert out["mu"].dtype == np.float32 and out["cov"].dtype == np.float32 and out["hyp"].dtype == np.float64
+    with threadpool_limits(1):
+        for m in range(M):
+            mo, co, ho, lo = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel, loss_every=25)
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m].astype(np.float64), mo) < F32_TOL
+            assert relerr(out["cov"][m].astype(np.float64), co) < F32_TOL
+            assert relerr(out["chol"][m].astype(np.float64), Lc) < F32_TOL
+            assert abs(out["logdet"][m] - ld) < F32_TOL * max(1.0, abs(ld))
+            assert relerr(out["hyp"][m], ho) < F32_TOL
+            assert np.allclose(out["loss"][m], lo, rtol=F32_TOL)
+            import scipy.linalg as sla
+            assert relerr(out["basis"][m, 1].astype(np.float64), sla.solve_triangular(Lc, mo, lower=True)) < 10 * F32_TOL
+
+
+def test_fp32_full_size_is_finite_and_close_to_fp64(ctx):
+    """Config 3 size (32-member batch trimmed to 4 for the test's run time): fp32 against the fp64 device path."""
+    data, _ = go.synthetic_ensemble(4, 2000, R=8, seed=2)
+    X, y, nu = member_inputs(data)
+    o32 = ctx.gp_fit_batch(X, y, nu, 2, kernel=1, dtype=np.float32)
+    o64 = ctx.gp_fit_batch(X, y, nu, 2, kernel=1)
+    assert not o32["info"].any() and np.isfinite(o32["cov"]).all()
+    assert relerr(o32["mu"].astype(np.float64), o64["mu"]) < F32_TOL
+    assert relerr(o32["cov"].astype(np.float64), o64["cov"]) < F32_TOL
+    assert relerr(o32["hyp"], o64["hyp"]) < F32_TOL
+
+
 def test_member_groups_do_not_change_the_result(ctx):
     data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
     X, y, nu = member_inputs(data)
