@@ -73,6 +73,8 @@ def load():
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_extract_diag_f32.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_widen_f32.argtypes = [_vp, C.c_int, C.c_size_t, _vp, _vp]
     lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_weights_normalise.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]
@@ -373,8 +375,12 @@ class Context:
                                                _ptr(mu_out), _ptr(var_out), C.byref(bad)))
         return bad.value
 
-    def extract_diag_dev(self, B, N, cov, var):
-        self._check(self.lib.bayens_extract_diag(self.h, DEVICE, B, N, _ptr(cov), _ptr(var)))
+    def extract_diag_dev(self, B, N, cov, var, f32=False):
+        fn = self.lib.bayens_extract_diag_f32 if f32 else self.lib.bayens_extract_diag
+        self._check(fn(self.h, DEVICE, B, N, _ptr(cov), _ptr(var)))
+
+    def widen_f32_dev(self, n, src, dst):
+        self._check(self.lib.bayens_widen_f32(self.h, DEVICE, int(n), _ptr(src), _ptr(dst)))
 
     def weighted_model_mean(self, data, R, w):
         data, w = _f64(data), _f64(w)

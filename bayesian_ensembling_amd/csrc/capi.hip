@@ -300,13 +300,9 @@ int bayens_profile_enable(bayens_ctx* c, int on) {
     BAYENS_HIP(hipDeviceSynchronize());
     std::vector<HipPrims*> all = c->gprims;
     all.push_back(c->prims);
-    for (HipPrims* hp : all) {
-      KernelProfile& p = hp->prof;
-      for (auto& e : p.events) { p.pool.push_back(e.a); p.pool.push_back(e.b); }
-      p.events.clear();
-      for (int f = 0; f < FAM_COUNT; ++f) { p.flop[f] = 0; p.bytes[f] = 0; p.launches[f] = 0; }
-      p.enabled = on != 0;
-    }
+    for (HipPrims* hp : all) hp->profile_reset(on != 0);
+    if (on && !c->f32) c->f32 = bayens_f32_create(c->stream);
+    if (c->f32) bayens_f32_profile_enable(c->f32, on);
     return 0;
   });
 }
@@ -317,6 +313,7 @@ int bayens_profile_bytes(bayens_ctx* c, int family, double* bytes) {
     all.push_back(c->prims);
     double b = 0;
     for (HipPrims* hp : all) b += hp->prof.bytes[family];
+    if (c->f32) bayens_f32_profile_add(c->f32, family, nullptr, nullptr, nullptr, &b);
     *bytes = b;
     return 0;
   });
@@ -330,16 +327,11 @@ int bayens_profile_get(bayens_ctx* c, int family, double* ms, double* flop, long
     double tot = 0, fl = 0;
     long n = 0;
     for (HipPrims* hp : all) {
-      KernelProfile& p = hp->prof;
-      for (auto& e : p.events) {
-        if (family != FAM_ALL && e.fam != family) continue;
-        float f = 0;
-        BAYENS_HIP(hipEventElapsedTime(&f, e.a, e.b));
-        tot += f;
-      }
-      fl += p.flop[family];
-      n += p.launches[family];
+      tot += hp->profile_ms(family);
+      fl += hp->prof.flop[family];
+      n += hp->prof.launches[family];
     }
+    if (c->f32) bayens_f32_profile_add(c->f32, family, &tot, &fl, &n, nullptr);
     if (ms) *ms = tot;
     if (flop) *flop = fl;
     if (launches) *launches = n;
@@ -511,6 +503,45 @@ int bayens_extract_diag(bayens_ctx* c, int loc, int B, int N, const double* cov,
     const double* dcov = st.in(cov, (size_t)B * N * N);
     double* dvar = st.out(var, (size_t)B * N);
     c->prims->extract_diag(B, N, dcov, dvar);
+    st.finish();
+    return 0;
+  });
+}
+
+// fp32 posteriors feed the (fp64) weight and scheme kernels through these two widening copies: the [M][N] tables
+// are a few MB, the covariance itself is never widened
+namespace {
+__global__ void widen_f32_kernel(size_t n, const float* src, double* dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i];
+}
+__global__ void extract_diag_f32_kernel(int N, const float* cov, double* var) {
+  const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) var[(size_t)b * N + i] = (double)cov[((size_t)b * N + i) * N + i];
+}
+}  // namespace
+
+int bayens_widen_f32(bayens_ctx* c, int loc, size_t n, const float* src, double* dst) {
+  return guarded(c, [&]() {
+    if (n == 0 || !src || !dst) return fail(c, BAYENS_E_ARG, "widen_f32: bad argument");
+    Stage st(c, loc);
+    const float* ds = st.in(src, n);
+    double* dd = st.out(dst, n);
+    hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, ds, dd);
+    BAYENS_HIP(hipGetLastError());
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_extract_diag_f32(bayens_ctx* c, int loc, int B, int N, const float* cov, double* var) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || !cov || !var) return fail(c, BAYENS_E_ARG, "extract_diag_f32: bad argument");
+    Stage st(c, loc);
+    const float* dcov = st.in(cov, (size_t)B * N * N);
+    double* dvar = st.out(var, (size_t)B * N);
+    hipLaunchKernelGGL(extract_diag_f32_kernel, dim3((N + 255) / 256, B), dim3(256), 0, c->stream, N, dcov, dvar);
+    BAYENS_HIP(hipGetLastError());
     st.finish();
     return 0;
   });

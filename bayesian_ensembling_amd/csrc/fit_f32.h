@@ -25,3 +25,6 @@ void* bayens_f32_create(hipStream_t stream);
 void bayens_f32_destroy(void* state);
 // returns 0 or a HIP error code / negative argument error; message in *err
 int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err);
+// per-launch accounting of the fp32 instance (same families as bayens_profile_get)
+void bayens_f32_profile_enable(void* state, int on);
+void bayens_f32_profile_add(void* state, int family, double* ms, double* flop, long* launches, double* bytes);

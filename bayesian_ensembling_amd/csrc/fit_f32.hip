@@ -27,6 +27,15 @@ using namespace bayens_f32;
 void* bayens_f32_create(hipStream_t stream) { return new State(stream); }
 void bayens_f32_destroy(void* state) { delete static_cast<State*>(state); }
 
+void bayens_f32_profile_enable(void* state, int on) { static_cast<State*>(state)->prims.profile_reset(on != 0); }
+void bayens_f32_profile_add(void* state, int family, double* ms, double* flop, long* launches, double* bytes) {
+  HipPrims& p = static_cast<State*>(state)->prims;
+  if (ms) *ms += p.profile_ms(family);
+  if (flop) *flop += p.prof.flop[family];
+  if (launches) *launches += p.prof.launches[family];
+  if (bytes) *bytes += p.prof.bytes[family];
+}
+
 int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
   State* st = static_cast<State*>(state);
   try {

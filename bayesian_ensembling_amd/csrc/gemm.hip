@@ -25,6 +25,7 @@ typedef real v2d __attribute__((ext_vector_type(2)));
 // B[l>>4][l&15]); the fp32 form issues in 32 cycles instead of 64.  Only the accumulator layout differs:
 // fp64 keeps rows (l>>4) + 4r in register r, fp32 rows 4(l>>4) + r.
 #ifdef BAYENS_F32
+#define gemm_f64_mfma gemm_f32_mfma   /* the kernel symbol of the fp32 instance: bayens_f32::gemm_f32_mfma<TA,TB> */
 #define BAYENS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 __device__ __forceinline__ int acc_row(int lk, int r) { return 4 * lk + r; }
 #else

@@ -51,6 +51,24 @@ struct HipPrims : Prims {
   bool in_side = false, side_pending = false;
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
+  // per-launch accounting on/off: recorded events go back to the pool, counters are cleared
+  void profile_reset(bool on) {
+    prof.enabled = on;
+    for (auto& e : prof.events) { prof.pool.push_back(e.a); prof.pool.push_back(e.b); }
+    prof.events.clear();
+    for (int f = 0; f < FAM_COUNT; ++f) { prof.flop[f] = 0; prof.bytes[f] = 0; prof.launches[f] = 0; }
+  }
+  // summed device ms of the recorded launches of one family (FAM_ALL: all); the device must be idle
+  double profile_ms(int family) {
+    double tot = 0;
+    for (auto& e : prof.events) {
+      if (family != FAM_ALL && e.fam != family) continue;
+      float f = 0;
+      BAYENS_HIP(hipEventElapsedTime(&f, e.a, e.b));
+      tot += f;
+    }
+    return tot;
+  }
   ~HipPrims() override;
   void ensure_scratch(int nb, int Np, int R4);
   void mark(const char* phase) override;

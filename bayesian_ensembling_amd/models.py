@@ -25,14 +25,20 @@ def _blank_array(process_model):
 
 
 class GPDTW1D:
-    def __init__(self, name: str = "GPRegressor", target="mean", kernel: str = "matern32") -> None:
+    def __init__(self, name: str = "GPRegressor", target="mean", kernel: str = "matern32",
+                 dtype: str = "float64") -> None:
         """target: 'mean' (mean over realisations - the documented stand-in for the reference's tslearn DTW
         barycentre, which cannot be reproduced offline), 'dba' (DTW barycentre averaging with the semantics of the
         reference's own ensembles/dtwa.py performDBA, 10 iterations, on the GPU) or a callable (R,N) ndarray -> (N,).
-        kernel: 'matern32' is the reference kernel (models.py:186); 'matern52' / 'rbf' are extensions."""
+        kernel: 'matern32' is the reference kernel (models.py:186); 'matern52' / 'rbf' are extensions.
+        dtype: 'float64' is the reference precision (ensembles/__init__.py:10); 'float32' runs the fit in fp32
+        (bayens_gp_fit_batch_f32, BASELINE config 3: 1e-3 relative) and hands the posterior back as float64."""
         self.name = name
         self.target = target
         self.kernel = kernel
+        if np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("dtype must be 'float64' or 'float32'")
+        self.dtype = np.dtype(dtype)
 
     # -- the boundary inputs (models.py:175-182) ------------------------------------------------------
     def _prologue(self, process_model):
@@ -71,7 +77,10 @@ class GPDTW1D:
                 y = np.stack([pro[i][1] for i in idxs])
             nu = np.stack([pro[i][2] for i in idxs])
             out = ctx.gp_fit_batch(X, y, nu, n_optim_nits, kernel=_lib.KERNEL_IDS[self.kernel],
-                                   want_loss=bool(progress_bar))
+                                   want_loss=bool(progress_bar), dtype=self.dtype)
+            if self.dtype != np.float64:   # the containers, weights and schemes work on float64 tables
+                out = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
+                       for k, v in out.items()}
             for j, i in enumerate(idxs):
                 dists[i] = Distribution(mu=out["mu"][j], covariance=out["cov"][j],
                                         dim_array=_blank_array(process_models[i]),

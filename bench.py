@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet); = 32 FLOP/clk/SIMD x 1024 SIMD x 2.4 GHz
+F32_MFMA_PEAK_TFLOPS = 157.3  # fp32 matrix peak: the 16x16x4 fp32 MFMA issues in half the cycles of the fp64 one
 
 
 def fit_flops(N, R, T):
@@ -68,6 +69,8 @@ def main():
     ap.add_argument("--nits", type=int, default=2, help="n_optim_nits (2 = the reference's test scale)")
     ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf"])
     ap.add_argument("--groups", type=int, default=1, help="member groups = HIP streams per fit batch")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="f64 = the reference precision (the headline); f32 = BASELINE config 3 (1e-3 parity bar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-members", type=int, default=2)
     args = ap.parse_args()
@@ -99,28 +102,38 @@ def main():
     M, N, R, T, R_obs = args.members, args.timesteps, args.realisations, args.nits, 3
     kid = _lib.KERNEL_IDS[args.kernel]
     X, y, nu, obs = make_inputs(M, N, R, R_obs, seed=0xB4E5 + rank)
-    dX, dy, dnu, dobs = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu), ctx.to_device(obs)
-    dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
-    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
+    f32 = args.dtype == "f32"
+    dt = np.float32 if f32 else np.float64
+    dX, dy, dnu, dobs = ctx.to_device(X, dt), ctx.to_device(y, dt), ctx.to_device(nu, dt), ctx.to_device(obs)
+    dmu, dcov, dchol = ctx.empty((M, N), dt), ctx.empty((M, N, N), dt), ctx.empty((M, N, N), dt)
+    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N), dt)
+    if f32:    # the weight / scheme kernels take fp64 tables: the fp32 posterior's [M][N] rows are widened (a few MB)
+        dmu64, dbasis64 = ctx.empty((M, N)), ctx.empty((M, 2, N))
+    else:
+        dmu64, dbasis64 = dmu, dbasis
     Mtot = M * world
     dll_loc, dvar_loc = ctx.empty((M, N)), ctx.empty((M, N))
     if host:
         dll_all, dmean_all, dvar_all = ctx.empty((Mtot, N)), ctx.empty((Mtot, N)), ctx.empty((Mtot, N))
     else:
-        dll_all, dmean_all, dvar_all = dll_loc, dmu, dvar_loc
+        dll_all, dmean_all, dvar_all = dll_loc, dmu64, dvar_loc
     dw, dbmu, dbvar = ctx.empty((Mtot, N)), ctx.empty((N,)), ctx.empty((N,))
 
     def fit():
-        return ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, kernel=kid, basis=dbasis)
+        return ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, kernel=kid, basis=dbasis,
+                                    f32=f32)
 
     def weighted_posterior():
         # LogLikelihoodWeight rows + posterior marginals of the local members, exchange of the [M, N] rows over
         # RCCL (log-likelihoods, means, variances), then normalisation over ALL members and the barycentre
-        ctx.loglik_rows_basis_dev(M, N, R_obs, dbasis, dld, dobs, dll_loc)
-        ctx.extract_diag_dev(M, N, dcov, dvar_loc)
+        if f32:
+            ctx.widen_f32_dev(M * 2 * N, dbasis, dbasis64)
+            ctx.widen_f32_dev(M * N, dmu, dmu64)
+        ctx.loglik_rows_basis_dev(M, N, R_obs, dbasis64, dld, dobs, dll_loc)
+        ctx.extract_diag_dev(M, N, dcov, dvar_loc, f32=f32)
         if host:
             ctx.allgather_rows(dll_loc, dll_all, M, N)
-            ctx.allgather_rows(dmu, dmean_all, M, N)
+            ctx.allgather_rows(dmu64, dmean_all, M, N)
             ctx.allgather_rows(dvar_loc, dvar_all, M, N)
         ctx.weights_normalise_dev(Mtot, N, dll_all, 1e-3, dw)
         return ctx.barycentre_dev(Mtot, N, dw, dmean_all, dvar_all, dbmu, dbvar)
@@ -156,7 +169,9 @@ def main():
         ctx.timer_start(); fit(); fit_ms = ctx.timer_stop()
         ctx.timer_start(); bad = weighted_posterior(); wp_ms = ctx.timer_stop()
         # the stand-alone entry point (mu, chol, logdet -> rows: two triangular solves per member) for comparison
-        ctx.timer_start(); ctx.loglik_rows_dev(M, N, R_obs, dmu, dchol, dld, dobs, dw); ll_chol_ms = ctx.timer_stop()
+        ll_chol_ms = None
+        if not f32:
+            ctx.timer_start(); ctx.loglik_rows_dev(M, N, R_obs, dmu, dchol, dld, dobs, dw); ll_chol_ms = ctx.timer_stop()
         ctx.set_groups(1)                 # per-kernel durations are only meaningful when kernels do not overlap
         fit()
         ctx.timer_start(); fit(); fit_serial_ms = ctx.timer_stop()
@@ -173,30 +188,33 @@ def main():
         ctx.set_groups(args.groups)
         gemm_tflops = p["flop"] / (p["ms"] * 1e-3) / 1e12
         traffic = None     # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
+        peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
+        kname = "bayens_f32::gemm_f32_mfma" if f32 else "bayens::gemm_f64_mfma"
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if files:
+            if files and not f32:    # (the PMC passes were collected on the fp64 instance)
                 traffic = round(json.load(open(files[-1]))["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
         group_tflops = p_all["flop"] / (p_all["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "bayens::gemm_f64_mfma<false, true>", "achieved": round(gemm_tflops, 3),
-                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / F64_MFMA_PEAK_TFLOPS, 4),
+        roof = {"bound": "mfma", "kernel": kname + "<false, true>", "achieved": round(gemm_tflops, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
                 "launches_per_fit_batch": p["launches"],
                 "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
                 "kernel_ms_per_fit_batch": round(p["ms"], 3),
-                "gemm_group": {"kernels": "gemm_f64_mfma<*>, gemm_panel64, trsm_panel_kernel",
-                               "achieved": round(group_tflops, 3), "frac": round(group_tflops / F64_MFMA_PEAK_TFLOPS, 4),
+                "gemm_group": {"kernels": kname.split("::")[1] + "<*>, gemm_panel64, trsm_panel_kernel",
+                               "achieved": round(group_tflops, 3), "frac": round(group_tflops / peak, 4),
                                "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
                 "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
                 "note": "HIP events around every launch of the kernel in one fit batch, one stream (no overlap); "
                         "traffic = HBM bytes per launch of this kernel from the rocprofv3 --pmc passes in profiles/*_pmc_traffic.json"}
         extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
                  "fit_algorithmic_tflops": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12, 3),
-                 "fit_frac_of_f64_peak": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
-                 "barycentre_not_converged": int(bad), "loglik_rows_from_chol_ms": round(ll_chol_ms, 4)}
+                 "fit_frac_of_mfma_peak": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12 / peak, 4),
+                 "barycentre_not_converged": int(bad),
+                 "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N, R, T, args.cpu_members)
     if host:
@@ -209,7 +227,7 @@ def main():
             "metric": "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step ensemble",
             "value": round(value, 3), "unit": "member-fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{M}-member x {N}-timestep synthetic ensemble per GPU, R={R} realisations, "
                                    f"{args.kernel} VGP fit (n_optim_nits={T}) + LogLikelihoodWeight(c=1e-3) + Barycentre",
                        "members_per_gpu": M, "timesteps": N, "realisations": R, "n_optim_nits": T,

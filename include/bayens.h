@@ -117,6 +117,9 @@ int bayens_mvn_factor_batch(bayens_ctx* ctx, int loc, int B, int N, const double
 
 /* _dist.variance() of a full-covariance posterior = diag(cov)  (ensemble_scheme.py:64-65, weights.py:311) */
 int bayens_extract_diag(bayens_ctx* ctx, int loc, int B, int N, const double* cov, double* var);
+/* fp32 posteriors (bayens_gp_fit_batch_f32) into the fp64 tables the weight / scheme entry points take */
+int bayens_extract_diag_f32(bayens_ctx* ctx, int loc, int B, int N, const float* cov, double* var);
+int bayens_widen_f32(bayens_ctx* ctx, int loc, size_t n, const float* src, double* dst);
 
 /* LogLikelihoodWeight._compute inner loops, MVN branch (ensembles/weights.py:88-104):
  * ll_mean[b][t] = mean_r log N(obs[r][t] * 1_N ; mu_b, cov_b)   obs [R_obs][N] */

@@ -152,6 +152,36 @@ def _collection(n_models, obs_n_reals, N=24, R=3, seed=0):
     return mc, es.ProcessModel(da(obs_n_reals), "obs")
 
 
+def test_config3_fp32_matern52_with_wasserstein_weights(ctx):
+    """BASELINE config 3 through the plug-in API: Matern-5/2 posteriors fitted in fp32, ModelSimilarityWeight
+    (temporal and single) and the log-likelihood weights + barycentre, against the float64 oracle: 1e-3 relative."""
+    M, N, R = 4, 120, 6
+    data, obs = go.synthetic_ensemble(M, N, R=R, R_obs=3, seed=9)
+    time = np.arange(N)
+
+    def pm(arr, name):
+        return es.ProcessModel(DataArray(arr, ("realisation", "time"), {"realisation": np.arange(arr.shape[0]), "time": time}), name)
+    mc = es.ModelCollection([pm(data[m], f"m{m}") for m in range(M)])
+    mc.fit(model=es.GPDTW1D(kernel="matern52", dtype="float32"), n_optim_nits=2, progress_bar=False)
+    mus, covs = [], []
+    for m in range(M):
+        X, y, nu = go.prologue(data[m])
+        mo, co, _ = go.gp_fit(X, y, nu, 2, kernel=1)
+        mus.append(mo); covs.append(co)
+        assert relerr(mc.models[m].distribution.mean.values, mo) < 1e-3
+    var = np.stack([np.diag(c) for c in covs])
+    w_t = es.ModelSimilarityWeight()(mc, pm(obs, "obs"), mode="temporal")
+    assert relerr(w_t.values, go.w2_weights_temporal(np.stack(mus), var)) < 1e-3
+    w_s = es.ModelSimilarityWeight()(mc, pm(obs, "obs"), mode="single")
+    assert relerr(np.asarray(w_s.values).reshape(-1), go.w2_weights_single(mus, covs)[0]) < 1e-3
+    w_l = es.LogLikelihoodWeight()(mc, pm(obs, "obs"), standardisation_constant=1e-3)
+    ll = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(mus[m], *go.mvn_factor(covs[m]), obs)) for m in range(M)])
+    assert relerr(w_l.values, go.loglik_weights(ll, 1e-3)[0]) < 1e-3
+    post = es.Barycentre()(mc, w_l)
+    bm, bv, _ = go.barycentre(go.loglik_weights(ll, 1e-3)[0], np.stack(mus), var)
+    assert relerr(post.mean.values, bm) < 1e-3
+
+
 @pytest.mark.parametrize("obs_n_reals", [1, 2, 5, 10])
 @pytest.mark.parametrize("n_models", [2, 5, 10])
 def test_weightings_api(ctx, n_models, obs_n_reals):
