@@ -35,7 +35,15 @@ __device__ __forceinline__ int acc_row(int lk, int r) { return lk + 4 * r; }
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 2;
+// One K step stages 8 staging vectors of k per operand row.  VEC = 2 in both precisions (K step 16).  Measured for
+// fp32 with VEC = 4 (16-byte loads, K step 32, row pad 4): 84 TFLOP/s against 91 with VEC = 2 - with 4-byte
+// elements the k-major image is read with 4-way bank conflicts at either pad and the wider step only lengthens the
+// exposed prologue of the short products; the fp32 instance needs operand-native LDS images, not a
+// wider step.
+constexpr int VEC = 2;                               // elements per staging vector
+constexpr int BM = 128, BN = 128, BK = 8 * VEC;
+constexpr int LDT = BM + (VEC == 2 ? 2 : 4);         // k-major LDS row: pad keeps vector stores 16-byte aligned
+typedef real vst __attribute__((ext_vector_type(VEC)));
 
 struct GemmArgs {
   const real* A;
@@ -49,43 +57,44 @@ struct GemmArgs {
   int tiles_m, tiles_n, total, nb;
 };
 
-// Stage one 128 x 16 operand tile into registers.  TR=true: memory is [row][k] (k contiguous) -> each
-// thread takes 4 x (2 consecutive k) of rows r, r+32, r+64, r+96; TR=false: memory is [k][row] -> each
-// thread takes 4 x (2 consecutive rows) of k-rows kr, kr+4, kr+8, kr+12.
+// Stage one 128 x BK operand tile into registers.  TR=true: memory is [row][k] (k contiguous) -> each thread
+// takes 4 x (VEC consecutive k) of rows r, r+32, r+64, r+96; TR=false: memory is [k][row] -> each thread takes
+// 4 x (VEC consecutive rows) of 4 k-rows.
 template <bool TR>
 __device__ __forceinline__ void stage_load(const real* base, int ld, int row0, int nrows,
-                                           int k0, int tid, v2d (&reg)[4]) {
+                                           int k0, int tid, vst (&reg)[4]) {
   if (TR) {
     const int kp = tid & 7, r = tid >> 3;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       int rr = row0 + r + 32 * p;
       rr = rr < nrows ? rr : nrows - 1;
-      reg[p] = *reinterpret_cast<const v2d*>(base + (long)rr * ld + k0 + 2 * kp);
+      reg[p] = *reinterpret_cast<const vst*>(base + (long)rr * ld + k0 + VEC * kp);
     }
   } else {
-    const int c2 = tid & 63, kr = tid >> 6;
-    int cc = row0 + 2 * c2;
-    cc = cc < nrows - 1 ? cc : nrows - 2;
+    constexpr int CW = BM / VEC;                 // threads per k-row
+    const int c = tid % CW, kr = tid / CW;
+    int cc = row0 + VEC * c;
+    cc = cc <= nrows - VEC ? cc : nrows - VEC;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-      reg[p] = *reinterpret_cast<const v2d*>(base + (long)(k0 + kr + 4 * p) * ld + cc);
+      reg[p] = *reinterpret_cast<const vst*>(base + (long)(k0 + kr + (256 / CW) * p) * ld + cc);
   }
 }
 
 template <bool TR>
-__device__ __forceinline__ void stage_store(real (*tile)[LDT], int tid, const v2d (&reg)[4]) {
+__device__ __forceinline__ void stage_store(real (*tile)[LDT], int tid, const vst (&reg)[4]) {
   if (TR) {
     const int kp = tid & 7, r = tid >> 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      tile[2 * kp][r + 32 * p] = reg[p].x;
-      tile[2 * kp + 1][r + 32 * p] = reg[p].y;
-    }
-  } else {
-    const int c2 = tid & 63, kr = tid >> 6;
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<v2d*>(&tile[kr + 4 * p][2 * c2]) = reg[p];
+      for (int e = 0; e < VEC; ++e) tile[VEC * kp + e][r + 32 * p] = reg[p][e];
+  } else {
+    constexpr int CW = BM / VEC;
+    const int c = tid % CW, kr = tid / CW;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<vst*>(&tile[kr + (256 / CW) * p][VEC * c]) = reg[p];
   }
 }
 
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0, 0, 0, 0};
 
-  v2d ra[4], rb[4];
+  vst ra[4], rb[4];
   if (nk > 0) {
     stage_load<!TA>(A, g.lda, row0, g.m, kbeg, tid, ra);
     stage_load<TB>(B, g.ldb, col0, g.n, kbeg, tid, rb);
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     }
     if (active) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < BK / 4; ++kk) {
         real a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = As[buf][kk * 4 + lk][wm * 64 + i * 16 + lr];
@@ -467,8 +476,8 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
   g.tiles_n = (n + BN - 1) / BN;
   g.total = g.tiles_m * g.tiles_n * nb;
   g.nb = nb;
-  if ((m % 64) || (n % 64) || (k % 64) || (A.ld & 1) || (B.ld & 1))
-    throw HipError{-1, "gemm: dimensions must be multiples of 64 and leading dimensions even"};
+  if ((m % 64) || (n % 64) || (k % 64) || (A.ld % VEC) || (B.ld % VEC))
+    throw HipError{-1, "gemm: dimensions must be multiples of 64 and leading dimensions 16-byte multiples"};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof.enabled) {
     auto take = [&]() {
