@@ -100,6 +100,8 @@ __device__ __forceinline__ void stage_store(real (*tile)[LDT], int tid, const vs
   }
 }
 
+// Register budget: two workgroups per CU (<=256 VGPR).  The fp32 instance needs 135 and runs three per CU; holding
+// it to 128 VGPR for four per CU was measured slower (85 against 91 TFLOP/s).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) real As[2][BK][LDT];
