@@ -8,6 +8,8 @@
 namespace BAYENS_NS {
 
 constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve takes
+constexpr int SEQ_MAX_NP = 512;  // members up to this padded size are launch-bound: iteration bodies are recorded
+constexpr int SEQ_MIN_ITERS = 4; // ... when there are enough repetitions to pay for recording
 
 static inline int split_point(int n) {
   int leaves = n / LEAF;
@@ -183,13 +185,24 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);
   }
 
+  // Small members are launch-bound (an iteration is ~100 launches of a few microseconds): there the two halves of the
+  // iteration body - everything up to the Cholesky of K, and the rest - are recorded once and replayed (hipGraph on
+  // the device back end).  The loss sample, when one is due, sits between the two halves.
+  P.seq_reset(Np <= SEQ_MAX_NP && fp.n_iters >= SEQ_MIN_ITERS, nb, Np, fp.R);
+  const bool in_pad = Np > N;
+  const int mrows = in_pad ? Np : Np + LEAF;
+  Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
   for (int it = 0; it < fp.n_iters; ++it) {
-    // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
-    P.mark("kmat");
-    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
-    P.mark("potrf K");
-    potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    if (!P.seq_begin(0)) {
+      // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
+      P.mark("kmat");
+      P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
+      P.mark("potrf K");
+      potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+      P.seq_end(0);
+    }
     if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY);
+    if (P.seq_begin(1)) continue;
     P.mark("Lam update");
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
@@ -203,9 +216,6 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
     // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.  The variational mean
     // m = S theta1 rides through the same two solves as one extra row (the last padded row when there is padding).
-    const bool in_pad = Np > N;
-    const int mrows = in_pad ? Np : Np + LEAF;
-    Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
     P.aug_set(nb, Np, trow, ws.theta1, in_pad ? 0 : LEAF - 1);
     trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);            // [G; theta1^T] C^-T
     trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);     // ... C^-1
@@ -221,7 +231,9 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1, false);        // Kbar^T = W^T L^-1
     P.mark("grad+adam");
     P.grad_adam(nb, N, Np, fp.R, X, fp.kernel, ws.T1, ws.ustate, fp.lr);
+    P.seq_end(1);
   }
+  P.seq_reset(false, nb, Np, fp.R);
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)

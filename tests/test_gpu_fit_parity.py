@@ -187,6 +187,17 @@ def test_fp32_full_size_is_finite_and_close_to_fp64(ctx):
     assert relerr(o32["hyp"], o64["hyp"]) < F32_TOL
 
 
+def test_recorded_iteration_replay_is_bit_identical(ctx, monkeypatch):
+    """BAYENS_SEQ=1: the optimiser iteration recorded into a hipGraph and replayed gives the same bits."""
+    data, _ = go.synthetic_ensemble(3, 150, R=4, seed=8)
+    X, y, nu = member_inputs(data)
+    plain = ctx.gp_fit_batch(X, y, nu, 30, want_loss=True)
+    monkeypatch.setenv("BAYENS_SEQ", "1")
+    replay = ctx.gp_fit_batch(X, y, nu, 30, want_loss=True)
+    for k in ("mu", "cov", "chol", "logdet", "hyp", "basis", "loss"):
+        assert np.array_equal(plain[k], replay[k]), k
+
+
 def test_member_groups_do_not_change_the_result(ctx):
     data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
     X, y, nu = member_inputs(data)
