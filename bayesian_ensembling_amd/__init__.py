@@ -8,6 +8,7 @@ from .dtwa import performDBA
 from .ensemble_scheme import AbstractEnsembleScheme, Barycentre, MultiModelMean, WeightedModelMean
 from .labelled import DataArray, concat
 from .models import GPDTW1D, MeanFieldApproximation
+from .nc4 import open_dataarray
 from .weights import (AbstractWeight, CRPSWeight, InverseSquareWeight, KSDWeight, LogLikelihoodWeight,
                       ModelSimilarityWeight, UniformWeight)
 from . import distributions

@@ -152,6 +152,22 @@ def _collection(n_models, obs_n_reals, N=24, R=3, seed=0):
     return mc, es.ProcessModel(da(obs_n_reals), "obs")
 
 
+def test_reference_data_file_to_posterior(ctx):
+    """File -> ProcessModel -> annual anomaly -> GPDTW1D posterior, from one of the reference's own data files
+    (N=86 annual steps, 6 realisations), against the oracle."""
+    import os
+    from conftest import GOLDEN
+    da = es.open_dataarray(os.path.join(GOLDEN, "nc_reference_IPSL_ssp126_gmst.nc"))
+    clim = np.stack([da.values[:, m::12].mean(axis=1) for m in range(12)]).mean(axis=1)
+    anom = es.ProcessModel(da, "IPSL-CM6A-LR").calculate_anomaly(climatology=clim, resample_freq="Y")
+    mc = es.ModelCollection([anom])
+    mc.fit(model=es.GPDTW1D(), n_optim_nits=30, progress_bar=False)
+    X, y, nu = go.prologue(np.asarray(anom.model_data.values))
+    mo, co, _ = go.gp_fit(X, y, nu, 30)
+    dist = mc.models[0].distribution
+    assert relerr(dist.mean.values, mo) < 1e-8 and relerr(np.asarray(dist.covariance), co) < 1e-8
+
+
 def test_config3_fp32_matern52_with_wasserstein_weights(ctx):
     """BASELINE config 3 through the plug-in API: Matern-5/2 posteriors fitted in fp32, ModelSimilarityWeight
     (temporal and single) and the log-likelihood weights + barycentre, against the float64 oracle: 1e-3 relative."""
