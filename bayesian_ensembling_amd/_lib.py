@@ -91,6 +91,7 @@ def load():
     lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.bayens_comm_destroy.argtypes = [_vp]
     lib.bayens_allgather_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
+    lib.bayens_w2_single_sharded.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_test_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
     lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
@@ -440,6 +441,10 @@ class Context:
 
     def comm_destroy(self):
         self._check(self.lib.bayens_comm_destroy(self.h))
+
+    def w2_single_sharded_dev(self, M, N, mu, chol, w, D):
+        """All members' mu / chol resident on every rank; pairs dealt over the communicator's ranks."""
+        self._check(self.lib.bayens_w2_single_sharded(self.h, DEVICE, M, N, _ptr(mu), _ptr(chol), _ptr(w), _ptr(D)))
 
     def allgather_rows(self, local, all_, M_loc, P):
         self._check(self.lib.bayens_allgather_rows(self.h, _ptr(local), _ptr(all_), M_loc, P))

@@ -25,6 +25,8 @@ typedef ncclResult_t (*pfn_ncclGetUniqueId)(ncclUniqueId*);
 typedef ncclResult_t (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
 typedef ncclResult_t (*pfn_ncclCommDestroy)(ncclComm_t);
 typedef ncclResult_t (*pfn_ncclAllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*pfn_ncclAllReduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, ncclComm_t,
+                                          hipStream_t);
 typedef const char* (*pfn_ncclGetErrorString)(ncclResult_t);
 constexpr int NCCL_FLOAT64 = 8;
 
@@ -34,6 +36,7 @@ struct RcclApi {
   pfn_ncclCommInitRank CommInitRank = nullptr;
   pfn_ncclCommDestroy CommDestroy = nullptr;
   pfn_ncclAllGather AllGather = nullptr;
+  pfn_ncclAllReduce AllReduce = nullptr;
   pfn_ncclGetErrorString GetErrorString = nullptr;
   bool load(std::string& err) {
     if (handle) return true;
@@ -47,6 +50,7 @@ struct RcclApi {
     CommInitRank = (pfn_ncclCommInitRank)dlsym(handle, "ncclCommInitRank");
     CommDestroy = (pfn_ncclCommDestroy)dlsym(handle, "ncclCommDestroy");
     AllGather = (pfn_ncclAllGather)dlsym(handle, "ncclAllGather");
+    AllReduce = (pfn_ncclAllReduce)dlsym(handle, "ncclAllReduce");
     GetErrorString = (pfn_ncclGetErrorString)dlsym(handle, "ncclGetErrorString");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather) { err = "librccl: missing symbols"; return false; }
     return true;
@@ -625,10 +629,18 @@ int bayens_w2_temporal(bayens_ctx* c, int loc, int M, int P, const double* mean,
   });
 }
 
-int bayens_w2_single(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, const double* sd,
-                     double* w, double* D) {
+namespace {
+// All-pairs Gaussian W2 table and weights.  sharded: every rank holds ALL M members (the caller all-gathered the
+// factors); the M(M-1)/2 polar iterations are dealt over the ranks of the communicator by anchor member i (i mod
+// nranks: the batches of an anchor have M-1-i pairs, so interleaving balances the work), each rank fills its part of
+// the nuclear-norm table and one ncclAllReduce (sum, M*M doubles) completes it everywhere.
+int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, const double* sd,
+                   double* w, double* D, bool sharded) {
   return guarded(c, [&]() {
     if (M <= 0 || N <= 0 || !mu || !w || (!chol && !sd)) return fail(c, BAYENS_E_ARG, "w2_single: bad argument");
+    if (sharded && (!c->comm || !c->rccl.AllReduce))
+      return fail(c, BAYENS_E_COMM, "w2_single_sharded: communicator not initialised");
+    const int nranks = sharded ? c->nranks : 1, rank = sharded ? c->rank : 0;
     Stage st(c, loc);
     const double* dmu = st.in(mu, (size_t)M * N);
     double* dw = st.out(w, (size_t)M);
@@ -656,12 +668,18 @@ int bayens_w2_single(bayens_ctx* c, int loc, int M, int N, const double* mu, con
     double* rel = st.scratch<double>((size_t)M);
     P.dot_all(M, Np, Lp, Lp, tr);                      // tr S_i = ||L_i||_F^2 (+ padding)
     P.pair_terms(M, N, dmu, nullptr, gap, nullptr);
+    if (sharded) BAYENS_HIP(hipMemsetAsync(nuc, 0, (size_t)M * M * sizeof(double), c->stream));
     for (int i = 0; i + 1 < M; ++i) {
+      if (i % nranks != rank) continue;
       const int nb = M - 1 - i;
       FitWorkspace wsi = ws;
       wsi.nb = nb;
       nuclear_norms(P, wsi, nb, Mat{Lpad + (size_t)i * Np * Np, Np, 0}, Mat{Lpad + (size_t)(i + 1) * Np * Np, Np, (long)Np * Np},
                     nuc + (size_t)i * M + i + 1, rel);
+    }
+    if (sharded) {
+      ncclResult_t r = c->rccl.AllReduce(nuc, nuc, (size_t)M * M, NCCL_FLOAT64, 0 /* ncclSum */, c->comm, c->stream);
+      if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllReduce failed");
     }
     // remove the identity padding's share (Np - N) from traces and nuclear norms: both enter as tr_i + tr_j - 2 nuc,
     // i.e. 2 (Np - N) - 2 (Np - N) = 0, so no correction is needed in D.
@@ -673,6 +691,18 @@ int bayens_w2_single(bayens_ctx* c, int loc, int M, int N, const double* mu, con
       if (hinfo[b]) return fail(c, BAYENS_E_NOTPD, "w2_single: a polar-iteration Cholesky failed");
     return 0;
   });
+}
+}  // namespace
+
+int bayens_w2_single(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, const double* sd,
+                     double* w, double* D) {
+  return w2_single_impl(c, loc, M, N, mu, chol, sd, w, D, false);
+}
+
+int bayens_w2_single_sharded(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, double* w,
+                             double* D) {
+  if (!chol) return c ? fail(c, BAYENS_E_ARG, "w2_single_sharded: needs the Cholesky factors") : BAYENS_E_ARG;
+  return w2_single_impl(c, loc, M, N, mu, chol, nullptr, w, D, true);
 }
 
 int bayens_barycentre(bayens_ctx* c, int loc, int M, int P, const double* w, const double* mean, const double* var,

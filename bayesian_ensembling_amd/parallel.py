@@ -99,3 +99,23 @@ def weighted_posterior_sharded(n_members, local_ll, local_mean, local_var, gathe
     w = normalise(np.ascontiguousarray(ll), c_std)
     mu, v, _ = barycentre(w, np.ascontiguousarray(mean), np.ascontiguousarray(var))
     return w, mu, v
+
+
+def w2_single_sharded(ctx, n_members, mu_local, chol_local):
+    """ModelSimilarityWeight(mode='single') over member-sharded posteriors.
+
+    mu_local [M_loc, N] / chol_local [M_loc, N, N]: this rank's members (equal M_loc on every rank, contiguous blocks in
+    rank order).  The factors are all-gathered over RCCL (M_loc * N^2 doubles per rank), every rank runs the polar
+    iterations of its share of the pairs and an all-reduce completes the distance table.  Returns (w [M], D [M, M])."""
+    M_loc, N = mu_local.shape
+    d_mu_loc, d_ch_loc = ctx.to_device(mu_local), ctx.to_device(chol_local)
+    d_mu, d_ch = ctx.empty((n_members, N)), ctx.empty((n_members, N, N))
+    d_w, d_D = ctx.empty((n_members,)), ctx.empty((n_members, n_members))
+    try:
+        ctx.allgather_rows(d_mu_loc, d_mu, M_loc, N)
+        ctx.allgather_rows(d_ch_loc, d_ch, M_loc, N * N)
+        ctx.w2_single_sharded_dev(n_members, N, d_mu, d_ch, d_w, d_D)
+        return d_w.download(), d_D.download()
+    finally:
+        for d in (d_mu_loc, d_ch_loc, d_mu, d_ch, d_w, d_D):
+            d.free()

@@ -152,6 +152,11 @@ int bayens_w2_temporal(bayens_ctx* ctx, int loc, int M, int P, const double* mea
  * (dx.Normal): pass chol = NULL and sd [M][N] = the distributions' stddev().  D [M][M] may be NULL. */
 int bayens_w2_single(bayens_ctx* ctx, int loc, int M, int N, const double* mu, const double* chol,
                      const double* sd, double* w, double* D);
+/* The same table with the M(M-1)/2 polar iterations dealt over the ranks of the communicator (bayens_comm_init):
+ * every rank passes ALL M members (all-gather the factors first, e.g. bayens_allgather_rows with P = N*N), computes
+ * the pairs of its anchor members, and one ncclAllReduce completes the table on every rank. */
+int bayens_w2_single_sharded(bayens_ctx* ctx, int loc, int M, int N, const double* mu, const double* chol,
+                             double* w, double* D);
 
 /* Barycentre._compute (ensembles/ensemble_scheme.py:52-78) + gaussian_barycentre
  * (ensembles/wasserstein.py:61-100).  w, mean, var [M][P]; mu_out, var_out [P] (var_out = sigma*^2). */

@@ -75,6 +75,20 @@ def test_w2_single_full_covariance(ctx, M, N):
     assert np.allclose(D, D.T, rtol=0, atol=0)
 
 
+def test_w2_single_sharded_over_a_one_rank_communicator(ctx):
+    """The multi-GPU form of mode='single' (all-gather of the factors, pairs dealt over ranks, all-reduce of the
+    nuclear-norm table) on a communicator of one rank: must equal the single-GPU table exactly."""
+    from bayesian_ensembling_amd import parallel
+    data, _, out = _posteriors(ctx, 4, 50, R=5, seed=13)
+    w_ref, D_ref = ctx.w2_single(out["mu"], chol=out["chol"])
+    ctx.comm_init(0, 1, ctx.comm_unique_id())
+    try:
+        w, D = parallel.w2_single_sharded(ctx, 4, out["mu"], out["chol"])
+    finally:
+        ctx.comm_destroy()
+    assert np.array_equal(D, D_ref) and np.array_equal(w, w_ref)
+
+
 def test_w2_single_diagonal_posteriors(ctx):
     rng = np.random.default_rng(12)
     M, N = 4, 33
