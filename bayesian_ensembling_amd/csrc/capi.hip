@@ -194,7 +194,7 @@ struct Stage {
 
 extern "C" {
 
-const char* bayens_version(void) { return "bayens 0.1 (gfx950, fp64 MFMA)"; }
+const char* bayens_version(void) { return "bayens 0.1 (gfx950, fp64 + fp32 MFMA)"; }
 
 int bayens_device_count(int* count) {
   if (!count) return BAYENS_E_ARG;

@@ -276,7 +276,7 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
                   double tol, int max_iters) {
   const int Np = ws.Np;
   const long is = ws.inv_stride();
-  Mat M = ws.K0, X = ws.Lb, Z = ws.Cb, T = ws.T1;
+  Mat M = ws.W0, X = ws.Lb, Z = ws.Cb, T = ws.T1;
   // M = L_j^T L_i  (both lower triangular: k >= max(i0, j0))
   P.gemm(nb, Np, Np, Np, 1.0, Lj, Li, 0.0, M, GEMM_TA | GEMM_KTRIM_TN_LOWER, 0.0);
   P.frob_normalise(nb, Np, M, X);

@@ -18,7 +18,8 @@ inline int pad_to_leaf(int n) { return ((n + LEAF - 1) / LEAF) * LEAF; }
 // Device workspace for a batch of nb members of padded size Np (all pointers device pointers).
 struct FitWorkspace {
   int nb = 0, Np = 0;
-  Mat K0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each; T1 carries LEAF extra rows ([nb][Np+64][Np])
+  Mat W0, Lb, Lam, Cb, T1, T2;     // [nb][Np][Np] each; T1 carries LEAF extra rows ([nb][Np+64][Np]); W0: spare
+                                   // (the fit never stores K0; the polar iteration of nuclear_norms uses it)
   real* invL = nullptr;          // [nb][Np/64][64][64]
   real* invC = nullptr;
   real* theta1 = nullptr;        // [nb][Np]
@@ -72,7 +73,7 @@ void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* cho
 // W2 distance of ensembles/wasserstein.py:41-45: tr (S_i^1/2 S_j S_i^1/2)^1/2 = sum of singular values of L_j^T L_i.
 // Polar factor by the Cholesky form of the QDWH iteration (Nakatsukasa, Bai, Gygi 2010): per step one X^T X,
 // one Cholesky and two triangular solves, all on the existing batched primitives; <= max_iters steps, stops when
-// every pair moved by less than tol.  Lj: the nb factors L_j (padded, lower).  Uses ws.K0 (M), ws.Lb (X), ws.Cb (Z),
+// every pair moved by less than tol.  Lj: the nb factors L_j (padded, lower).  Uses ws.W0 (M), ws.Lb (X), ws.Cb (Z),
 // ws.T1 (T).  nuc: device [nb], scratch_rel: device [nb].  Returns the number of iterations taken.
 int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel,
                   double ell0 = 1e-7, double tol = 1e-13, int max_iters = 16);

@@ -32,7 +32,7 @@ struct DeviceWs {
     w.nb = nb; w.Np = Np;
     const size_t msz = (size_t)nb * Np * Np * sizeof(real);
     auto mat = [&]() { return Mat{(real*)dalloc(msz), Np, (long)Np * Np}; };
-    w.K0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T2 = mat();
+    w.W0 = mat(); w.Lb = mat(); w.Lam = mat(); w.Cb = mat(); w.T2 = mat();
     w.T1 = Mat{(real*)dalloc((size_t)nb * (Np + LEAF) * Np * sizeof(real)), Np, (long)(Np + LEAF) * Np};
     const size_t isz = (size_t)nb * Np * LEAF * sizeof(real);
     w.invL = (real*)dalloc(isz); w.invC = (real*)dalloc(isz);
@@ -48,7 +48,7 @@ struct DeviceWs {
   FitWorkspace view(int b0, int nb) const {
     FitWorkspace v = ws;
     v.nb = nb;
-    for (Mat* m : {&v.K0, &v.Lb, &v.Lam, &v.Cb, &v.T1, &v.T2}) m->p += (long)b0 * m->stride;
+    for (Mat* m : {&v.W0, &v.Lb, &v.Lam, &v.Cb, &v.T1, &v.T2}) m->p += (long)b0 * m->stride;
     const long is = v.inv_stride();
     v.invL += b0 * is; v.invC += b0 * is;
     for (real** p : {&v.theta1, &v.mvec, &v.avec, &v.y, &v.nu, &v.muvec, &v.uvec}) *p += (long)b0 * v.Np;

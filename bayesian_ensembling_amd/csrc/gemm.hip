@@ -328,20 +328,9 @@ __device__ __forceinline__ void stage64_store(real (*tile)[SLD], int tid, const 
   }
 }
 
-// acc[jt] += sgn * As[wave rows][:] * Bs[:][16 jt ..]   (Bs is the k-major image B[k][col])
-__device__ __forceinline__ void panel_mma(v4d (&acc)[4], const real (*As)[SLD], const real (*Bs)[SLD], int wave,
-                                          int lane, double sgn) {
-  const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    const real a = (real)sgn * As[wave * 16 + lr][kk * 4 + lk];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
-  }
-}
-
-// the same product with the inverted diagonal block as B operand: op(M_j) is triangular, so the 4x16 sub-tiles of
-// Bs that are entirely zero are skipped (40 of 64 MFMAs remain).  UPPER: Bs[k][col] != 0 only for k <= col.
+// acc[jt] += As[wave rows][:] * Bs[:][16 jt ..] (Bs the k-major image B[k][col]) for the product with the inverted
+// diagonal block: op(M_j) is triangular, so the 4x16 sub-tiles of Bs that are entirely zero are skipped (40 of 64
+// MFMAs remain).  UPPER: Bs[k][col] != 0 only for k <= col.
 template <bool UPPER>
 __device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const real (*As)[SLD], const real (*Bs)[SLD], int wave,
                                               int lane) {

@@ -374,7 +374,7 @@ struct HostWs {
   HostWs(int nb, int Np) {
     ws.nb = nb; ws.Np = Np;
     auto mat = [&]() { return Mat{alloc((size_t)nb * Np * Np), Np, (long)Np * Np}; };
-    ws.K0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T2 = mat();
+    ws.W0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T2 = mat();
     ws.T1 = Mat{alloc((size_t)nb * (Np + LEAF) * Np), Np, (long)(Np + LEAF) * Np};
     ws.invL = alloc((size_t)nb * Np * LEAF); ws.invC = alloc((size_t)nb * Np * LEAF);
     ws.theta1 = alloc((size_t)nb * Np); ws.mvec = alloc((size_t)nb * Np); ws.avec = alloc((size_t)nb * Np);
