@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   }
   if (bi == bj) return;
   __syncthreads();
-  for (int q = 0; q < 16; ++q) {                           // mirrored block (bj, bi): G^T into Gfull, zeros into Cb
+  for (int q = 0; q < 16; ++q) {                           // mirrored block (bj, bi): G^T into Gfull
     const int r = r0 + 4 * q;
     const long off = (long)(bj * 64 + r) * Gfull.ld + bi * 64 + c;
     gf[off] = tile[c][r];
-    cb[(long)(bj * 64 + r) * Cb.ld + bi * 64 + c] = 0.0;
   }
+  // (Cb's blocks above the block diagonal are left alone: the factorisation and the solves with C never read them)
 }
 
 // At = L - jitter * Linv^T (prims.h at_from_linv): output tile (bi, bj) needs L's tile (bi, bj) (lower part) and
@@ -705,9 +705,21 @@ __global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* 
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const real* l = L.p + b * L.stride;
-  double s = 0.0;
-  for (int i = j0 + w; i < n; i += 4)
-    s += l[(long)i * L.ld + j0 + c] * (y[(long)b * n + i] / nu[(long)b * n + i]);
+  // rows j0 .. n-1 of the 64-column strip, 4 waves x 4 rows in flight (the strip of column block 0 is n rows long:
+  // one row per wave and trip leaves the load latency exposed)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const long vb = (long)b * n;
+  int i = j0 + w;
+  for (; i + 12 < n; i += 16) {
+    const double a0 = l[(long)i * L.ld + j0 + c], a1 = l[(long)(i + 4) * L.ld + j0 + c];
+    const double a2 = l[(long)(i + 8) * L.ld + j0 + c], a3 = l[(long)(i + 12) * L.ld + j0 + c];
+    s0 += a0 * ((double)y[vb + i] / (double)nu[vb + i]);
+    s1 += a1 * ((double)y[vb + i + 4] / (double)nu[vb + i + 4]);
+    s2 += a2 * ((double)y[vb + i + 8] / (double)nu[vb + i + 8]);
+    s3 += a3 * ((double)y[vb + i + 12] / (double)nu[vb + i + 12]);
+  }
+  for (; i < n; i += 4) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (double)nu[vb + i]);
+  const double s = (s0 + s1) + (s2 + s3);
   part[w][c] = s;
   __syncthreads();
   if (w == 0) {

@@ -110,7 +110,8 @@ struct Prims {
   virtual void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                        real* out) = 0;
   // natural-gradient precision update from G = L^T D L (lower 64-blocks of G valid):
-  //   Lam <- (1-gamma) Lam + gamma (I + G) on the lower triangle;  Cb <- tril(Lam) with zeros above;
+  //   Lam <- (1-gamma) Lam + gamma (I + G) on the lower triangle;  Cb <- tril(Lam) (zeros above the diagonal inside
+  //   the diagonal 64-blocks; the blocks above the block diagonal are neither written nor ever read);
   //   Gfull <- G mirrored to a full symmetric matrix
   virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) = 0;
   // Phi(L^T Lbar) without forming Lbar: for i >= j, (L^T Lbar)_ij = u_i m_j + (G S)_ij with u = L^T D (L m - y)

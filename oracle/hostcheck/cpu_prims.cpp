@@ -192,7 +192,9 @@ struct CpuPrims : Prims {
           double& lam = Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j];
           lam = (1 - gamma) * lam + gamma * (g + (i == j ? 1.0 : 0.0));
           Cb.p[b * Cb.stride + (size_t)i * Cb.ld + j] = lam;
-          if (j < i) Cb.p[b * Cb.stride + (size_t)j * Cb.ld + i] = 0.0;
+          // zeros only inside the diagonal 64-block; blocks above the block diagonal are never read (and stay
+          // NaN-poisoned here, so a read would show up)
+          if (j < i && j / 64 == i / 64) Cb.p[b * Cb.stride + (size_t)j * Cb.ld + i] = 0.0;
           Gfull.p[b * Gfull.stride + (size_t)i * Gfull.ld + j] = g;
           Gfull.p[b * Gfull.stride + (size_t)j * Gfull.ld + i] = g;
         }
