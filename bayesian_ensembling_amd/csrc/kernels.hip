@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, real* inv, lo
 // Two leaves in one launch: the 128x128 diagonal block [A11 .; A21 A22] is factored by one workgroup -
 // leaf(A11), L21 = A21 inv(L11)^T, A22 -= L21 L21^T, leaf(A22) - with L21 held in LDS between the steps.
 // Replaces four launches (leaf, 64x64 panel solve, 64^3 update, leaf) at the bottom of the blocked Cholesky.
-__global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, real* inv, long inv_stride, int pivot_base,
+__global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv, long inv_stride, int pivot_base,
                                                           int* info) {
   // two 64x64 images rotate through the four steps (77 KB in all, so two workgroups - or one beside two GEMM
   // workgroups - fit a CU):   leaf 1: S = U, Mi = V | panel: T = U, Mi = V | update: T = U, S = V | leaf 2: S = V, Mi = U
@@ -642,18 +642,28 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, real* inv, l
   const long ld = Ablk.ld;
   real* a = Ablk.p + b * Ablk.stride;
   real* iv = inv + b * inv_stride;
+  // A21 is requested up front (it does not depend on the first leaf) and A22 right after the first leaf, BEFORE that
+  // leaf's result stores: a load issued behind stores waits for them too (one in-order counter), and both blocks
+  // are only needed a phase later.  (Requesting A22 up front as well costs 64 more live VGPRs - one workgroup per CU
+  // instead of two, which large batches of small members notice.)
+  real p21[16], p22[16];
   for (int q = 0; q < 16; ++q) {
     const int r = rq + 4 * q;
     U[r][c] = c <= r ? a[r * ld + c] : 0.0;
     V[r][c] = 0.0;
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p21[q] = a[(64 + rq + 4 * q) * ld + c];
   __syncthreads();
   leaf_factor(U, V, Tt, b, tid, pivot_base, info, stamps);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p22[q] = a[(64 + rq + 4 * q) * ld + 64 + c];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {   // L11, inv(L11) out; A21 in (each thread replaces only its own elements of U)
     const int r = rq + 4 * q;
     a[r * ld + c] = c <= r ? U[r][c] : 0.0;
     iv[r * 64 + c] = c <= r ? V[r][c] : 0.0;
-    U[r][c] = a[(64 + r) * ld + c];
+    U[r][c] = p21[q];
   }
   __syncthreads();
   {   // L21 = A21 inv(L11)^T: wave w owns rows 16w..16w+15 (reads and writes only those rows of U)
@@ -667,10 +677,11 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(Mat Ablk, real* inv, l
     for (int J = 0; J < 4; ++J) tile_store(U, 16 * wave, 16 * J, lane, acc[J]);
   }
   __syncthreads();
+#pragma unroll
   for (int q = 0; q < 16; ++q) {   // L21 out; A22 (lower) into V, whose inverse image is no longer needed
     const int r = rq + 4 * q;
     a[(64 + r) * ld + c] = U[r][c];
-    V[r][c] = c <= r ? a[(64 + r) * ld + 64 + c] : 0.0;
+    V[r][c] = c <= r ? (double)p22[q] : 0.0;
   }
   __syncthreads();
   {   // A22 -= L21 L21^T on the lower 16-block pairs
