@@ -196,17 +196,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile.  The C values of one 16-row
   // strip (16 per lane) are all loaded before the first store of that strip: with a runtime ldc the compiler
   // cannot reorder a load past an earlier store, and one exposed memory round trip per element (64 per lane)
-  // cost ~27 us per tile; batched, it is one round trip per strip.
+  // cost ~27 us per tile.  The strips are software-pipelined: the loads of strip i+1 are issued before the stores
+  // of strip i, because a load queued behind stores waits for them too (one in-order memory counter).
+  real cv[2][4][4];
+  auto load_strip = [&](int i, real (&dst)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
+  };
+  const bool accumulate = g.beta != 0.0;
+  if (accumulate) load_strip(0, cv[0]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    real cv[4][4];
-    if (g.beta != 0.0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cv[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
-    }
+    if (accumulate && i + 1 < 4) load_strip(i + 1, cv[(i + 1) & 1]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = col0 + wn * 64 + j * 16 + lr;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wm * 64 + i * 16 + acc_row(lk, r);
         double v = g.alpha * acc[i][j][r];
-        if (g.beta != 0.0) v += g.beta * cv[j][r];
+        if (accumulate) v += g.beta * cv[i & 1][j][r];
         if (row == col) v += g.diag_add;
         C[(long)row * g.ldc + col] = v;
       }
