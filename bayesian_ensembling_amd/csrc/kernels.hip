@@ -60,12 +60,16 @@ __global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const real* s = src.p + b * src.stride;
   real* d = dst.p + b * dst.stride;
-#pragma unroll 4
+  // (loads first, stores after: src and dst may alias as far as the compiler knows, and a load behind a store
+  //  waits for it - one in-order memory counter)
+  real v[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    double v = (mode == 1 && j > i) ? 0.0 : s[(long)i * src.ld + j];
-    d[(long)i * dst.ld + j] = v;
+    v[q] = (mode == 1 && j > i) ? (real)0 : s[(long)i * src.ld + j];
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
 }
 
 __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
@@ -123,10 +127,15 @@ __global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const real* s = src.p + b * src.stride;
   real* d = dst.p + b * dst.stride;
+  real v[16], w[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    d[(long)i * dst.ld + j] = s[(long)i * src.ld + j] * (1.0 / sqrt(nu[(long)b * n + i]));
+    v[q] = s[(long)i * src.ld + j];
+    w[q] = nu[(long)b * n + i];
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q] * (1.0 / sqrt((double)w[q]));
 }
 
 // Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
@@ -137,21 +146,24 @@ __global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, 
   const real* g = GS.p + b * GS.stride;
   real* p = Phi.p + b * Phi.stride;
   const double mj = mvec[(long)b * n + j];
+  double v[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    double v = 0.0;
+    v[q] = 0.0;
     if (j <= i) {
-      v = u[(long)b * n + i] * mj + g[(long)i * GS.ld + j];
-      if (j == i) v *= 0.5;
+      v[q] = u[(long)b * n + i] * mj + g[(long)i * GS.ld + j];
+      if (j == i) v[q] *= 0.5;
     }
-    p[(long)i * Phi.ld + j] = v;
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[(long)(i0 + 4 * q) * Phi.ld + j] = v[q];
 }
 
 // natural-gradient precision update (prims.h lam_update): one workgroup per lower 64x64 block (bi >= bj) updates
 // Lam, seeds Cb (lower; the mirrored block of Cb is cleared) and mirrors G into the full symmetric Gfull.
 __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
-  __shared__ double tile[64][65];
+  __shared__ real tile[64][65];
   const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi) return;
   const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
@@ -159,14 +171,24 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   real* lam = Lam.p + b * Lam.stride;
   real* cb = Cb.p + b * Cb.stride;
   real* gf = Gfull.p + b * Gfull.stride;
+  const int j = bj * 64 + c;
+  // all loads of the tile first, then all stores: the matrices may alias as far as the compiler knows, so a load
+  // written after a store stays behind it - and then waits for it (one in-order memory counter)
+  real gv[16], lv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = bi * 64 + r0 + 4 * q;
+    gv[q] = g[(long)i * G.ld + j];
+    lv[q] = j <= i ? lam[(long)i * Lam.ld + j] : (real)0;
+  }
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
-    const int i = bi * 64 + r, j = bj * 64 + c;
-    const double gv = g[(long)i * G.ld + j];
-    tile[r][c] = gv;
-    gf[(long)i * Gfull.ld + j] = gv;                      // the diagonal block of G is complete (both triangles)
+    const int i = bi * 64 + r;
+    tile[r][c] = gv[q];
+    gf[(long)i * Gfull.ld + j] = gv[q];                   // the diagonal block of G is complete (both triangles)
     if (j <= i) {
-      const double v = (1.0 - gamma) * lam[(long)i * Lam.ld + j] + gamma * (gv + (i == j ? 1.0 : 0.0));
+      const double v = (1.0 - gamma) * lv[q] + gamma * (gv[q] + (i == j ? 1.0 : 0.0));
       lam[(long)i * Lam.ld + j] = v;
       cb[(long)i * Cb.ld + j] = v;
     } else {
@@ -175,10 +197,10 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   }
   if (bi == bj) return;
   __syncthreads();
+#pragma unroll
   for (int q = 0; q < 16; ++q) {                           // mirrored block (bj, bi): G^T into Gfull
     const int r = r0 + 4 * q;
-    const long off = (long)(bj * 64 + r) * Gfull.ld + bi * 64 + c;
-    gf[off] = tile[c][r];
+    gf[(long)(bj * 64 + r) * Gfull.ld + bi * 64 + c] = tile[c][r];
   }
   // (Cb's blocks above the block diagonal are left alone: the factorisation and the solves with C never read them)
 }
@@ -200,12 +222,18 @@ __global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Lin
     }
     __syncthreads();
   }
+  double lv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = bi * 64 + r0 + 4 * q, j = bj * 64 + c;
+    lv[q] = j <= i ? (double)l[(long)i * L.ld + j] : 0.0;
+  }
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
     const int i = bi * 64 + r, j = bj * 64 + c;
-    const double lv = j <= i ? l[(long)i * L.ld + j] : 0.0;
     const double lit = bj >= bi ? tile[c][r] : 0.0;        // (Linv^T)_ij = Linv_ji
-    at[(long)i * At.ld + j] = lv - jitter * lit;
+    at[(long)i * At.ld + j] = lv[q] - jitter * lit;
   }
 }
 
@@ -227,14 +255,21 @@ __global__ void extract_kernel(int N, Mat src, real* dst, int mode) {
   const real* s = src.p + b * src.stride;
   real* d = dst + (long)b * N * N;
   if (j >= N) return;
+  real v[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    if (i >= N) break;
-    double v;
-    if (mode == 0) v = s[(long)i * src.ld + j];
-    else if (mode == 1) v = j <= i ? s[(long)i * src.ld + j] : s[(long)j * src.ld + i];
-    else v = j <= i ? s[(long)i * src.ld + j] : 0.0;
-    d[(long)i * N + j] = v;
+    v[q] = 0;
+    if (i < N) {
+      if (mode == 0) v[q] = s[(long)i * src.ld + j];
+      else if (mode == 1) v[q] = j <= i ? s[(long)i * src.ld + j] : s[(long)j * src.ld + i];
+      else v[q] = j <= i ? s[(long)i * src.ld + j] : (real)0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    if (i < N) d[(long)i * N + j] = v[q];
   }
 }
 
