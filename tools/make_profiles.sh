@@ -13,7 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pf.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pw.log 2>&1 || exit 4
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pm.log 2>&1 || exit 5
 cd $R
+python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util.txt > /dev/null
+rm -rf $OUT/${TAG}_pm
 KT=$(find $OUT/${TAG}_kt -name "*.db" | head -1); PF=$(find $OUT/${TAG}_pf -name "*.db" | head -1); PW=$(find $OUT/${TAG}_pw -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $KT $OUT/${TAG}_kernel_stats_final.txt > /dev/null
 python3 tools/rocpd_pmc.py $PF FETCH_SIZE $OUT/${TAG}_pmc_fetch_size.txt > /dev/null
