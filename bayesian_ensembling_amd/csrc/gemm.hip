@@ -335,7 +335,9 @@ __device__ __forceinline__ void stage64_store(real (*tile)[SLD], int tid, const 
 // acc[jt] += As[wave rows][:] * Bs[:][16 jt ..] (Bs the k-major image B[k][col]) for the product with the inverted
 // diagonal block: op(M_j) is triangular, so the 4x16 sub-tiles of Bs that are entirely zero are skipped (40 of 64
 // MFMAs remain).  UPPER: Bs[k][col] != 0 only for k <= col.
-template <bool UPPER>
+// BT: Bs holds the transpose of the B operand (Bs[col][k]) and is read with swapped indices - a 2-way-conflicted read
+// instead of the 4-way-conflicted scalar transposing store that would build the k-major image.
+template <bool UPPER, bool BT>
 __device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const real (*As)[SLD], const real (*Bs)[SLD], int wave,
                                               int lane) {
   const int lr = lane & 15, lk = lane >> 4;
@@ -345,7 +347,7 @@ __device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const real (*As)[SL
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool live = UPPER ? (kk < 4 * j + 4) : (kk >= 4 * j);
-      if (live) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
+      if (live) acc[j] = BAYENS_MFMA16(a, BT ? Bs[j * 16 + lr][kk * 4 + lk] : Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
     }
   }
 }
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) As[wave * 16 + acc_row(lk, r)][jt * 16 + lr] = acc[jt][r];
         }
-        stage64_store<!RLN>(Bs, tid, rb);
+        stage64_store<false>(Bs, tid, rb);       // as stored; RLT reads it transposed (see panel_mma_tri)
         __syncthreads();
         // next tile's global load flies while this product runs
         if (t < s) tile_load(s, t + 1, rb);
@@ -412,13 +414,14 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
           for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
-              acc[jt] = BAYENS_MFMA16(xf[t][kk], Bs[kk * 4 + lk][jt * 16 + lr], acc[jt]);
+              acc[jt] = BAYENS_MFMA16(xf[t][kk], RLN ? Bs[kk * 4 + lk][jt * 16 + lr] : Bs[jt * 16 + lr][kk * 4 + lk],
+                                      acc[jt]);
         } else {
           // X_j = acc op(M_j); RLT: Bs[k][col] = M_j[col][k] (upper triangular image); RLN: Bs[k][col] = M_j[k][col]
           v4d x[4];
 #pragma unroll
           for (int jt = 0; jt < 4; ++jt) x[jt] = v4d{0, 0, 0, 0};
-          panel_mma_tri<!RLN>(x, As, Bs, wave, lane);
+          panel_mma_tri<!RLN, !RLN>(x, As, Bs, wave, lane);
 #pragma unroll
           for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
