@@ -73,6 +73,8 @@ def load():
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_weighted_posterior.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                              C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_int)]
     lib.bayens_extract_diag_f32.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_widen_f32.argtypes = [_vp, C.c_int, C.c_size_t, _vp, _vp]
     lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
@@ -375,6 +377,24 @@ class Context:
         self._check(self.lib.bayens_barycentre(self.h, DEVICE, M, P, _ptr(w), _ptr(mean), _ptr(var), tol, init_var,
                                                _ptr(mu_out), _ptr(var_out), C.byref(bad)))
         return bad.value
+
+    def weighted_posterior_dev(self, M, N, R_obs, basis, logdet, obs, mu, cov, w, mu_out, var_out, c_std=1e-3,
+                               tol=1e-6, init_var=1.0):
+        """LogLikelihoodWeight + Barycentre on resident buffers, one host synchronisation; returns n_not_converged."""
+        bad = C.c_int()
+        self._check(self.lib.bayens_weighted_posterior(self.h, DEVICE, M, N, R_obs, _ptr(basis), _ptr(logdet), _ptr(obs),
+                                                       _ptr(mu), _ptr(cov), c_std, tol, init_var, _ptr(w), _ptr(mu_out),
+                                                       _ptr(var_out), C.byref(bad)))
+        return bad.value
+
+    def weighted_posterior(self, basis, logdet, obs, mu, cov, c_std=1e-3, tol=1e-6, init_var=1.0):
+        basis, logdet, obs, mu, cov = _f64(basis), _f64(logdet), _f64(obs), _f64(mu), _f64(cov)
+        M, N = mu.shape
+        w, bm, bv, bad = np.empty((M, N)), np.empty(N), np.empty(N), C.c_int()
+        self._check(self.lib.bayens_weighted_posterior(self.h, HOST, M, N, obs.shape[0], _ptr(basis), _ptr(logdet),
+                                                       _ptr(obs), _ptr(mu), _ptr(cov), c_std, tol, init_var, _ptr(w),
+                                                       _ptr(bm), _ptr(bv), C.byref(bad)))
+        return w, bm, bv, bad.value
 
     def extract_diag_dev(self, B, N, cov, var, f32=False):
         fn = self.lib.bayens_extract_diag_f32 if f32 else self.lib.bayens_extract_diag

@@ -601,6 +601,45 @@ int bayens_normal_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, c
   });
 }
 
+// LogLikelihoodWeight + Barycentre in one call (the reference's weighted posterior: weights.py:87-131 followed by
+// ensemble_scheme.py:43-81): log-likelihood rows from the basis, the members' marginal variances from their
+// covariances, normalisation over the members and the barycentre fixed point are queued back to back and the host
+// waits once - the four separate entry points synchronise after each step.
+int bayens_weighted_posterior(bayens_ctx* c, int loc, int M, int N, int R_obs, const double* ll_basis,
+                              const double* logdet, const double* obs, const double* mu, const double* cov,
+                              double c_std, double tol, double init_var, double* w, double* mu_out, double* var_out,
+                              int* n_not_converged) {
+  return guarded(c, [&]() {
+    if (M <= 0 || N <= 0 || R_obs <= 0 || !ll_basis || !logdet || !obs || !mu || !cov || !mu_out || !var_out)
+      return fail(c, BAYENS_E_ARG, "weighted_posterior: bad argument");
+    Stage st(c, loc);
+    const double* db = st.in(ll_basis, (size_t)M * 2 * N);
+    const double* dld = st.in(logdet, (size_t)M);
+    const double* dobs = st.in(obs, (size_t)R_obs * N);
+    const double* dmu = st.in(mu, (size_t)M * N);
+    const double* dcov = st.in(cov, (size_t)M * N * N);
+    double* dw = w ? st.out(w, (size_t)M * N) : nullptr;
+    double* dbm = st.out(mu_out, (size_t)N);
+    double* dbv = st.out(var_out, (size_t)N);
+    // persistent scratch: [M*3] dots | [1] not-converged count (as int) | [M*N] ll rows | [M*N] variances | [M*N] w
+    double* sc = c->small_scratch((size_t)M * 3 + 2 + 3 * (size_t)M * N);
+    double* dots = sc;
+    int* dbad = reinterpret_cast<int*>(sc + (size_t)M * 3);
+    double* dll = sc + (size_t)M * 3 + 2;
+    double* dvar = dll + (size_t)M * N;
+    if (!dw) dw = dvar + (size_t)M * N;
+    c->prims->loglik_rows_basis(M, N, R_obs, db, dld, dobs, dll, dots);
+    c->prims->extract_diag(M, N, dcov, dvar);
+    c->prims->weights_normalise(M, N, dll, c_std, dw, nullptr);
+    c->prims->barycentre(M, N, dw, dmu, dvar, tol, init_var, dbm, dbv, dbad);
+    int hbad = 0;
+    BAYENS_HIP(hipMemcpyAsync(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    if (n_not_converged) *n_not_converged = hbad;
+    return 0;
+  });
+}
+
 int bayens_weights_normalise(bayens_ctx* c, int loc, int M, int P, const double* ll_mean, double c_std, int scheme,
                              double* w, double* w_raw) {
   return guarded(c, [&]() {

@@ -126,6 +126,9 @@ def main():
     def weighted_posterior():
         # LogLikelihoodWeight rows + posterior marginals of the local members, exchange of the [M, N] rows over
         # RCCL (log-likelihoods, means, variances), then normalisation over ALL members and the barycentre
+        if not host and not f32:
+            # one GPU: the whole weighted posterior (rows -> weights -> barycentre) is one entry point, one host wait
+            return ctx.weighted_posterior_dev(M, N, R_obs, dbasis, dld, dobs, dmu, dcov, dw, dbmu, dbvar, c_std=1e-3)
         if f32:
             ctx.widen_f32_dev(M * 2 * N, dbasis, dbasis64)
             ctx.widen_f32_dev(M * N, dmu, dmu64)

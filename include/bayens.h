@@ -135,6 +135,14 @@ int bayens_loglik_rows_basis(bayens_ctx* ctx, int loc, int B, int N, int R_obs, 
 int bayens_normal_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                               const double* mu, const double* scale, const double* obs, double* ll_mean);
 
+/* LogLikelihoodWeight + Barycentre in one call - the reference's weighted posterior (weights.py:87-131 then
+ * ensemble_scheme.py:43-81): rows from the basis of bayens_gp_fit_batch, marginal variances from cov [M][N][N],
+ * w [M][N] (nullable), barycentre mu_out / var_out [N].  One host synchronisation instead of one per step. */
+int bayens_weighted_posterior(bayens_ctx* ctx, int loc, int M, int N, int R_obs, const double* ll_basis,
+                              const double* logdet, const double* obs, const double* mu, const double* cov,
+                              double c_std, double tol, double init_var, double* w, double* mu_out,
+                              double* var_out, int* n_not_converged);
+
 /* standardise + normalise over the model axis (ensembles/weights.py:107,118-123):
  * w_raw = exp(c_std * ll_mean), w = w_raw / sum_m w_raw.  scheme 0 = exp.  w_raw may be NULL. */
 int bayens_weights_normalise(bayens_ctx* ctx, int loc, int M, int P, const double* ll_mean,

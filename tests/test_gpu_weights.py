@@ -37,6 +37,15 @@ def test_loglik_rows_and_weights(ctx, M, N, R_obs):
         assert np.allclose(w.sum(axis=0), 1.0, rtol=1e-12)
 
 
+def test_weighted_posterior_in_one_call_equals_the_separate_steps(ctx):
+    data, obs, out = _posteriors(ctx, 5, 90, R=4, seed=17)
+    w, bm, bv, bad = ctx.weighted_posterior(out["basis"], out["logdet"], obs, out["mu"], out["cov"], c_std=1e-3)
+    ll = ctx.loglik_rows_basis(out["basis"], out["logdet"], obs)
+    w_ref = ctx.weights_normalise(ll, 1e-3)
+    bm_ref, bv_ref, bad_ref = ctx.barycentre(w_ref, out["mu"], ctx.extract_diag(out["cov"]))
+    assert np.array_equal(w, w_ref) and np.array_equal(bm, bm_ref) and np.array_equal(bv, bv_ref) and bad == bad_ref
+
+
 def test_exp_underflow_gives_nan_like_the_reference(ctx):
     ll = np.array([[-4000.0, -10.0], [-3000.0, -12.0]])
     w = ctx.weights_normalise(ll, 1.0)
