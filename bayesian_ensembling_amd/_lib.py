@@ -99,6 +99,7 @@ def load():
     lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_bench_leaf.argtypes = [_vp, C.c_int, C.c_int, _dp, _vp]
     lib.bayens_bench_potrf.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
+    lib.bayens_bench_mfma_peak.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
@@ -489,6 +490,11 @@ class Context:
         st = np.zeros(16, dtype=np.uint64)
         self._check(self.lib.bayens_bench_leaf(self.h, nb, reps, C.byref(us), st.ctypes.data))
         return us.value, st
+
+    def bench_mfma_peak(self, waves_per_simd=2):
+        tf = C.c_double()
+        self._check(self.lib.bayens_bench_mfma_peak(self.h, waves_per_simd, C.byref(tf)))
+        return tf.value
 
     def bench_potrf(self, nb=32, n=2048, reps=10):
         us = C.c_double()

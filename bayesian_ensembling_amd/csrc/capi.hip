@@ -976,6 +976,46 @@ int bayens_bench_leaf(bayens_ctx* c, int nb, int reps, double* us_per_launch, un
   });
 }
 
+namespace {
+typedef double mfma_v4d __attribute__((ext_vector_type(4)));
+// register-only MFMA loop: 16 independent accumulators per wave, no memory traffic - what the matrix pipes sustain
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, double* sink) {
+  mfma_v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = mfma_v4d{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;     // keeps the loop alive
+}
+}  // namespace
+
+int bayens_bench_mfma_peak(bayens_ctx* c, int waves_per_simd, double* tflops) {
+  return guarded(c, [&]() {
+    if (waves_per_simd < 1 || waves_per_simd > 2 || !tflops) return fail(c, BAYENS_E_ARG, "bench_mfma_peak: bad argument");
+    hipDeviceProp_t p;
+    BAYENS_HIP(hipGetDeviceProperties(&p, c->device));
+    const int iters = 20000;
+    const int blocks = p.multiProcessorCount * waves_per_simd;          // 4 waves per block = one per SIMD
+    double* sink = c->small_scratch(1);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->stream, 100, sink);   // warm-up
+    BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->stream, iters, sink);
+    BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+    BAYENS_HIP(hipEventSynchronize(c->t1));
+    float ms = 0;
+    BAYENS_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    const double flop = (double)blocks * 4 * iters * 16 * (2.0 * 16 * 16 * 4);
+    *tflops = flop / (ms * 1e-3) / 1e12;
+    return 0;
+  });
+}
+
 int bayens_bench_potrf(bayens_ctx* c, int nb, int n, int reps, double* us_per_factor) {
   return guarded(c, [&]() {
     if (n % LEAF || n <= 0 || reps <= 0) return fail(c, BAYENS_E_ARG, "bench_potrf: n must be a positive multiple of 64");

@@ -215,6 +215,10 @@ int bayens_bench_leaf(bayens_ctx* ctx, int nb, int reps, double* us_per_launch, 
 /* Diagnostic: nb device-generated SPD matrices of order n (a multiple of 64); us_per_factor = time of one batched
  * blocked Cholesky (the copy that restores the input between repetitions is timed separately and subtracted). */
 int bayens_bench_potrf(bayens_ctx* ctx, int nb, int n, int reps, double* us_per_factor);
+/* Diagnostic: what the fp64 matrix pipes sustain from registers alone (16 independent v_mfma_f64_16x16x4_f64
+ * accumulators per wave, waves_per_simd = 1 or 2 waves on every SIMD, no memory traffic) - the measured ceiling the
+ * GEMM's K loop is compared with. */
+int bayens_bench_mfma_peak(bayens_ctx* ctx, int waves_per_simd, double* tflops);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
