@@ -1023,12 +1023,21 @@ __global__ void normal_loglik_kernel(int N, int R_obs, const double* mu, const d
 }
 
 // weights.py:107,118-123: w_raw = exp(c ll), w = w_raw / sum_m w_raw; thread per point, coalesced over points
-__global__ void normalise_kernel(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// weights.py:107,118-123.  64 points per workgroup, the members dealt over the four waves (the sums over the members
+// are latency chains of exp(): one thread per point made them the kernel's whole duration).
+__global__ __launch_bounds__(256) void normalise_kernel(int M, int P, const double* ll_mean, double c_std, double* w,
+                                                        double* w_raw) {
+  __shared__ double part[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  double s = 0.0;
+  if (t < P)
+    for (int m = g; m < M; m += 4) s += exp(c_std * ll_mean[(long)m * P + t]);
+  part[g][tx] = s;
+  __syncthreads();
+  const double sum = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
   if (t >= P) return;
-  double sum = 0.0;
-  for (int m = 0; m < M; ++m) sum += exp(c_std * ll_mean[(long)m * P + t]);
-  for (int m = 0; m < M; ++m) {
+  for (int m = g; m < M; m += 4) {
     const double raw = exp(c_std * ll_mean[(long)m * P + t]);
     w[(long)m * P + t] = raw / sum;
     if (w_raw) w_raw[(long)m * P + t] = raw;
@@ -1056,26 +1065,47 @@ __global__ void w2_temporal_kernel(int M, int P, const double* mean, const doubl
 }
 
 // ensemble_scheme.py:52-78 + wasserstein.py:61-100 (signed convergence test, <= 201 sweeps)
-__global__ void barycentre_kernel(int M, int P, const double* w, const double* mean, const double* var,
-                                  double tol, double init_var, double* mu_out, double* var_out, int* n_bad) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P) return;
+// ensemble_scheme.py:43-81 + wasserstein.py:61-100: per point, mu* = sum_m w mu and the fixed point
+// v <- sum_m w sqrt(v) sigma_m with the reference's signed stopping test.  Same layout as normalise_kernel: 64 points
+// per workgroup, members dealt over four waves, the block leaves the loop when all of its points have stopped.
+__global__ __launch_bounds__(256) void barycentre_kernel(int M, int P, const double* w, const double* mean,
+                                                         const double* var, double tol, double init_var, double* mu_out,
+                                                         double* var_out, int* n_bad) {
+  __shared__ double part[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
   double v = init_var;
   int n_iters = 0;
+  bool done = t >= P;
   while (true) {
-    double cand = 0.0;
-    const double sv = sqrt(v);
-    for (int m = 0; m < M; ++m) cand += w[(long)m * P + t] * sv * sqrt(var[(long)m * P + t]);
-    if (cand - v < tol) { v = cand; break; }
-    v = cand;
-    ++n_iters;
-    if (n_iters > 200) { atomicAdd(n_bad, 1); break; }
+    double p = 0.0;
+    if (!done) {
+      const double sv = sqrt(v);
+      for (int m = g; m < M; m += 4) p += w[(long)m * P + t] * sv * sqrt(var[(long)m * P + t]);
+    }
+    part[g][tx] = p;
+    __syncthreads();
+    const double cand = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+    if (!done) {
+      if (cand - v < tol) { v = cand; done = true; }
+      else {
+        v = cand;
+        ++n_iters;
+        if (n_iters > 200) { if (g == 0) atomicAdd(n_bad, 1); done = true; }
+      }
+    }
+    if (__syncthreads_and(done)) break;       // (also the barrier that protects `part` for the next round)
   }
-  double mu = 0.0;
-  for (int m = 0; m < M; ++m) mu += w[(long)m * P + t] * mean[(long)m * P + t];
-  mu_out[t] = mu;
-  const double sig = sqrt(v);
-  var_out[t] = sig * sig;    // Barycentre passes bary_stds ** 2 (ensemble_scheme.py:76)
+  double p = 0.0;
+  if (t < P)
+    for (int m = g; m < M; m += 4) p += w[(long)m * P + t] * mean[(long)m * P + t];
+  part[g][tx] = p;
+  __syncthreads();
+  if (g == 0 && t < P) {
+    mu_out[t] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+    const double sig = sqrt(v);
+    var_out[t] = sig * sig;    // Barycentre passes bary_stds ** 2 (ensemble_scheme.py:76)
+  }
 }
 
 // ensemble_scheme.py:136-160: mean and (std ** 2) across realisations (ddof = 0), weighted
@@ -1618,7 +1648,7 @@ void HipPrims::normal_loglik_rows(int B, int N, int R_obs, const double* mu, con
   LAUNCH_CHECK();
 }
 void HipPrims::weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw) {
-  hipLaunchKernelGGL(normalise_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, ll_mean, c_std, w, w_raw);
+  hipLaunchKernelGGL(normalise_kernel, dim3((P + 63) / 64), dim3(256), 0, stream, M, P, ll_mean, c_std, w, w_raw);
   LAUNCH_CHECK();
 }
 void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, double* w) {
@@ -1628,7 +1658,7 @@ void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, 
 void HipPrims::barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,
                           double init_var, double* mu_out, double* var_out, int* n_bad) {
   BAYENS_HIP(hipMemsetAsync(n_bad, 0, sizeof(int), stream));
-  hipLaunchKernelGGL(barycentre_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, w, mean, var, tol,
+  hipLaunchKernelGGL(barycentre_kernel, dim3((P + 63) / 64), dim3(256), 0, stream, M, P, w, mean, var, tol,
                      init_var, mu_out, var_out, n_bad);
   LAUNCH_CHECK();
 }
