@@ -100,6 +100,7 @@ def load():
     lib.bayens_bench_leaf.argtypes = [_vp, C.c_int, C.c_int, _dp, _vp]
     lib.bayens_bench_potrf.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_bench_mfma_peak.argtypes = [_vp, C.c_int, _dp]
+    lib.bayens_bench_mfma_lds.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
@@ -494,6 +495,11 @@ class Context:
     def bench_mfma_peak(self, waves_per_simd=2):
         tf = C.c_double()
         self._check(self.lib.bayens_bench_mfma_peak(self.h, waves_per_simd, C.byref(tf)))
+        return tf.value
+
+    def bench_mfma_lds(self, mode=0):
+        tf = C.c_double()
+        self._check(self.lib.bayens_bench_mfma_lds(self.h, mode, C.byref(tf)))
         return tf.value
 
     def bench_potrf(self, nb=32, n=2048, reps=10):

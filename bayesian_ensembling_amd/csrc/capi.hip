@@ -995,6 +995,93 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, double* si
 }
 }  // namespace
 
+namespace {
+// the same stream with the GEMM K loop's operand traffic: per 16 MFMAs, 4 + 4 operands come from LDS (no barriers,
+// no global loads) - separates "feeding the pipes from LDS" from everything else in the K loop
+// mode bits: 1 = one workgroup barrier per 64-MFMA step, 2 = eight ds_write_b64 per step (the next tile's staging),
+// 4 = eight 16-byte global loads per step whose data the writes wait for, 8 = those loads are issued a whole step
+// ahead (second register set), 16 = the stores sit in the middle of the step's MFMA stream instead of its end
+__global__ __launch_bounds__(256, 2) void mfma_lds_kernel(int iters, double* sink, int mode, const double* src) {
+  __shared__ double T[4][16][130];
+  for (int e = threadIdx.x; e < 4 * 16 * 130; e += 256) (&T[0][0][0])[e] = 1.0 + e * 1e-9;
+  __syncthreads();
+  mfma_v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = mfma_v4d{0.0, 0.0, 0.0, 0.0};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  v2 g[8], h[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { g[q] = v2{1.0, 1.0}; h[q] = v2{1.0, 1.0}; }
+  const v2* gp = reinterpret_cast<const v2*>(src) + (size_t)blockIdx.x * 256 * 8 + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const int buf = (it & 1) * 2;
+    if (mode & 8) {      // what was requested a step ago becomes the data to store; request the next
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = h[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[q] = gp[(size_t)q * 256 + ((it & 63) << 16)];
+    } else if (mode & 4) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = gp[(size_t)q * 256 + ((it & 63) << 16)];
+    }
+    auto stores = [&]() {
+      const int kp = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T[(buf ^ 2)][2 * kp][r + 32 * q] = g[q].x;
+        T[(buf ^ 2)][2 * kp + 1][r + 32 * q] = g[q].y;
+        T[(buf ^ 2) + 1][2 * kp][r + 32 * q] = g[4 + q].x;
+        T[(buf ^ 2) + 1][2 * kp + 1][r + 32 * q] = g[4 + q].y;
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk == 2 && (mode & 16) && (mode & 2)) stores();
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = T[buf][kk * 4 + lk][wm * 64 + i * 16 + lr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = T[buf + 1][kk * 4 + lk][wn * 64 + j * 16 + lr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+    }
+    if ((mode & 2) && !(mode & 16)) stores();
+    if (mode & 1) __syncthreads();
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;
+}
+}  // namespace
+
+int bayens_bench_mfma_lds(bayens_ctx* c, int mode, double* tflops) {
+  return guarded(c, [&]() {
+    if (!tflops) return fail(c, BAYENS_E_ARG, "bench_mfma_lds: bad argument");
+    Stage st(c, BAYENS_DEVICE);
+    double* src = st.scratch<double>((size_t)64 * 65536 * 2 + (size_t)512 * 256 * 8 * 2);
+    BAYENS_HIP(hipMemsetAsync(src, 0, ((size_t)64 * 65536 * 2 + (size_t)512 * 256 * 8 * 2) * sizeof(double), c->stream));
+    hipDeviceProp_t p;
+    BAYENS_HIP(hipGetDeviceProperties(&p, c->device));
+    const int iters = 5000;
+    const int blocks = p.multiProcessorCount * 2;
+    double* sink = c->small_scratch(1);
+    hipLaunchKernelGGL(mfma_lds_kernel, dim3(blocks), dim3(256), 0, c->stream, 50, sink, mode, src);
+    BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+    hipLaunchKernelGGL(mfma_lds_kernel, dim3(blocks), dim3(256), 0, c->stream, iters, sink, mode, src);
+    BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+    BAYENS_HIP(hipEventSynchronize(c->t1));
+    float ms = 0;
+    BAYENS_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *tflops = (double)blocks * 4 * iters * 64 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+    return 0;
+  });
+}
+
 int bayens_bench_mfma_peak(bayens_ctx* c, int waves_per_simd, double* tflops) {
   return guarded(c, [&]() {
     if (waves_per_simd < 1 || waves_per_simd > 2 || !tflops) return fail(c, BAYENS_E_ARG, "bench_mfma_peak: bad argument");

@@ -219,6 +219,10 @@ int bayens_bench_potrf(bayens_ctx* ctx, int nb, int n, int reps, double* us_per_
  * accumulators per wave, waves_per_simd = 1 or 2 waves on every SIMD, no memory traffic) - the measured ceiling the
  * GEMM's K loop is compared with. */
 int bayens_bench_mfma_peak(bayens_ctx* ctx, int waves_per_simd, double* tflops);
+/* Diagnostic: the same MFMA stream fed from LDS exactly as the GEMM's K loop feeds it (8 operand reads per 16 MFMAs,
+ * two workgroups per CU).  mode bits add the rest of a K step one by one: 1 = a workgroup barrier per 64 MFMAs,
+ * 2 = the eight transposing LDS stores of the next tile, 4 = eight 16-byte global loads feeding those stores. */
+int bayens_bench_mfma_lds(bayens_ctx* ctx, int mode, double* tflops);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
