@@ -93,6 +93,10 @@ def load():
     lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.bayens_comm_destroy.argtypes = [_vp]
     lib.bayens_allgather_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
+    lib.bayens_comm_info.argtypes = [_vp, _ip, _ip, C.c_char_p, C.c_int]
+    lib.bayens_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
+    lib.bayens_allgather_member_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_comm_max.argtypes = [_vp, _dp]
     lib.bayens_w2_single_sharded.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_test_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp,
                                      C.c_int, C.c_double, _vp, C.c_int, C.c_int, C.c_double]
@@ -463,6 +467,24 @@ class Context:
 
     def comm_destroy(self):
         self._check(self.lib.bayens_comm_destroy(self.h))
+
+    def comm_info(self):
+        """(rank, nranks, path of the RCCL library in use); nranks 0 = no communicator."""
+        r, n = C.c_int(), C.c_int()
+        buf = C.create_string_buffer(512)
+        self._check(self.lib.bayens_comm_info(self.h, C.byref(r), C.byref(n), buf, 512))
+        return r.value, n.value, buf.value.decode()
+
+    def allgather_member_rows(self, M, P, M_loc, ll_loc, mean_loc, var_loc, ll_all, mean_all, var_all):
+        """The exchange of the sharded weighted posterior on resident rows (uneven shards allowed)."""
+        self._check(self.lib.bayens_allgather_member_rows(self.h, M, P, M_loc, _ptr(ll_loc), _ptr(mean_loc),
+                                                          _ptr(var_loc), _ptr(ll_all), _ptr(mean_all), _ptr(var_all)))
+
+    def comm_max(self, x):
+        """max over the ranks of one double; also a barrier (every rank's stream has drained when it returns)."""
+        v = C.c_double(float(x))
+        self._check(self.lib.bayens_comm_max(self.h, C.byref(v)))
+        return v.value
 
     def w2_single_sharded_dev(self, M, N, mu, chol, w, D):
         """All members' mu / chol resident on every rank; pairs dealt over the communicator's ranks."""

@@ -26,17 +26,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "bayens.h")]
     if not force and os.path.exists(LIB) and not any(_newer(d, LIB) for d in deps):
         return LIB
-    objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
+    jobs = []
     for src, f32 in [(f, False) for f in SOURCES] + [(f, True) for f in SOURCES_F32]:
         obj = os.path.join(bdir, src + (".f32.o" if f32 else ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + \
               (["-DBAYENS_F32"] if f32 else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append((cmd, obj))
+
+    def compile_one(job):
         if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    # the translation units are independent: compile them side by side (bounded: hipcc peaks at ~2 GB per unit)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(6, os.cpu_count() or 1))) as pool:
+        objs = list(pool.map(compile_one, jobs))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -29,9 +29,11 @@ typedef ncclResult_t (*pfn_ncclAllReduce)(const void*, void*, size_t, int /*nccl
                                           hipStream_t);
 typedef const char* (*pfn_ncclGetErrorString)(ncclResult_t);
 constexpr int NCCL_FLOAT64 = 8;
+constexpr int NCCL_SUM = 0, NCCL_MAX = 2;
 
 struct RcclApi {
   void* handle = nullptr;
+  std::string path;
   pfn_ncclGetUniqueId GetUniqueId = nullptr;
   pfn_ncclCommInitRank CommInitRank = nullptr;
   pfn_ncclCommDestroy CommDestroy = nullptr;
@@ -40,10 +42,18 @@ struct RcclApi {
   pfn_ncclGetErrorString GetErrorString = nullptr;
   bool load(std::string& err) {
     if (handle) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (handle) break;
+    // ROCm's own RCCL first, by absolute path (ROCM_PATH, then /opt/rocm): it is built against the libamdhip64 this
+    // library links.  The bare sonames come last - under them the loader would hand back whatever copy a host
+    // program (e.g. PyTorch's bundled one) happens to have mapped already.
+    std::vector<std::string> names;
+    if (const char* rp = getenv("ROCM_PATH")) names.push_back(std::string(rp) + "/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so");
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const auto& n : names) {
+      handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (handle) { path = n; break; }
     }
     if (!handle) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
     GetUniqueId = (pfn_ncclGetUniqueId)dlsym(handle, "ncclGetUniqueId");
@@ -85,6 +95,17 @@ struct bayens_ctx {
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  double* xbuf = nullptr;          // packed rows of the member exchange: [rows][3][P] sent | [nranks][rows][3][P] received
+  size_t xbuf_cap = 0;
+  double* exchange_scratch(size_t count) {
+    if (count > xbuf_cap) {
+      if (xbuf) (void)hipFree(xbuf);
+      xbuf = nullptr;
+      if (hipMalloc((void**)&xbuf, count * sizeof(double)) != hipSuccess) throw HipError{BAYENS_E_ALLOC, "hipMalloc"};
+      xbuf_cap = count;
+    }
+    return xbuf;
+  }
 };
 
 namespace {
@@ -102,7 +123,7 @@ int guarded(bayens_ctx* c, F&& f) {
     if (e != hipSuccess) return fail(c, (int)e, std::string("hipSetDevice: ") + hipGetErrorString(e));
     return f();
   } catch (const HipError& e) {
-    return fail(c, e.code > 0 ? e.code : BAYENS_E_ARG, e.what);
+    return fail(c, e.code != 0 ? e.code : BAYENS_E_ARG, e.what);   // hipError_t (> 0) or a BAYENS_E_* code (< 0) as thrown
   } catch (const std::exception& e) {
     return fail(c, BAYENS_E_ALLOC, e.what());
   }
@@ -240,6 +261,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   free_ws(c);
   if (c->f32) bayens_f32_destroy(c->f32);
   if (c->sscratch) (void)hipFree(c->sscratch);
+  if (c->xbuf) (void)hipFree(c->xbuf);
   for (auto* p : c->gprims) delete p;
   for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   delete c->prims;
@@ -703,22 +725,29 @@ int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const
     Mat Lp{Lpad, Np, (long)Np * Np};
     P.pad_in(M, N, Np, dch, Lp);                       // identity padding: contributes exactly Np - N to every norm
     double* tr = st.scratch<double>((size_t)M);
-    double* nuc = st.scratch<double>((size_t)M * M);
+    double* nuc = st.scratch<double>((size_t)M * M + 1);
     double* rel = st.scratch<double>((size_t)M);
     P.dot_all(M, Np, Lp, Lp, tr);                      // tr S_i = ||L_i||_F^2 (+ padding)
     P.pair_terms(M, N, dmu, nullptr, gap, nullptr);
-    if (sharded) BAYENS_HIP(hipMemsetAsync(nuc, 0, (size_t)M * M * sizeof(double), c->stream));
+    // nuc[M*M] is followed by one more double: the number of anchors whose polar iteration did not converge (summed
+    // over the ranks by the same all-reduce, so that every rank takes the same decision)
+    BAYENS_HIP(hipMemsetAsync(nuc, 0, ((size_t)M * M + 1) * sizeof(double), c->stream));
+    double not_converged = 0.0;
     for (int i = 0; i + 1 < M; ++i) {
       if (i % nranks != rank) continue;
       const int nb = M - 1 - i;
       FitWorkspace wsi = ws;
       wsi.nb = nb;
-      nuclear_norms(P, wsi, nb, Mat{Lpad + (size_t)i * Np * Np, Np, 0}, Mat{Lpad + (size_t)(i + 1) * Np * Np, Np, (long)Np * Np},
-                    nuc + (size_t)i * M + i + 1, rel);
+      const int its = nuclear_norms(P, wsi, nb, Mat{Lpad + (size_t)i * Np * Np, Np, 0},
+                                    Mat{Lpad + (size_t)(i + 1) * Np * Np, Np, (long)Np * Np}, nuc + (size_t)i * M + i + 1, rel);
+      if (its <= 0) not_converged += 1.0;
     }
     if (sharded) {
-      ncclResult_t r = c->rccl.AllReduce(nuc, nuc, (size_t)M * M, NCCL_FLOAT64, 0 /* ncclSum */, c->comm, c->stream);
+      BAYENS_HIP(hipMemcpyAsync(nuc + (size_t)M * M, &not_converged, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      BAYENS_HIP(hipStreamSynchronize(c->stream));     // (the source is a stack variable that is overwritten below)
+      ncclResult_t r = c->rccl.AllReduce(nuc, nuc, (size_t)M * M + 1, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
       if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllReduce failed");
+      BAYENS_HIP(hipMemcpyAsync(&not_converged, nuc + (size_t)M * M, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     // remove the identity padding's share (Np - N) from traces and nuclear norms: both enter as tr_i + tr_j - 2 nuc,
     // i.e. 2 (Np - N) - 2 (Np - N) = 0, so no correction is needed in D.
@@ -728,6 +757,9 @@ int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const
     st.finish();
     for (int b = 0; b < M; ++b)
       if (hinfo[b]) return fail(c, BAYENS_E_NOTPD, "w2_single: a polar-iteration Cholesky failed");
+    if (not_converged > 0.0)
+      return fail(c, BAYENS_E_NOCONV, "w2_single: the polar iteration of at least one pair did not converge (ill-conditioned "
+                                      "or non-finite covariance factors); w and D are not valid");
     return 0;
   });
 }
@@ -894,6 +926,93 @@ int bayens_allgather_rows(bayens_ctx* c, const double* local_dev, double* all_de
     if (!local_dev || !all_dev || M_loc <= 0 || P <= 0) return fail(c, BAYENS_E_ARG, "allgather_rows: bad argument");
     ncclResult_t r = c->rccl.AllGather(local_dev, all_dev, (size_t)M_loc * P, NCCL_FLOAT64, c->comm, c->stream);
     if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllGather failed");
+    return 0;
+  });
+}
+
+int bayens_comm_info(bayens_ctx* c, int* rank, int* nranks, char* lib_path, int lib_path_len) {
+  return guarded(c, [&]() {
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->comm ? c->nranks : 0;
+    if (lib_path && lib_path_len > 0) snprintf(lib_path, lib_path_len, "%s", c->rccl.path.c_str());
+    return 0;
+  });
+}
+
+// The member exchange of the sharded weighted posterior.  Members are dealt to the ranks in contiguous blocks, the
+// first M % nranks ranks holding one more (bayens_shard_bounds); every rank contributes rows = ceil(M / nranks)
+// packed [3][P] rows (log-likelihood, mean, variance; unused rows are never read) to ONE ncclAllGather and compacts
+// the received [nranks][rows][3][P] image into the three [M][P] tables.
+}  // extern "C"
+namespace {
+__global__ void pack_rows_kernel(int M_loc, int P, const double* ll, const double* mean, const double* var, double* packed) {
+  const int m = blockIdx.y, which = blockIdx.z, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P || m >= M_loc) return;
+  const double* src = which == 0 ? ll : (which == 1 ? mean : var);
+  packed[((size_t)m * 3 + which) * P + t] = src[(size_t)m * P + t];
+}
+__global__ void unpack_rows_kernel(int M, int nranks, int rows, int P, const double* gathered, double* ll, double* mean,
+                                   double* var) {
+  const int m = blockIdx.y, which = blockIdx.z, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P || m >= M) return;
+  const int base = M / nranks, extra = M % nranks;          // ranks < extra own base + 1 members
+  int r, loc;
+  if (m < (base + 1) * extra) { r = m / (base + 1); loc = m - r * (base + 1); }
+  else { const int q = m - (base + 1) * extra; r = extra + q / base; loc = q - (r - extra) * base; }
+  double* dst = which == 0 ? ll : (which == 1 ? mean : var);
+  dst[(size_t)m * P + t] = gathered[(((size_t)r * rows + loc) * 3 + which) * P + t];
+}
+}  // namespace
+extern "C" {
+
+int bayens_shard_bounds(int M, int rank, int nranks, int* lo, int* hi) {
+  if (M < 0 || nranks <= 0 || rank < 0 || rank >= nranks || !lo || !hi) return BAYENS_E_ARG;
+  const int base = M / nranks, extra = M % nranks;
+  *lo = rank * base + (rank < extra ? rank : extra);
+  *hi = *lo + base + (rank < extra ? 1 : 0);
+  return 0;
+}
+
+int bayens_allgather_member_rows(bayens_ctx* c, int M, int P, int M_loc, const double* ll_loc, const double* mean_loc,
+                                 const double* var_loc, double* ll_all, double* mean_all, double* var_all) {
+  return guarded(c, [&]() {
+    if (!c->comm) return fail(c, BAYENS_E_COMM, "allgather_member_rows: communicator not initialised");
+    if (M <= 0 || P <= 0 || !ll_loc || !mean_loc || !var_loc || !ll_all || !mean_all || !var_all)
+      return fail(c, BAYENS_E_ARG, "allgather_member_rows: bad argument");
+    int lo = 0, hi = 0;
+    bayens_shard_bounds(M, c->rank, c->nranks, &lo, &hi);
+    if (M_loc != hi - lo)
+      return fail(c, BAYENS_E_ARG, "allgather_member_rows: M_loc is not this rank's block of the M members (bayens_shard_bounds)");
+    const int rows = (M + c->nranks - 1) / c->nranks;
+    const size_t per_rank = (size_t)rows * 3 * P;
+    double* send = c->exchange_scratch(per_rank * (c->nranks + 1));
+    double* recv = send + per_rank;
+    const dim3 block(256);
+    if (M_loc > 0) {
+      hipLaunchKernelGGL(pack_rows_kernel, dim3((P + 255) / 256, M_loc, 3), block, 0, c->stream, M_loc, P, ll_loc, mean_loc,
+                         var_loc, send);
+      BAYENS_HIP(hipGetLastError());
+    }
+    ncclResult_t r = c->rccl.AllGather(send, recv, per_rank, NCCL_FLOAT64, c->comm, c->stream);
+    if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllGather failed");
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((P + 255) / 256, M, 3), block, 0, c->stream, M, c->nranks, rows, P, recv,
+                       ll_all, mean_all, var_all);
+    BAYENS_HIP(hipGetLastError());
+    return 0;
+  });
+}
+
+int bayens_comm_max(bayens_ctx* c, double* value) {
+  return guarded(c, [&]() {
+    if (!c->comm || !c->rccl.AllReduce) return fail(c, BAYENS_E_COMM, "comm_max: communicator not initialised");
+    if (!value) return fail(c, BAYENS_E_ARG, "comm_max: null value");
+    double* d = c->small_scratch(2) + 1;      // (slot 0 is the barycentre's not-converged counter)
+    BAYENS_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    ncclResult_t r = c->rccl.AllReduce(d, d, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, c->stream);
+    if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllReduce failed");
+    BAYENS_HIP(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
     return 0;
   });
 }

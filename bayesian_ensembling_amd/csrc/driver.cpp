@@ -8,8 +8,18 @@
 namespace BAYENS_NS {
 
 constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve takes
-constexpr int SEQ_MAX_NP = 512;  // members up to this padded size are launch-bound: iteration bodies are recorded
-constexpr int SEQ_MIN_ITERS = 4; // ... when there are enough repetitions to pay for recording
+
+// A side section (Prims::side_begin / side_end) that cannot leave the back end on the side stream when a launch
+// inside it throws.
+namespace {
+struct SideSection {
+  Prims& P;
+  bool open = true;
+  explicit SideSection(Prims& p) : P(p) { P.side_begin(); }
+  void end() { open = false; P.side_end(); }
+  ~SideSection() { if (open) P.side_cancel(); }
+};
+}  // namespace
 
 static inline int split_point(int n) {
   int leaves = n / LEAF;
@@ -122,10 +132,10 @@ void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info
     P.gemm(nb, m, w2, w, -1.0, A.sub(c1, k0), A.sub(c1, k0), 1.0, A.sub(c1, c1), GEMM_TB | GEMM_TRI_OUT, 0.0);
     if (below > w2) {
       const int c2 = c1 + w2;
-      P.side_begin();
+      SideSection side(P);            // (restores the main stream if the launch throws)
       P.gemm(nb, m - w2, below - w2, w, -1.0, A.sub(c2, k0), A.sub(c2, k0), 1.0, A.sub(c2, c2),
              GEMM_TB | GEMM_TRI_OUT, 0.0);
-      P.side_end();
+      side.end();
     }
   }
   P.side_join();
@@ -185,24 +195,16 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);
   }
 
-  // Small members are launch-bound (an iteration is ~100 launches of a few microseconds): there the two halves of the
-  // iteration body - everything up to the Cholesky of K, and the rest - are recorded once and replayed (hipGraph on
-  // the device back end).  The loss sample, when one is due, sits between the two halves.
-  P.seq_reset(Np <= SEQ_MAX_NP && fp.n_iters >= SEQ_MIN_ITERS, nb, Np, fp.R);
   const bool in_pad = Np > N;
   const int mrows = in_pad ? Np : Np + LEAF;
   Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
   for (int it = 0; it < fp.n_iters; ++it) {
-    if (!P.seq_begin(0)) {
-      // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
-      P.mark("kmat");
-      P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
-      P.mark("potrf K");
-      potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
-      P.seq_end(0);
-    }
+    // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
+    P.mark("kmat");
+    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
+    P.mark("potrf K");
+    potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
     if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY);
-    if (P.seq_begin(1)) continue;
     P.mark("Lam update");
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
@@ -231,9 +233,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T1, false);        // Kbar^T = W^T L^-1
     P.mark("grad+adam");
     P.grad_adam(nb, N, Np, fp.R, X, fp.kernel, ws.T1, ws.ustate, fp.lr);
-    P.seq_end(1);
   }
-  P.seq_reset(false, nb, Np, fp.R);
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
@@ -283,6 +283,7 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
   double ell = ell0;
   std::vector<double> rel(nb);
   int it = 0;
+  bool converged = false;
   for (; it < max_iters; ++it) {
     // dynamically weighted Halley coefficients from the current lower bound of the singular values
     const double l2 = ell * ell;
@@ -301,10 +302,10 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
     P.read_back(scratch_rel, rel.data(), nb);
     double worst = 0.0;
     for (double r : rel) worst = r > worst || r != r ? r : worst;
-    if (worst < tol) { ++it; break; }
+    if (worst < tol) { ++it; converged = true; break; }
   }
   P.dot_all(nb, Np, X, M, nuc);    // ||M||_* = tr(U^T M)
-  return it;
+  return converged ? it : -it;     // a NaN step or a pair still moving after max_iters: the caller must not use nuc
 }
 
 double fit_flops(int N, int R, int n_iters) {

@@ -74,7 +74,8 @@ void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* cho
 // Polar factor by the Cholesky form of the QDWH iteration (Nakatsukasa, Bai, Gygi 2010): per step one X^T X,
 // one Cholesky and two triangular solves, all on the existing batched primitives; <= max_iters steps, stops when
 // every pair moved by less than tol.  Lj: the nb factors L_j (padded, lower).  Uses ws.W0 (M), ws.Lb (X), ws.Cb (Z),
-// ws.T1 (T).  nuc: device [nb], scratch_rel: device [nb].  Returns the number of iterations taken.
+// ws.T1 (T).  nuc: device [nb], scratch_rel: device [nb].  Returns the number of iterations taken, NEGATED when the
+// iteration did not converge (a pair still moved by >= tol after max_iters, or a step produced NaN).
 int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel,
                   double ell0 = 1e-7, double tol = 1e-13, int max_iters = 16);
 

@@ -49,10 +49,6 @@ struct HipPrims : Prims {
   hipStream_t side_stream = nullptr, main_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool in_side = false, side_pending = false;
-  // recorded launch sequences (hipGraph): seq_reset / seq_begin / seq_end
-  static constexpr int SEQ_TAGS = 2;
-  hipGraphExec_t seq_exec[SEQ_TAGS] = {nullptr, nullptr};
-  bool seq_on = false, seq_capturing = false;
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
   // per-launch accounting on/off: recorded events go back to the pool, counters are cleared
@@ -76,13 +72,11 @@ struct HipPrims : Prims {
   ~HipPrims() override;
   void ensure_scratch(int nb, int Np, int R4);
   void mark(const char* phase) override;
-  void seq_reset(bool enable, int nb, int Np, int R) override;
-  bool seq_begin(int tag) override;
-  void seq_end(int tag) override;
   void ensure_side_stream();
   void side_begin() override;
   void side_end() override;
   void side_join() override;
+  void side_cancel() noexcept override { if (in_side) { stream = main_stream; in_side = false; } }
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
             double diag_add) override;

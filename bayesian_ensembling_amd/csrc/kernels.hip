@@ -1348,53 +1348,9 @@ HipPrims::~HipPrims() {
   if (gpart) (void)hipFree(gpart);
   for (auto& e : prof.events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
-  for (int t = 0; t < SEQ_TAGS; ++t) if (seq_exec[t]) (void)hipGraphExecDestroy(seq_exec[t]);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (side_stream) (void)hipStreamDestroy(side_stream);
-}
-
-// Recorded launch sequences: the body between seq_begin() and seq_end() is captured from the stream (the look-ahead
-// side stream joins the capture through its fork / join events) into a hipGraph, instantiated once and replayed
-// with one hipGraphLaunch per repetition: for small members the ~100 launches of an optimiser iteration cost more
-// host time than device time.
-void HipPrims::seq_reset(bool enable, int nb, int Np, int R) {
-  if (seq_capturing) {                       // a body threw while it was being recorded: drop the capture
-    hipGraph_t g = nullptr;
-    (void)hipStreamEndCapture(stream, &g);
-    if (g) (void)hipGraphDestroy(g);
-    seq_capturing = false;
-  }
-  for (int t = 0; t < SEQ_TAGS; ++t)
-    if (seq_exec[t]) { (void)hipGraphExecDestroy(seq_exec[t]); seq_exec[t] = nullptr; }
-  // Off unless BAYENS_SEQ=1: measured at M=8, N=200, 500 iterations: 261 ms replayed against 257 ms launched one by
-  // one.  The iteration is a chain of ~100 dependent kernels of 3-5 us; the HIP queue already overlaps the host's
-  // launch work with their execution, and a graph node costs the device as much as a launch.
-  const char* want = std::getenv("BAYENS_SEQ");
-  seq_on = enable && !prof.enabled && want && want[0] == '1';
-  if (seq_on) {                              // nothing may be allocated or created while recording
-    ensure_scratch(nb, Np, ((R + 3) / 4) * 4);
-    ensure_side_stream();
-  }
-}
-bool HipPrims::seq_begin(int tag) {
-  if (!seq_on || tag < 0 || tag >= SEQ_TAGS) return false;
-  if (seq_exec[tag]) {
-    BAYENS_HIP(hipGraphLaunch(seq_exec[tag], stream));
-    return true;
-  }
-  BAYENS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-  seq_capturing = true;
-  return false;
-}
-void HipPrims::seq_end(int tag) {
-  if (!seq_capturing) return;
-  hipGraph_t g = nullptr;
-  seq_capturing = false;
-  BAYENS_HIP(hipStreamEndCapture(stream, &g));
-  BAYENS_HIP(hipGraphInstantiate(&seq_exec[tag], g, nullptr, nullptr, 0));
-  (void)hipGraphDestroy(g);
-  BAYENS_HIP(hipGraphLaunch(seq_exec[tag], stream));
 }
 
 void HipPrims::ensure_side_stream() {

@@ -68,16 +68,8 @@ struct Prims {
   virtual void side_begin() {}
   virtual void side_end() {}
   virtual void side_join() {}
-
-  // Replayable launch sequences (optional; launch-bound small problems).  seq_reset() forgets every recorded
-  // sequence and says whether recording is wanted for the coming fit (nb, Np, R: so that nothing has to be
-  // allocated while a sequence is being recorded).  seq_begin(tag): true = the sequence recorded under `tag` was
-  // replayed, the caller skips the body; false = the caller issues the body (it may be recorded rather than run)
-  // and then calls seq_end(tag), after which the body has run exactly once.  A body must depend on nothing but
-  // device memory contents (same pointers, sizes and scalars every time).
-  virtual void seq_reset(bool /*enable*/, int /*nb*/, int /*Np*/, int /*R*/) {}
-  virtual bool seq_begin(int /*tag*/) { return false; }
-  virtual void seq_end(int /*tag*/) {}
+  // leaves a side section without publishing it (error path: a launch inside the section threw); never throws
+  virtual void side_cancel() noexcept {}
 
   virtual void potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) = 0;
   // two adjacent leaves (a 128x128 diagonal block): leaf, 64x64 panel solve, 64^3 update, leaf.  A back end may

@@ -5,17 +5,27 @@ ensemble (BASELINE.json configs[1]), one process per GPU.
 One "step" = one pass of the hot path over the per-rank batch of synthetic members, inputs already resident
 in HBM: bayens_gp_fit_batch (Matern-3/2 VGP, n_optim_nits natgrad+Adam iterations, full-cov prediction,
 chol/logdet) -> loglik rows -> [RCCL all-gather of the packed (ll, mean, var) rows when N > 1] -> weights
-normalisation -> Wasserstein barycentre.  Members shard embarrassingly: each rank fits its own 32 members
-("weak" scaling); the only collective is the all-gather of [32, 3, 2000] fp64 rows per rank.
+normalisation -> Wasserstein barycentre.  Members shard embarrassingly: each rank fits its own members ("weak"
+scaling); the only collective is ONE all-gather of [M_loc, 3, 2000] fp64 rows per rank
+(bayesian_ensembling_amd.parallel.weighted_posterior_sharded - the function the CPU gloo test drives too).
 
-Prints ONE JSON line on rank 0.  Run:  python bench.py --gpus 1 --steps 5 --warmup 1
+Launch:  python bench.py --gpus N --steps K --warmup W
+  * under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set, e.g. python -m torch.distributed.run): this process is one rank;
+  * plainly with --gpus N > 1: N child ranks are started here, BEFORE anything touches a GPU, one device each.
+No PyTorch in the ranks: the 128-byte RCCL id travels through a file rendezvous, barrier and max-over-ranks are an
+ncclAllReduce.  Rank 0 prints ONE JSON line.
+
+Presets: --config c2 (default: 32 members/GPU, fp64 Matern-3/2), c3 (fp32 Matern-5/2), c4 (16 members/GPU = 128 members
+over 8 GPUs).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet); = 32 FLOP/clk/SIMD x 1024 SIMD x 2.4 GHz
-F32_MFMA_PEAK_TFLOPS = 157.3  # fp32 matrix peak: the 16x16x4 fp32 MFMA issues in half the cycles of the fp64 one
+F32_MFMA_PEAK_TFLOPS = 157.3  # fp32 matrix peak (MI355X_MICROARCH.md: 16x16x4 fp32 MFMA, 64 FLOP/clk/SIMD)
+METRIC = "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step ensemble"
 
 
 def fit_flops(N, R, T):
@@ -58,188 +69,287 @@ def cpu_baseline(N, R, T, members):
                       f"NumPy/LAPACK oracle, {dt:.1f} s"}
 
 
+class Workload:
+    """Resident inputs/outputs of one configuration on one rank and the step over them."""
+
+    def __init__(self, ctx, M, N, R, T, kernel, f32, rank, world, exchange, groups=1, R_obs=3):
+        from bayesian_ensembling_amd import _lib, parallel
+        self.ctx, self.M, self.N, self.R, self.T, self.f32, self.R_obs = ctx, M, N, R, T, f32, R_obs
+        self.kernel, self.kid, self.world, self.exchange, self.parallel = kernel, _lib.KERNEL_IDS[kernel], world, exchange, parallel
+        self.Mtot = M * world
+        X, y, nu, obs = make_inputs(M, N, R, R_obs, seed=0xB4E5 + rank)
+        dt = np.float32 if f32 else np.float64
+        self.dX, self.dy, self.dnu, self.dobs = ctx.to_device(X, dt), ctx.to_device(y, dt), ctx.to_device(nu, dt), ctx.to_device(obs)
+        self.dmu, self.dcov, self.dchol = ctx.empty((M, N), dt), ctx.empty((M, N, N), dt), ctx.empty((M, N, N), dt)
+        self.dld, self.dhyp, self.dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N), dt)
+        if f32:   # the weight / scheme kernels take fp64 tables: the fp32 posterior's [M][N] rows are widened (a few MB)
+            self.dmu64, self.dbasis64 = ctx.empty((M, N)), ctx.empty((M, 2, N))
+        else:
+            self.dmu64, self.dbasis64 = self.dmu, self.dbasis
+        self.dll_loc, self.dvar_loc = ctx.empty((M, N)), ctx.empty((M, N))
+        self.dw, self.dbmu, self.dbvar = ctx.empty((self.Mtot, N)), ctx.empty((N,)), ctx.empty((N,))
+        self.bufs = [self.dX, self.dy, self.dnu, self.dobs, self.dmu, self.dcov, self.dchol, self.dld, self.dhyp, self.dbasis,
+                     self.dll_loc, self.dvar_loc, self.dw, self.dbmu, self.dbvar] + ([self.dmu64, self.dbasis64] if f32 else [])
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+    def fit(self, T=None):
+        return self.ctx.gp_fit_batch_dev(self.M, self.N, self.R, self.dX, self.dy, self.dnu, self.T if T is None else T,
+                                         self.dmu, self.dcov, self.dchol, self.dld, self.dhyp, kernel=self.kid,
+                                         basis=self.dbasis, f32=self.f32)
+
+    def local_rows(self):
+        """LogLikelihoodWeight rows + posterior marginals of this rank's members ([M, N] each, resident)."""
+        c = self.ctx
+        if self.f32:
+            c.widen_f32_dev(self.M * 2 * self.N, self.dbasis, self.dbasis64)
+            c.widen_f32_dev(self.M * self.N, self.dmu, self.dmu64)
+        c.loglik_rows_basis_dev(self.M, self.N, self.R_obs, self.dbasis64, self.dld, self.dobs, self.dll_loc)
+        c.extract_diag_dev(self.M, self.N, self.dcov, self.dvar_loc, f32=self.f32)
+
+    def weighted_posterior(self, local_only=False):
+        """Weights over ALL members + barycentre.  local_only: this rank's members alone, no collective (the untimed
+        rank-0 diagnostics - a collective there would wait for ranks that have already left)."""
+        c, M, N = self.ctx, self.M, self.N
+        if (self.exchange is None or local_only) and not self.f32:
+            # one GPU: the whole weighted posterior (rows -> weights -> barycentre) is one entry point, one host wait
+            return c.weighted_posterior_dev(M, N, self.R_obs, self.dbasis, self.dld, self.dobs, self.dmu, self.dcov, self.dw,
+                                            self.dbmu, self.dbvar, c_std=1e-3)
+        self.local_rows()
+        if self.exchange is None or local_only:
+            c.weights_normalise_dev(M, N, self.dll_loc, 1e-3, self.dw)
+            return c.barycentre_dev(M, N, self.dw, self.dmu64, self.dvar_loc, self.dbmu, self.dbvar)
+        bad = []
+
+        def normalise(ll, c_std):
+            c.weights_normalise_dev(self.Mtot, N, ll, c_std, self.dw)
+            return self.dw
+
+        def barycentre(w, mean, var):
+            bad.append(c.barycentre_dev(self.Mtot, N, w, mean, var, self.dbmu, self.dbvar))
+            return self.dbmu, self.dbvar, bad[-1]
+
+        self.parallel.weighted_posterior_sharded(self.Mtot, self.dll_loc, self.dmu64, self.dvar_loc, self.exchange,
+                                                 normalise, barycentre, c_std=1e-3)
+        return bad[-1]
+
+    def step(self):
+        self.fit()
+        return self.weighted_posterior()
+
+    def timed(self, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + device sync on both sides; max over ranks."""
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.exchange is not None:
+            elapsed = self.exchange.max_float(elapsed)
+        return elapsed
+
+    def barrier(self):
+        self.ctx.sync()
+        if self.exchange is not None:
+            self.exchange.barrier()
+
+    def roofline(self):
+        """Per-launch HIP events around every launch of the GEMM group in ONE fit batch, on the stream they run on
+        (look-ahead off so that kernels do not overlap).  The dominant kernel is the NT GEMM."""
+        c, f32, N = self.ctx, self.f32, self.N
+        c.set_groups(1)
+        self.fit()
+        c.timer_start(); self.fit(); fit_serial_ms = c.timer_stop()
+        c.profile_enable(True)
+        self.fit()
+        p, p_all = c.profile_get(1), c.profile_get(0)
+        stages = c.profile_stages()
+        if os.environ.get("BAYENS_PRINT_SHAPES"):
+            print(c.profile_shapes(), file=sys.stderr, flush=True)
+        c.profile_enable(False)
+        if os.environ.get("BAYENS_PRINT_STAGES"):
+            print(stages, file=sys.stderr, flush=True)
+        peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
+        kname = "bayens_f32::gemm_f32_mfma" if f32 else "bayens::gemm_f64_mfma"
+        # the launches are issued on members padded to Np = ceil(N/64)*64: the flop the kernel is credited with here is
+        # the ALGORITHMIC flop of the unpadded problem, (N/Np)^3 of what the padded launches compute
+        Np = -(-N // 64) * 64
+        unpad = (N / Np) ** 3
+        tfl_padded = p["flop"] / (p["ms"] * 1e-3) / 1e12
+        tfl = tfl_padded * unpad
+        group = p_all["flop"] / (p_all["ms"] * 1e-3) / 1e12 * unpad
+        traffic, traffic_from = None, None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if files and not f32 and (self.M, N, self.T) == (32, 2000, 2):    # the PMC passes were collected on this workload
+                traffic = round(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+                traffic_from = os.path.basename(files[-1])
+        except Exception:
+            traffic = None
+        return {"bound": "mfma", "kernel": kname + "<false, true>", "achieved": round(tfl, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(tfl / peak, 4), "traffic": traffic, "traffic_source": traffic_from,
+                "achieved_on_padded_dims": round(tfl_padded, 3), "frac_on_padded_dims": round(tfl_padded / peak, 4),
+                "padded_order": Np,
+                "algorithmic_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
+                "launches_per_fit_batch": p["launches"],
+                "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
+                "kernel_ms_per_fit_batch": round(p["ms"], 3),
+                "gemm_group": {"kernels": kname.split("::")[1] + "<*>, gemm_panel64, trsm_panel_kernel",
+                               "achieved": round(group, 3), "frac": round(group / peak, 4),
+                               "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
+                "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
+                "note": "HIP events around every launch of the kernel in one fit batch, one stream (no overlap); achieved = "
+                        "algorithmic flop of the UNPADDED problem / summed launch time; traffic = HBM bytes per launch of "
+                        "this kernel from the rocprofv3 --pmc passes named in traffic_source (not measured in this run)"}
+
+
+def spawn_ranks(args):
+    """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
+    rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), BAYENS_RDZV=rdzv,
+                   MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:           # one rank failed: the others would wait for it at the next collective
+                    rc = code
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--members", type=int, default=32, help="members per GPU")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+                    help="BASELINE.json preset: c2 = 32 members/GPU fp64 matern32 (headline); c3 = fp32 matern52; "
+                         "c4 = 16 members/GPU (128 members sharded 8-way)")
+    ap.add_argument("--members", type=int, default=None, help="members per GPU (default: the preset's)")
     ap.add_argument("--timesteps", type=int, default=2000)
     ap.add_argument("--realisations", type=int, default=8)
     ap.add_argument("--nits", type=int, default=2, help="n_optim_nits (2 = the reference's test scale)")
-    ap.add_argument("--kernel", default="matern32", choices=["matern32", "matern52", "rbf"])
+    ap.add_argument("--kernel", default=None, choices=["matern32", "matern52", "rbf"])
     ap.add_argument("--groups", type=int, default=1, help="member groups = HIP streams per fit batch")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"],
                     help="f64 = the reference precision (the headline); f32 = BASELINE config 3 (1e-3 parity bar)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "file"],
+                    help="N > 1 transport: rccl (the product) or file = host-staged rehearsal for several ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (T=500, config 3, RBF)")
     ap.add_argument("--cpu-members", type=int, default=2)
     args = ap.parse_args()
+    preset = {"c2": (32, "matern32", "f64"), "c3": (32, "matern52", "f32"), "c4": (16, "matern32", "f64")}[args.config]
+    args.members = args.members or preset[0]
+    args.kernel = args.kernel or preset[1]
+    args.dtype = args.dtype or preset[2]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                       # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must match")
 
-    force_comm = bool(os.environ.get("BAYENS_FORCE_COMM"))    # exercise the RCCL path with a single rank
-    if world > 1 or force_comm:
-        # torch (gloo) is the control plane of the multi-process run.  It must be imported BEFORE libbayens: torch
-        # bundles its own libamdhip64 / librccl (same sonames as /opt/rocm's); whichever HIP runtime is loaded
-        # first is the one the whole process uses, and RCCL only initialises on the runtime it was built against.
-        import torch.distributed as dist
     from bayesian_ensembling_amd import _lib, parallel
     n_dev = _lib.device_count()
     if n_dev <= 0:
         raise SystemExit("no HIP device visible: the hot path needs an MI355X (there is no CPU fallback)")
+    if local_rank >= n_dev and args.exchange == "rccl" and n_dev != 1:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} device(s) visible")
     ctx = _lib.Context(local_rank % n_dev)  # (a launcher may expose a single device to every rank)
     ctx.set_groups(args.groups)
-    host = None
+    exchange, rdzv = None, None
+    force_comm = bool(os.environ.get("BAYENS_FORCE_COMM"))    # exercise the RCCL path with a single rank
     if world > 1 or force_comm:
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only (barrier, max, uid)
-        host = parallel.HostGather()
-        parallel.init_rccl(ctx, host)       # data plane: ncclAllGather over xGMI inside libbayens
+        rdzv = parallel.FileRendezvous(parallel.FileRendezvous.directory_from_env(), rank, world)
+        exchange = parallel.RcclExchange(ctx, rdzv) if args.exchange == "rccl" else parallel.HostStagedExchange(ctx, rdzv)
 
-    M, N, R, T, R_obs = args.members, args.timesteps, args.realisations, args.nits, 3
-    kid = _lib.KERNEL_IDS[args.kernel]
-    X, y, nu, obs = make_inputs(M, N, R, R_obs, seed=0xB4E5 + rank)
+    M, N, R, T = args.members, args.timesteps, args.realisations, args.nits
     f32 = args.dtype == "f32"
-    dt = np.float32 if f32 else np.float64
-    dX, dy, dnu, dobs = ctx.to_device(X, dt), ctx.to_device(y, dt), ctx.to_device(nu, dt), ctx.to_device(obs)
-    dmu, dcov, dchol = ctx.empty((M, N), dt), ctx.empty((M, N, N), dt), ctx.empty((M, N, N), dt)
-    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N), dt)
-    if f32:    # the weight / scheme kernels take fp64 tables: the fp32 posterior's [M][N] rows are widened (a few MB)
-        dmu64, dbasis64 = ctx.empty((M, N)), ctx.empty((M, 2, N))
-    else:
-        dmu64, dbasis64 = dmu, dbasis
-    Mtot = M * world
-    dll_loc, dvar_loc = ctx.empty((M, N)), ctx.empty((M, N))
-    if host:
-        dll_all, dmean_all, dvar_all = ctx.empty((Mtot, N)), ctx.empty((Mtot, N)), ctx.empty((Mtot, N))
-    else:
-        dll_all, dmean_all, dvar_all = dll_loc, dmu64, dvar_loc
-    dw, dbmu, dbvar = ctx.empty((Mtot, N)), ctx.empty((N,)), ctx.empty((N,))
-
-    def fit():
-        return ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, kernel=kid, basis=dbasis,
-                                    f32=f32)
-
-    def weighted_posterior():
-        # LogLikelihoodWeight rows + posterior marginals of the local members, exchange of the [M, N] rows over
-        # RCCL (log-likelihoods, means, variances), then normalisation over ALL members and the barycentre
-        if not host and not f32:
-            # one GPU: the whole weighted posterior (rows -> weights -> barycentre) is one entry point, one host wait
-            return ctx.weighted_posterior_dev(M, N, R_obs, dbasis, dld, dobs, dmu, dcov, dw, dbmu, dbvar, c_std=1e-3)
-        if f32:
-            ctx.widen_f32_dev(M * 2 * N, dbasis, dbasis64)
-            ctx.widen_f32_dev(M * N, dmu, dmu64)
-        ctx.loglik_rows_basis_dev(M, N, R_obs, dbasis64, dld, dobs, dll_loc)
-        ctx.extract_diag_dev(M, N, dcov, dvar_loc, f32=f32)
-        if host:
-            ctx.allgather_rows(dll_loc, dll_all, M, N)
-            ctx.allgather_rows(dmu64, dmean_all, M, N)
-            ctx.allgather_rows(dvar_loc, dvar_all, M, N)
-        ctx.weights_normalise_dev(Mtot, N, dll_all, 1e-3, dw)
-        return ctx.barycentre_dev(Mtot, N, dw, dmean_all, dvar_all, dbmu, dbvar)
-
-    def step():
-        fit()
-        return weighted_posterior()
-
-    def barrier():
-        ctx.sync()
-        if host:
-            host.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if host:
-        elapsed = host.max_float(elapsed)
+    wl = Workload(ctx, M, N, R, T, args.kernel, f32, rank, world, exchange, args.groups)
+    elapsed = wl.timed(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
-    value = Mtot * args.steps / elapsed
+    value = wl.Mtot * args.steps / elapsed
+    rccl_lib = ctx.comm_info()[2] if exchange is not None and args.exchange == "rccl" else None
+    if exchange is not None:        # every rank leaves the communicator here; what follows on rank 0 is local
+        exchange.close()
+        rdzv.close()
+    if rank != 0:
+        return
 
-    # ---- untimed diagnostics on rank 0: latencies with HIP events, GEMM roofline, CPU baseline ----
-    extra = {}
-    roof = None
+    # ---- untimed diagnostics on rank 0 (no collectives): latencies with HIP events, GEMM roofline, CPU baseline ----
+    peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
+    ctx.timer_start(); wl.fit(); fit_ms = ctx.timer_stop()
+    ctx.timer_start(); bad = wl.weighted_posterior(local_only=True); wp_ms = ctx.timer_stop()
+    ll_chol_ms = None
+    if not f32:     # the stand-alone entry point (mu, chol, logdet -> rows) for comparison
+        ctx.timer_start(); ctx.loglik_rows_dev(M, N, wl.R_obs, wl.dmu, wl.dchol, wl.dld, wl.dobs, wl.dll_loc); ll_chol_ms = ctx.timer_stop()
+    roof = wl.roofline()
+    ctx.set_groups(args.groups)
+    fit_tfl = M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12
+    extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
+             "fit_algorithmic_tflops": round(fit_tfl, 3), "fit_frac_of_mfma_peak": round(fit_tfl / peak, 4),
+             "barycentre_not_converged": int(bad),
+             "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4)}
     cpu = None
-    if rank == 0:
-        ctx.timer_start(); fit(); fit_ms = ctx.timer_stop()
-        ctx.timer_start(); bad = weighted_posterior(); wp_ms = ctx.timer_stop()
-        # the stand-alone entry point (mu, chol, logdet -> rows: two triangular solves per member) for comparison
-        ll_chol_ms = None
-        if not f32:
-            ctx.timer_start(); ctx.loglik_rows_dev(M, N, R_obs, dmu, dchol, dld, dobs, dw); ll_chol_ms = ctx.timer_stop()
-        ctx.set_groups(1)                 # per-kernel durations are only meaningful when kernels do not overlap
-        fit()
-        ctx.timer_start(); fit(); fit_serial_ms = ctx.timer_stop()
-        ctx.profile_enable(True)
-        fit()
-        p = ctx.profile_get(1)            # the dominant kernel: gemm_f64_mfma<false,true> (A row-major, B^T)
-        p_all = ctx.profile_get(0)
-        stages = ctx.profile_stages()
-        if os.environ.get("BAYENS_PRINT_SHAPES"):
-            print(ctx.profile_shapes(), file=sys.stderr, flush=True)
-        ctx.profile_enable(False)
-        if os.environ.get("BAYENS_PRINT_STAGES"):
-            print(stages, file=sys.stderr, flush=True)
-        ctx.set_groups(args.groups)
-        gemm_tflops = p["flop"] / (p["ms"] * 1e-3) / 1e12
-        traffic = None     # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
-        peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
-        kname = "bayens_f32::gemm_f32_mfma" if f32 else "bayens::gemm_f64_mfma"
-        try:
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if files and not f32:    # (the PMC passes were collected on the fp64 instance)
-                traffic = round(json.load(open(files[-1]))["hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
-        group_tflops = p_all["flop"] / (p_all["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": kname + "<false, true>", "achieved": round(gemm_tflops, 3),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
-                "launches_per_fit_batch": p["launches"],
-                "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 2),
-                "kernel_ms_per_fit_batch": round(p["ms"], 3),
-                "gemm_group": {"kernels": kname.split("::")[1] + "<*>, gemm_panel64, trsm_panel_kernel",
-                               "achieved": round(group_tflops, 3), "frac": round(group_tflops / peak, 4),
-                               "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
-                "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
-                "note": "HIP events around every launch of the kernel in one fit batch, one stream (no overlap); "
-                        "traffic = HBM bytes per launch of this kernel from the rocprofv3 --pmc passes in profiles/*_pmc_traffic.json"}
-        extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
-                 "fit_algorithmic_tflops": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12, 3),
-                 "fit_frac_of_mfma_peak": round(M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12 / peak, 4),
-                 "barycentre_not_converged": int(bad),
-                 "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4)}
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(N, R, T, args.cpu_members)
-    if host:
-        host.barrier()
-        ctx.comm_destroy()
-        dist.destroy_process_group()
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, R, T, args.cpu_members)
 
-    if rank == 0:
-        out = {
-            "metric": "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step ensemble",
-            "value": round(value, 3), "unit": "member-fits/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{M}-member x {N}-timestep synthetic ensemble per GPU, R={R} realisations, "
-                                   f"{args.kernel} VGP fit (n_optim_nits={T}) + LogLikelihoodWeight(c=1e-3) + Barycentre",
-                       "members_per_gpu": M, "timesteps": N, "realisations": R, "n_optim_nits": T,
-                       "kernel": args.kernel, "obs_realisations": R_obs, "member_groups": args.groups,
-                       "parallelism": f"member-sharded x{world}, RCCL all-gather of [M,3,N] rows" if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        out.update(extra)
-        print(json.dumps(out), flush=True)
+    # ---- extra lines (single GPU, the headline preset): API-default iteration count, config 3, the RBF wording ----
+    if world == 1 and not args.no_extras and args.config == "c2" and (M, N, T, args.kernel, f32) == (32, 2000, 2, "matern32", False):
+        ctx.timer_start(); wl.fit(T=500); t500_ms = ctx.timer_stop()
+        extra["n_optim_nits_500"] = {
+            "member_fits_per_s": round(M / (t500_ms * 1e-3), 3), "fit_batch_s": round(t500_ms * 1e-3, 3),
+            "fit_algorithmic_tflops": round(M * fit_flops(N, R, 500) / (t500_ms * 1e-3) / 1e12, 3),
+            "note": "the API default n_optim_nits=500 (ensembles/models.py:167), same 32 x 2000 batch, one fit batch"}
+        wl.free()
+        for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):
+            w2 = Workload(ctx, M, N, R, T, kern, is32, 0, 1, None)
+            el = w2.timed(3, 1)
+            r2 = w2.roofline()
+            extra[key] = {"value": round(M * 3 / el, 3), "unit": "member-fits/s", "ms_per_step": round(el / 3 * 1e3, 3),
+                          "dtype": "f32" if is32 else "f64", "kernel": kern,
+                          "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                          "frac_on_padded_dims", "avg_launch_us")}}
+            w2.free()
+
+    out = {
+        "metric": METRIC, "value": round(value, 3), "unit": "member-fits/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{M}-member x {N}-timestep synthetic ensemble per GPU, R={R} realisations, "
+                               f"{args.kernel} VGP fit (n_optim_nits={T}) + LogLikelihoodWeight(c=1e-3) + Barycentre",
+                   "preset": args.config, "members_per_gpu": M, "members_total": M * world, "timesteps": N,
+                   "realisations": R, "n_optim_nits": T, "kernel": args.kernel, "obs_realisations": wl.R_obs,
+                   "member_groups": args.groups,
+                   "parallelism": (f"member-sharded x{world}, one RCCL all-gather of packed [M_loc,3,N] rows per step"
+                                   if world > 1 else "single GPU"),
+                   "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    out.update(extra)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

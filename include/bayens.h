@@ -35,7 +35,8 @@ enum {
   BAYENS_E_NOTPD = -2,    /* a Cholesky pivot was not positive; info[] holds member-wise pivots */
   BAYENS_E_NOGPU = -3,    /* no HIP device / kernel image not loadable */
   BAYENS_E_COMM = -4,     /* RCCL not initialised or not loadable */
-  BAYENS_E_ALLOC = -5
+  BAYENS_E_ALLOC = -5,
+  BAYENS_E_NOCONV = -6    /* an iteration (the polar iteration of bayens_w2_single) did not converge: outputs invalid */
 };
 
 /* ---- context, memory and timing plumbing -------------------------------------------------- */
@@ -199,8 +200,23 @@ int bayens_dba_batch(bayens_ctx* ctx, int loc, int B, int R, int N, const double
 int bayens_comm_unique_id(bayens_ctx* ctx, void* id128);            /* 128-byte ncclUniqueId, rank 0 */
 int bayens_comm_init(bayens_ctx* ctx, int rank, int nranks, const void* id128);
 int bayens_comm_destroy(bayens_ctx* ctx);
-/* local [M_loc][P] device rows -> all [nranks*M_loc][P] device rows (ncclAllGather on the ctx stream) */
+/* rank / size of the communicator (nranks 0 = none) and the path of the RCCL library that was loaded */
+int bayens_comm_info(bayens_ctx* ctx, int* rank, int* nranks, char* lib_path, int lib_path_len);
+/* local [M_loc][P] device rows -> all [nranks*M_loc][P] device rows (ncclAllGather on the ctx stream).  Every rank
+ * must pass the same M_loc and all_dev must hold nranks * M_loc rows. */
 int bayens_allgather_rows(bayens_ctx* ctx, const double* local_dev, double* all_dev, int M_loc, int P);
+/* Block partition of M members over nranks ranks (the first M % nranks ranks own one member more): members
+ * [*lo, *hi) belong to `rank`.  Pure host arithmetic, no context needed. */
+int bayens_shard_bounds(int M, int rank, int nranks, int* lo, int* hi);
+/* The exchange step of the member-sharded weighted posterior (the reference couples the members only in
+ * the normalisation ensembles/weights.py:118-123 and the barycentre ensemble_scheme.py:52-78): this rank's M_loc =
+ * hi - lo rows of mean log-likelihood, posterior mean and posterior variance ([M_loc][P] each, device) -> the full
+ * [M][P] tables on every rank, in ONE ncclAllGather of packed [ceil(M/nranks)][3][P] rows.  M need not divide evenly. */
+int bayens_allgather_member_rows(bayens_ctx* ctx, int M, int P, int M_loc, const double* ll_loc, const double* mean_loc,
+                                 const double* var_loc, double* ll_all, double* mean_all, double* var_all);
+/* all-reduce(max) of one host double over the communicator (through HBM, ncclAllReduce); returns after the ctx stream
+ * has drained on every rank, so it is also the barrier of the multi-GPU timing protocol */
+int bayens_comm_max(bayens_ctx* ctx, double* value);
 
 /* ---- diagnostic entry points used by the GPU unit tests (device primitives, batched) ------- */
 /* C = alpha * op(A) op(B) + beta * C on host buffers; flags as in csrc/prims.h */

@@ -189,15 +189,66 @@ def test_fp32_full_size_is_finite_and_close_to_fp64(ctx):
     assert relerr(o32["hyp"], o64["hyp"]) < F32_TOL
 
 
-def test_recorded_iteration_replay_is_bit_identical(ctx, monkeypatch):
-    """BAYENS_SEQ=1: the optimiser iteration recorded into a hipGraph and replayed gives the same bits."""
-    data, _ = go.synthetic_ensemble(3, 150, R=4, seed=8)
+@pytest.mark.parametrize("M", [16, 32])
+def test_benchmarked_batch_sizes_small_members_all_against_the_oracle(ctx, M):
+    """The bench's batch (32 members) and config 4's per-GPU share (16): every member vs the oracle at N = 200."""
+    data, _ = go.synthetic_ensemble(M, 200, R=8, seed=40 + M)
     X, y, nu = member_inputs(data)
-    plain = ctx.gp_fit_batch(X, y, nu, 30, want_loss=True)
-    monkeypatch.setenv("BAYENS_SEQ", "1")
-    replay = ctx.gp_fit_batch(X, y, nu, 30, want_loss=True)
-    for k in ("mu", "cov", "chol", "logdet", "hyp", "basis", "loss"):
-        assert np.array_equal(plain[k], replay[k]), k
+    out = ctx.gp_fit_batch(X, y, nu, 2)
+    assert not out["info"].any()
+    with threadpool_limits(1):
+        for m in range(M):
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], 2)
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m], mo) < 1e-10 and relerr(out["cov"][m], co) < 1e-10, m
+            assert relerr(out["chol"][m], Lc) < 1e-10 and relerr(out["hyp"][m], ho) < 1e-10, m
+            assert abs(out["logdet"][m] - ld) < 1e-9 * max(1.0, abs(ld)), m
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_benchmarked_configuration_full_size(ctx, M):
+    """BASELINE config 2 exactly as bench.py runs it (32 x 2000, R = 8, T = 2; 16 = config 4's per-GPU share), on
+    resident buffers: members 0 / M/2-1 / M-1 against the oracle, and EVERY member bit-equal to the same member fitted
+    in a batch of 4 (the triangular GEMM launches deal tiles differently when nb % 8 == 0, gemm.hip)."""
+    N, R, T = 2000, 8, 2
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=0xB4E5)
+    X, y, nu = member_inputs(data)
+    dX, dy, dnu = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu)
+    dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
+    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
+    bufs = [dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis]
+    try:
+        info = ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
+        assert not info.any()
+        mu, hyp, ld, basis = dmu.download(), dhyp.download(), dld.download(), dbasis.download()
+        for b0 in range(0, M, 4):
+            ref = ctx.gp_fit_batch(X[b0:b0 + 4], y[b0:b0 + 4], nu[b0:b0 + 4], T)
+            assert np.array_equal(mu[b0:b0 + 4], ref["mu"]) and np.array_equal(hyp[b0:b0 + 4], ref["hyp"]), b0
+            assert np.array_equal(ld[b0:b0 + 4], ref["logdet"]) and np.array_equal(basis[b0:b0 + 4], ref["basis"]), b0
+            for j in range(4):     # covariance and factor member by member (32 MB each)
+                cov = np.empty((N, N)); ch = np.empty((N, N))
+                ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, cov.ctypes.data, dcov.offset((b0 + j) * N * N * 8), cov.nbytes))
+                ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, ch.ctypes.data, dchol.offset((b0 + j) * N * N * 8), ch.nbytes))
+                assert np.array_equal(cov, ref["cov"][j]) and np.array_equal(ch, ref["chol"][j]), b0 + j
+                if b0 + j in (0, M // 2 - 1, M - 1):
+                    mo, co, ho = go.gp_fit(X[b0 + j], y[b0 + j], nu[b0 + j], T)
+                    assert relerr(mu[b0 + j], mo) < 1e-9 and relerr(cov, co) < 1e-9 and relerr(hyp[b0 + j], ho) < 1e-9
+    finally:
+        for b in bufs:
+            b.free()
+
+
+def test_config3_full_size_against_the_fp64_oracle(ctx):
+    """BASELINE config 3 at size: fp32 Matern-5/2, N = 2000 - one member against the float64 ORACLE (1e-3)."""
+    data, _ = go.synthetic_ensemble(2, 2000, R=8, seed=2)
+    X, y, nu = member_inputs(data)
+    o32 = ctx.gp_fit_batch(X, y, nu, 2, kernel=1, dtype=np.float32)
+    assert not o32["info"].any()
+    mo, co, ho = go.gp_fit(X[0], y[0], nu[0], 2, kernel=1)
+    Lc, ld = go.mvn_factor(co)
+    assert relerr(o32["mu"][0].astype(np.float64), mo) < F32_TOL and relerr(o32["cov"][0].astype(np.float64), co) < F32_TOL
+    assert relerr(o32["chol"][0].astype(np.float64), Lc) < F32_TOL and relerr(o32["hyp"][0], ho) < F32_TOL
+    assert abs(o32["logdet"][0] - ld) < F32_TOL * abs(ld)
 
 
 def test_member_groups_do_not_change_the_result(ctx):

@@ -35,9 +35,12 @@ def test_gemm_is_exact_on_integer_data_with_asymmetric_operands(ctx):
     assert np.array_equal(out, A @ B)
 
 
-def test_gemm_triangular_output_and_ktrim(ctx):
-    rng = np.random.default_rng(5)
-    nb, n = 2, 320
+@pytest.mark.parametrize("nb", [2, 16, 32])
+def test_gemm_triangular_output_and_ktrim(ctx, nb):
+    # nb = 16 / 32: the member-interleaved tile dealing of triangular launches with nb % 8 == 0 and more than one
+    # member per XCD (gemm.hip: mpc = nb >> 3 > 1) - the branch the 32-member bench and config 4's 16-member share run
+    rng = np.random.default_rng(5 + nb)
+    n = 320
     A = np.tril(rng.standard_normal((nb, n, n)))
     B = np.tril(rng.standard_normal((nb, n, n)))
     C0 = rng.standard_normal((nb, n, n))

@@ -70,7 +70,8 @@ def test_w2_temporal(ctx):
     assert relerr(ctx.w2_temporal(mean, var), go.w2_weights_temporal(mean, var)) < 1e-13
 
 
-@pytest.mark.parametrize("M,N", [(4, 40), (3, 100), (5, 64)])
+@pytest.mark.parametrize("M,N", [(4, 40), (3, 100), (5, 64), (4, 1000)])    # (4, 1000): fitted covariances at size - the
+# polar iteration's convergence depends on their conditioning (6 pairs; the oracle's SVD takes ~1 s per pair)
 def test_w2_single_full_covariance(ctx, M, N):
     """mode='single' (weights.py:240-265): all-pairs Gaussian W2 with SVD-based sqrtm in the oracle, polar iteration
     on L_j^T L_i on the device."""

@@ -1,7 +1,9 @@
-"""world_size-2 gloo rehearsal of the multi-GPU exchange: each rank owns a block of members,
-packs [M_loc, 3, P] rows, all-gathers them and computes the replicated weights + barycentre.  The per-member
-rows come from the oracle here (no GPU in this container); on the GPU the same `weighted_posterior_sharded`
-runs over ncclAllGather."""
+"""world_size-2 rehearsals of the multi-GPU exchange on the CPU.  Each rank owns a block of members,
+contributes its [M_loc, P] rows of mean log-likelihood / mean / variance, and `parallel.weighted_posterior_sharded` -
+the SAME function bench.py's N > 1 leg calls with the RCCL transport - gathers them and computes the replicated
+weights + barycentre.  Transports here: gloo (`HostGather`) and the file rendezvous that bootstraps RCCL
+(`FileRendezvous`).  The per-member rows and the normalise / barycentre callbacks come from the oracle (no GPU in
+this container)."""
 import os
 import socket
 
@@ -23,44 +25,87 @@ def test_shard_bounds_cover_everything():
             assert max(h - l for l, h in spans) == parallel.padded_rows(M, W)
 
 
+def test_shard_bounds_match_the_c_abi():
+    import ctypes
+    from bayesian_ensembling_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)          # pure host arithmetic: callable without a GPU
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    for M in (0, 1, 5, 16, 33, 128):
+        for W in (1, 2, 3, 8):
+            for r in range(W):
+                assert lib.bayens_shard_bounds(M, r, W, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == parallel.shard_bounds(M, r, W)
+    assert lib.bayens_shard_bounds(4, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == -1
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, M, P, out_dir):
+def _tables(M, P):
+    rng = np.random.default_rng(11)
+    return -50.0 - 30.0 * rng.random((M, P)), rng.standard_normal((M, P)), rng.uniform(0.05, 2.0, (M, P))
+
+
+def _run_rank(rank, world, exchange, M, P, out_dir):
+    ll, mean, var = _tables(M, P)
+    lo, hi = parallel.shard_bounds(M, rank, world)
+    w, mu, v = parallel.weighted_posterior_sharded(
+        M, ll[lo:hi], mean[lo:hi], var[lo:hi], exchange,
+        lambda l, c: go.loglik_weights(l, c)[0], lambda w_, m_, v_: go.barycentre(w_, m_, v_), c_std=1e-2)
+    uid = exchange.broadcast_bytes(bytes(range(128)) if rank == 0 else b"", 128)
+    tmax = exchange.max_float(float(rank + 1))
+    exchange.barrier()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), w=w, mu=mu, v=v, uid=np.frombuffer(uid, dtype=np.uint8), tmax=tmax)
+
+
+def _gloo_worker(rank, world, port, M, P, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rng = np.random.default_rng(11)
-        ll = -50.0 - 30.0 * rng.random((M, P))
-        mean = rng.standard_normal((M, P))
-        var = rng.uniform(0.05, 2.0, (M, P))
-        lo, hi = parallel.shard_bounds(M, rank, world)
-        host = parallel.HostGather()
-        w, mu, v = parallel.weighted_posterior_sharded(
-            M, ll[lo:hi], mean[lo:hi], var[lo:hi], host,
-            lambda l, c: go.loglik_weights(l, c)[0], lambda w_, m_, v_: go.barycentre(w_, m_, v_), c_std=1e-2)
-        uid = host.broadcast_bytes(bytes(range(128)) if rank == 0 else b"", 128)
-        tmax = host.max_float(float(rank + 1))
-        host.barrier()
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), w=w, mu=mu, v=v, uid=np.frombuffer(uid, dtype=np.uint8), tmax=tmax)
+        _run_rank(rank, world, parallel.HostGather(), M, P, out_dir)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("M", [5, 8])
-def test_two_rank_gather_matches_single_process(tmp_path, M):
-    P, world = 37, 2
-    mp.spawn(_worker, args=(world, _free_port(), M, P, str(tmp_path)), nprocs=world, join=True)
-    rng = np.random.default_rng(11)
-    ll = -50.0 - 30.0 * rng.random((M, P))
-    mean = rng.standard_normal((M, P))
-    var = rng.uniform(0.05, 2.0, (M, P))
+def _file_worker(rank, world, rdzv_dir, M, P, out_dir):
+    ex = parallel.FileRendezvous(rdzv_dir, rank, world, timeout_s=60)
+    _run_rank(rank, world, ex, M, P, out_dir)
+    ex.close()
+
+
+def _check(tmp_path, M, P, world):
+    ll, mean, var = _tables(M, P)
     w_ref, _ = go.loglik_weights(ll, 1e-2)
     mu_ref, v_ref, _ = go.barycentre(w_ref, mean, var)
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(got["w"], w_ref) and np.array_equal(got["mu"], mu_ref) and np.array_equal(got["v"], v_ref)
-        assert list(got["uid"]) == list(range(128)) and got["tmax"] == 2.0
+        assert list(got["uid"]) == list(range(128)) and got["tmax"] == float(world)
+
+
+@pytest.mark.parametrize("M", [5, 8])
+def test_two_rank_gather_matches_single_process(tmp_path, M):
+    P, world = 37, 2
+    mp.spawn(_gloo_worker, args=(world, _free_port(), M, P, str(tmp_path)), nprocs=world, join=True)
+    _check(tmp_path, M, P, world)
+
+
+@pytest.mark.parametrize("M,world", [(5, 2), (7, 3)])
+def test_file_rendezvous_gather_matches_single_process(tmp_path, M, world):
+    """The transport that bootstraps RCCL (and rehearses N ranks on one GPU), uneven shards included."""
+    P = 29
+    rdzv = tmp_path / "rdzv"
+    mp.spawn(_file_worker, args=(world, str(rdzv), M, P, str(tmp_path)), nprocs=world, join=True)
+    _check(tmp_path, M, P, world)
+    assert not rdzv.exists()                      # rank 0 removed the rendezvous directory after the last round
+
+
+def test_w2_single_sharded_rejects_uneven_shards():
+    class FakeCtx:
+        def comm_info(self):
+            return 0, 2, "librccl"
+    with pytest.raises(ValueError, match="n_members=5"):
+        parallel.w2_single_sharded(FakeCtx(), 5, np.zeros((3, 4)), np.zeros((3, 4, 4)))
