@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 
@@ -462,8 +463,18 @@ class Context:
         return buf.raw
 
     def comm_init(self, rank, nranks, uid):
+        """Joins the communicator.  RCCL prints a version banner on the C-level stdout while initialising; it is sent
+        to stderr so that a program's stdout stays what the program itself prints (bench.py: ONE JSON line)."""
         buf = C.create_string_buffer(bytes(uid), 128)
-        self._check(self.lib.bayens_comm_init(self.h, rank, nranks, buf))
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = self.lib.bayens_comm_init(self.h, rank, nranks, buf)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        self._check(rc)
 
     def comm_destroy(self):
         self._check(self.lib.bayens_comm_destroy(self.h))

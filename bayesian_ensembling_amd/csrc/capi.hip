@@ -14,6 +14,7 @@
 #include "fit_f32.h"
 #include "fit_ws.h"
 #include "hip_prims.h"
+#include "small.h"
 
 using namespace bayens;
 
@@ -92,6 +93,7 @@ struct bayens_ctx {
     }
     return sscratch;
   }
+  int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -241,6 +243,10 @@ int bayens_ctx_create(int device, bayens_ctx** out) {
   (void)hipEventCreate(&c->t0);
   (void)hipEventCreate(&c->t1);
   c->prims = new HipPrims(c->stream);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+  }
   if (const char* env = getenv("BAYENS_STREAMS")) c->ngroups = std::max(1, std::min(16, atoi(env)));
   for (int g = 0; g < 16; ++g) {
     hipStream_t s = nullptr;
@@ -431,8 +437,11 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
+    // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
+    static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
+    const bool small = !no_small && smalln::small_fit_supported(N, R) && !(loss_trace && n_iters > 0);
     const int Np = pad_to_leaf(N);
-    ensure_ws(c, B, Np);
+    if (!small) ensure_ws(c, B, Np);
     Stage st(c, loc);
     const double* dX = st.in(X, (size_t)B * N * R);
     const double* dy = st.in(y_mean, (size_t)B * N);
@@ -443,6 +452,18 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     double* dld = st.out(logdet, (size_t)B);
     double* dhyp = st.out(hyp, (size_t)B * 2);
     double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
+    if (small) {
+      int* dinfo = st.scratch<int>((size_t)B);
+      smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo};
+      smalln::small_fit(c->stream, a, c->n_cus);
+      std::vector<int> hinfo(B, 0);
+      BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      st.finish();
+      int bad = 0;
+      for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+      if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
+      return 0;
+    }
     FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
     fp.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
     fp.loss_trace = fp.loss_stride > 0 ? st.out(loss_trace, (size_t)B * fp.loss_stride) : nullptr;

@@ -1,0 +1,32 @@
+// small.h - host interface of the fused small-member fit (small.hip): one workgroup per member, N <= SMALL_MAX_N.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bayens {
+namespace smalln {
+
+// 6 tiles of 16 per side, two padded rows reserved for the bordered Cholesky of the covariance (1^T, mu^T)
+constexpr int SMALL_MAX_N = 94;
+
+struct SmallArgs {
+  int B, N, R, kernel, n_iters;
+  double gamma, lr, jitter;
+  const double* X;       // [B][N][R]
+  const double* y;       // [B][N]
+  const double* nu;      // [B][N]
+  double* mu;            // [B][N]
+  double* cov;           // [B][N][N] or null (reduced export)
+  double* var;           // [B][N] = diag(cov) or null
+  double* chol;          // [B][N][N] or null
+  double* logdet;        // [B] or null
+  double* hyp;           // [B][2] or null
+  double* basis;         // [B][2][N] or null
+  int* info;             // [B]
+};
+
+bool small_fit_supported(int N, int R);
+// queues the fit of all B members on `stream` (grid = resident workgroups, members dealt round-robin)
+void small_fit(hipStream_t stream, const SmallArgs& args, int n_cus);
+
+}  // namespace smalln
+}  // namespace bayens
