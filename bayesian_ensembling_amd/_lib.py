@@ -71,6 +71,8 @@ def load():
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
+    lib.bayens_gp_fit_batch_reduced.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                                C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -107,6 +109,7 @@ def load():
     lib.bayens_bench_mfma_peak.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_bench_mfma_lds.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
+    lib.bayens_small_stamps.argtypes = [_vp, C.c_int, _vp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
     return lib
@@ -278,6 +281,30 @@ class Context:
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
                                           _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
         self._check(rc)
+        return info
+
+    def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
+        """Small members (N <= 94), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance)."""
+        X = _f64(X)
+        B, N, R = X.shape
+        y_mean, y_var = _f64(y_mean).reshape(B, N), _f64(y_var).reshape(B, N)
+        mu, var, logdet, hyp = np.empty((B, N)), np.empty((B, N)), np.empty(B), np.empty((B, 2))
+        basis, info = np.empty((B, 2, N)), np.zeros(B, dtype=np.int32)
+        rc = self.lib.bayens_gp_fit_batch_reduced(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+                                                  int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var), _ptr(logdet),
+                                                  _ptr(hyp), _ptr(info), _ptr(basis))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
+        return {"mu": mu, "var": var, "logdet": logdet, "hyp": hyp, "basis": basis, "info": info}
+
+    def gp_fit_batch_reduced_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, var, logdet=None, hyp=None, basis=None,
+                                 kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.bayens_gp_fit_batch_reduced(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),
+                                                         int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var),
+                                                         _ptr(logdet), _ptr(hyp), _ptr(info), _ptr(basis)))
         return info
 
     def mvn_factor_batch(self, cov, mu=None):
@@ -539,6 +566,12 @@ class Context:
         us = C.c_double()
         self._check(self.lib.bayens_bench_potrf(self.h, nb, n, reps, C.byref(us)))
         return us.value
+
+    def small_stamps(self, enable=True, read=False):
+        """Phase stamps of the fused small-member kernel (diagnostic); returns 32 uint64 when read=True."""
+        out = np.zeros(32, dtype=np.uint64) if read else None
+        self._check(self.lib.bayens_small_stamps(self.h, 1 if enable else 0, _ptr(out)))
+        return out
 
     def test_potrf(self, A):
         A = np.array(A, dtype=np.float64, order="C", copy=True)

@@ -94,6 +94,7 @@ struct bayens_ctx {
     return sscratch;
   }
   int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
+  unsigned long long* small_stamps = nullptr;   // diagnostic phase stamps of the fused kernel (bayens_small_stamps)
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -268,6 +269,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   if (c->f32) bayens_f32_destroy(c->f32);
   if (c->sscratch) (void)hipFree(c->sscratch);
   if (c->xbuf) (void)hipFree(c->xbuf);
+  if (c->small_stamps) (void)hipFree(c->small_stamps);
   for (auto* p : c->gprims) delete p;
   for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   delete c->prims;
@@ -439,7 +441,7 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
     // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
     static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
-    const bool small = !no_small && smalln::small_fit_supported(N, R) && !(loss_trace && n_iters > 0);
+    const bool small = !no_small && smalln::small_fit_supported(N, R);
     const int Np = pad_to_leaf(N);
     if (!small) ensure_ws(c, B, Np);
     Stage st(c, loc);
@@ -455,6 +457,9 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (small) {
       int* dinfo = st.scratch<int>((size_t)B);
       smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo};
+      a.stamps = c->small_stamps;
+      a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+      a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
       smalln::small_fit(c->stream, a, c->n_cus);
       std::vector<int> hinfo(B, 0);
       BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -474,6 +479,38 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     int bad = 0;
     for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
     if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
+    return 0;
+  });
+}
+
+int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
+                                const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
+                                double* mu, double* var, double* logdet, double* hyp, int* info, double* ll_basis) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !var || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: unknown kernel id");
+    if (!smalln::small_fit_supported(N, R))
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: N must be at most 94 (larger members: bayens_gp_fit_batch + bayens_extract_diag)");
+    Stage st(c, loc);
+    const double* dX = st.in(X, (size_t)B * N * R);
+    const double* dy = st.in(y_mean, (size_t)B * N);
+    const double* dnu = st.in(y_var, (size_t)B * N);
+    double* dmu = st.out(mu, (size_t)B * N);
+    double* dvar = st.out(var, (size_t)B * N);
+    double* dld = st.out(logdet, (size_t)B);
+    double* dhyp = st.out(hyp, (size_t)B * 2);
+    double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
+    int* dinfo = st.scratch<int>((size_t)B);
+    smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo};
+    a.stamps = c->small_stamps;
+    smalln::small_fit(c->stream, a, c->n_cus);
+    std::vector<int> hinfo(B, 0);
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch_reduced: matrix not positive definite (see info[])");
     return 0;
   });
 }
@@ -1034,6 +1071,21 @@ int bayens_comm_max(bayens_ctx* c, double* value) {
     if (r != 0) return fail(c, BAYENS_E_COMM, "ncclAllReduce failed");
     BAYENS_HIP(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BAYENS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  });
+}
+
+int bayens_small_stamps(bayens_ctx* c, int enable, unsigned long long* stamps32) {
+  return guarded(c, [&]() {
+    if (enable && !c->small_stamps) {
+      BAYENS_HIP(hipMalloc((void**)&c->small_stamps, 32 * sizeof(unsigned long long)));
+      BAYENS_HIP(hipMemset(c->small_stamps, 0, 32 * sizeof(unsigned long long)));
+    }
+    if (stamps32 && c->small_stamps) {
+      BAYENS_HIP(hipStreamSynchronize(c->stream));
+      BAYENS_HIP(hipMemcpy(stamps32, c->small_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (!enable && c->small_stamps) { (void)hipFree(c->small_stamps); c->small_stamps = nullptr; }
     return 0;
   });
 }

@@ -22,6 +22,9 @@ struct SmallArgs {
   double* hyp;           // [B][2] or null
   double* basis;         // [B][2][N] or null
   int* info;             // [B]
+  double* loss = nullptr;   // [B][loss_stride]: -ELBO after iterations 0, 25, 50, ... (models.py:211-215) or null
+  int loss_stride = 0;
+  unsigned long long* stamps = nullptr;   // diagnostic: 32 cycle-counter stamps of workgroup 0 (null in production)
 };
 
 bool small_fit_supported(int N, int R);

@@ -35,6 +35,11 @@ constexpr int NTH = NW * 64;
 constexpr double SQRT3 = 1.7320508075688772;
 constexpr double SQRT5 = 2.23606797749979;
 
+__device__ __forceinline__ double* lds_base() {
+  extern __shared__ __attribute__((aligned(16))) double lds_block[];
+  return lds_block;
+}
+
 struct Lane {
   int rc[4];   // rc[q] = swizzled offset of element (lr, 4q + lk)
   int cr[4];   // cr[q] = swizzled offset of element (4q + lk, lr)   (= accumulator register q of this lane)
@@ -49,7 +54,11 @@ __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
   j = p - ((i * (i + 1)) >> 1);
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
-#define SYNC() __syncthreads()
+// Workgroup barrier for LDS traffic only: every hand-off between waves goes through LDS, global memory holds read-only
+// inputs and write-only outputs, so the barrier must not wait for outstanding global stores (__syncthreads() does).
+#define SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// diagnostic: wave 0 / lane 0 of workgroup 0 stamps the phase boundaries of its member (g.stamps null in production)
+#define STAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[k] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ v4d ld_tile(const double* t, const Lane& o) {
   v4d a;
@@ -73,6 +82,28 @@ __device__ __forceinline__ v4d mma(v4d acc, const double* A, const double* B, co
   return acc;
 }
 
+// acc += sum_{k0 <= k < k1} A_k B_k with the operands of step k+1 requested before the MFMAs of step k are issued:
+// la(k, q) / lb(k, q) return this lane's A / B operand of MFMA q of step k (LDS reads)
+template <class LoadA, class LoadB>
+__device__ __forceinline__ v4d acc_run(v4d acc, int k0, int k1, LoadA la, LoadB lb) {
+  if (k0 >= k1) return acc;
+  double a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = la(k0, q); b[q] = lb(k0, q); }
+#pragma unroll 1
+  for (int k = k0; k < k1; ++k) {
+    const int kn = k + 1 < k1 ? k + 1 : k;
+    double an[4], bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { an[q] = la(kn, q); bn[q] = lb(kn, q); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = MFMA(a[q], b[q], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; }
+  }
+  return acc;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -80,44 +111,83 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ double softplus_d(double u) { return u > 30.0 ? u : log1p(exp(u)); }
 
-__device__ __forceinline__ void kern_eval(int kernel, double var, double ls, double r2, double& K, double& dK) {
+// exp(x) for x <= 0 (the kernels only exponentiate -c r): n = rint(x log2 e), Cody-Waite reduction, degree-13 Taylor
+// polynomial on |t| <= ln2 / 2 (truncation 4e-18), 2^n by v_ldexp_f64.  ~20 instructions against ~35 of the library exp.
+__device__ __forceinline__ double exp_neg(double x) {
+  x = x < -745.0 ? -745.0 : x;
+  const double n = rint(x * 1.4426950408889634);
+  double t = fma(n, -0.6931471803691238, x);
+  t = fma(n, -1.9082149292705877e-10, t);
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = fma(p, t, 2.08767569878681e-09);               // 1/12!
+  p = fma(p, t, 2.505210838544172e-08);              // 1/11!
+  p = fma(p, t, 2.755731922398589e-07);              // 1/10!
+  p = fma(p, t, 2.7557319223985893e-06);             // 1/9!
+  p = fma(p, t, 2.48015873015873e-05);               // 1/8!
+  p = fma(p, t, 0.0001984126984126984);              // 1/7!
+  p = fma(p, t, 0.001388888888888889);               // 1/6!
+  p = fma(p, t, 0.008333333333333333);               // 1/5!
+  p = fma(p, t, 0.041666666666666664);               // 1/4!
+  p = fma(p, t, 0.16666666666666666);                // 1/3!
+  p = fma(p, t, 0.5);
+  p = fma(p, t, 1.0);
+  p = fma(p, t, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+// sqrt(d), d >= 1e-36: v_rsq_f64 seed (2^-26) and two Goldschmidt corrections
+__device__ __forceinline__ double sqrt_pos(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double r = d * y;
+  const double h = 0.5 * y;
+  r = fma(fma(-r, r, d), h, r);
+  r = fma(fma(-r, r, d), h, r);
+  return r;
+}
+// The stationary kernels in unit-variance form (GPflow 2.1.5; Matern-3/2 is the one the reference instantiates,
+// models.py:186):  K = variance * k1,  dK/dlengthscale = (variance / lengthscale) * cl * k2  with
+//   Matern-3/2  k1 = (1 + sqrt3 r) e^{-sqrt3 r}             k2 = r^2 e^{-sqrt3 r}               cl = 3
+//   Matern-5/2  k1 = (1 + sqrt5 r + 5/3 r^2) e^{-sqrt5 r}   k2 = r^2 (1 + sqrt5 r) e^{-sqrt5 r}  cl = 5/3
+//   RBF         k1 = e^{-r2/2}                              k2 = r2 e^{-r2/2}                    cl = 1
+// r = sqrt(max(r2, 1e-36)); entries on the clamp branch contribute no lengthscale gradient.
+template <bool GRAD>
+__device__ __forceinline__ void kern_unit(int kernel, double r2, double& k1, double& k2) {
+  k2 = 0.0;
   if (kernel == 2) {
     const double r2c = r2 > 0.0 ? r2 : 0.0;
-    K = var * exp(-0.5 * r2c);
-    dK = K * r2c / ls;
+    k1 = exp_neg(-0.5 * r2c);
+    if (GRAD) k2 = r2c * k1;
     return;
   }
   const bool clamp = r2 <= 1e-36;
-  const double r = sqrt(r2 > 1e-36 ? r2 : 1e-36);
+  const double r = sqrt_pos(clamp ? 1e-36 : r2);
   if (kernel == 0) {
-    const double e = exp(-SQRT3 * r);
-    K = var * (1.0 + SQRT3 * r) * e;
-    dK = 3.0 * var * r * r * e / ls;
+    const double e = exp_neg(-SQRT3 * r);
+    k1 = fma(SQRT3, r, 1.0) * e;
+    if (GRAD) k2 = clamp ? 0.0 : r * r * e;
   } else {
-    const double e = exp(-SQRT5 * r);
-    K = var * (1.0 + SQRT5 * r + (5.0 / 3.0) * r * r) * e;
-    dK = (5.0 / 3.0) * var * r * r * (1.0 + SQRT5 * r) * e / ls;
+    const double e = exp_neg(-SQRT5 * r);
+    const double q = fma(SQRT5, r, 1.0);
+    k1 = fma((5.0 / 3.0) * r, r, q) * e;
+    if (GRAD) k2 = clamp ? 0.0 : r * r * q * e;
   }
-  if (clamp) dK = 0.0;
 }
+__device__ __forceinline__ double kern_cl(int kernel) { return kernel == 0 ? 3.0 : (kernel == 1 ? 5.0 / 3.0 : 1.0); }
 
-// ---- 16x16 diagonal tile: Cholesky + inverse of the factor in registers (one wave; the tile is replicated in the
-// four 16-lane rows, lane l owns row l & 15; pivots and columns travel by DPP row broadcast; 1/L_ii from a Newton-
-// refined v_rsq_f64).  T: the tile (lower part read; factor written back with zeros above the diagonal);
-// Dk: inverse of the factor (zeros above the diagonal).  Same routine as leaf_factor's P1 in kernels.hip.
-template <int K>
-__device__ __forceinline__ double bcast16_k(double v) {
-  return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false);
-}
-__device__ __forceinline__ double readlane_d(double v, int k) {
-  switch (k) {
-    case 0: return bcast16_k<0>(v);   case 1: return bcast16_k<1>(v);   case 2: return bcast16_k<2>(v);
-    case 3: return bcast16_k<3>(v);   case 4: return bcast16_k<4>(v);   case 5: return bcast16_k<5>(v);
-    case 6: return bcast16_k<6>(v);   case 7: return bcast16_k<7>(v);   case 8: return bcast16_k<8>(v);
-    case 9: return bcast16_k<9>(v);   case 10: return bcast16_k<10>(v); case 11: return bcast16_k<11>(v);
-    case 12: return bcast16_k<12>(v); case 13: return bcast16_k<13>(v); case 14: return bcast16_k<14>(v);
-    default: return bcast16_k<15>(v);
-  }
+// ---- 16x16 diagonal tile: Cholesky + inverse of the factor, one wave, the tile in ONE accumulator (4 doubles per
+// lane).  Four sub-steps of four columns; sub-step s:
+//   * register s of the (symmetric, fully updated) accumulator IS the 16x4 column panel V = A[:, 4s..4s+3] in MFMA
+//     operand layout (lane (lr, lk) holds A[4s+lk][lr] = A[lr][4s+lk]);
+//   * its 4x4 diagonal block (10 values) is broadcast with v_readlane and factored + inverted redundantly by every
+//     lane: four Newton-refined v_rsq_f64 in a row are the only serial chain (16 per tile instead of 16 column steps);
+//   * P = V M4^T (the factor's columns) is ONE v_mfma_f64_16x16x4 with A = M4 (zero-padded to 16x4), B = V: its result
+//     register 0 is P in operand layout again, so the rank-4 update A -= P P^T is the next MFMA, with no lane movement;
+//   * the inverse rides along: F starts as I, Q = M4 F[4s..4s+3, :] (= rows 4s.. of L^-1), F -= P Q - two more MFMAs
+//     off the critical path.
+// The factor leaves in operand layout (offsets rc[s]), the inverse in accumulator layout (cr[s]).  ~70 registers.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double((int)hi, (int)lo);
 }
 __device__ __forceinline__ double rsqrt_refined(double d) {
   double r = __builtin_amdgcn_rsq(d);
@@ -125,111 +195,167 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   const double e = fma(-d * r, r, 1.0);
   return fma(0.5 * r, e, r);
 }
-__device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivot_base, int& bad) {
-  double row[16], rinv[16], m[16];
-  const int li = lane & 15;
+__device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
+  v4d acc, fac;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) row[j] = T[swz(li, j)];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double d = readlane_d(row[j], j);
-    const bool ok = d > 0.0;
-    bad = (!ok && bad == 0) ? pivot_base + j + 1 : bad;
-    d = ok ? d : 1.0;
-    const double r = rsqrt_refined(d);
-    rinv[j] = r;
-    row[j] = li == j ? d * r : (li > j ? row[j] * r : 0.0);
-    const double lij = row[j];
-#pragma unroll
-    for (int k = j + 1; k < 16; ++k) {
-      const double lkj = readlane_d(row[j], k);
-      row[k] = fma(-lij, lkj, row[k]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < 4; ++r) {
+    const int row = o.lk + 4 * r, col = o.lr;
+    acc[r] = T[row >= col ? swz(row, col) : swz(col, row)];      // symmetric image from the lower triangle
+    fac[r] = row == col ? 1.0 : 0.0;
   }
+  double lcol[4], xrow[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(row[j]));
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double sacc = li == i ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) sacc = fma(-readlane_d(row[k], i), m[k], sacc);
-    m[i] = sacc * rinv[i];
-    asm volatile("" : "+v"(m[i]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane < 16) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      T[swz(li, j)] = row[j];
-      Dk[swz(j, li)] = m[j];      // m[j] = inverse[j][li]
+  for (int s = 0; s < 4; ++s) {
+    const double v = acc[s];
+    // d_ab = A[4s+a][4s+b] sits in lane (lk = a, lr = 4s + b)
+    const double d00 = readlane_f64(v, 4 * s), d10 = readlane_f64(v, 16 + 4 * s), d20 = readlane_f64(v, 32 + 4 * s),
+                 d30 = readlane_f64(v, 48 + 4 * s), d11 = readlane_f64(v, 16 + 4 * s + 1), d21 = readlane_f64(v, 32 + 4 * s + 1),
+                 d31 = readlane_f64(v, 48 + 4 * s + 1), d22 = readlane_f64(v, 32 + 4 * s + 2), d32 = readlane_f64(v, 48 + 4 * s + 2),
+                 d33 = readlane_f64(v, 48 + 4 * s + 3);
+    const int pb = pivot_base + 4 * s;
+    double t = d00;
+    if (!(t > 0.0)) { bad = bad == 0 ? pb + 1 : bad; t = 1.0; }
+    const double r0 = rsqrt_refined(t);
+    const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    t = fma(-l10, l10, d11);
+    if (!(t > 0.0)) { bad = bad == 0 ? pb + 2 : bad; t = 1.0; }
+    const double r1 = rsqrt_refined(t);
+    const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+    t = fma(-l21, l21, fma(-l20, l20, d22));
+    if (!(t > 0.0)) { bad = bad == 0 ? pb + 3 : bad; t = 1.0; }
+    const double r2 = rsqrt_refined(t);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+    t = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+    if (!(t > 0.0)) { bad = bad == 0 ? pb + 4 : bad; t = 1.0; }
+    const double r3 = rsqrt_refined(t);
+    // M4 = L4^-1 (lower): m_aa = r_a
+    const double m10 = -l10 * r0 * r1;
+    const double m21 = -l21 * r1 * r2;
+    const double m20 = -fma(l21, m10, l20 * r0) * r2;
+    const double m32 = -l32 * r2 * r3;
+    const double m31 = -fma(l32, m21, l31 * r1) * r3;
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * r0)) * r3;
+    // this lane's entry of the zero-padded 16x4 A operand: M4[lr][lk] for lr < 4
+    double ia = 0.0;
+    if (o.lr == 0) ia = o.lk == 0 ? r0 : 0.0;
+    else if (o.lr == 1) ia = o.lk == 0 ? m10 : (o.lk == 1 ? r1 : 0.0);
+    else if (o.lr == 2) ia = o.lk == 0 ? m20 : (o.lk == 1 ? m21 : (o.lk == 2 ? r2 : 0.0));
+    else if (o.lr == 3) ia = o.lk == 0 ? m30 : (o.lk == 1 ? m31 : (o.lk == 2 ? m32 : r3));
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    const v4d pt = MFMA(ia, v, zero);                          // register 0 at lane (lr, lk): P[lr][lk] = L[lr][4s+lk]
+    const double pm = o.lr >= 4 * s + o.lk ? pt[0] : 0.0;      // rows above the diagonal (and finished rows) are zero
+    lcol[s] = pm;
+    const v4d qt = MFMA(ia, fac[s], zero);                     // register 0: Q[lk][lr] = Linv[4s+lk][lr]
+    xrow[s] = qt[0];
+    if (s < 3) {
+      acc = MFMA(-pm, pm, acc);                                // A -= P P^T
+      fac = MFMA(-pm, qt[0], fac);                             // F -= P Q
     }
+  }
+  // every lane holds 4 entries of the factor (operand layout) and 4 of the inverse (accumulator layout)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    T[o.rc[s]] = lcol[s];
+    Dk[o.cr[s]] = xrow[s];
   }
 }
 
 // ---- blocked Cholesky of the lower-packed buffer A in place; D[k] = inverse of diagonal tile k.  WITH_INV: the
 // inverse of the factor is formed alongside in Xb by block forward substitution (X_ji accumulates -sum_k L_jk X_ki and
-// is finished by inv_jj when row j is reached): no extra serial chain, the products ride in the same three phases.
+// is finished by inv_jj when row j is reached): no extra serial chain, its products ride in the same phases.
+// Two phases per block column with a one-step look-ahead: [panel of column k (every wave)] [wave 0: update of the next
+// diagonal tile and its factorisation | waves 1..7: the rest of the trailing update], so the serial 16x16 factorisation
+// hides the whole trailing update.
+// (not inlined: the factorisation keeps ~110 registers busy; as a function of its own it is compiled without the
+//  caller's register tiles in the way, which are saved and restored once per call instead of spilling all along)
 template <int NT, bool WITH_INV>
-__device__ __forceinline__ void potrf_lds(double* A, double* D, double* Xb, const Lane& o, int wave, int lane, int& bad) {
+__device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const Lane& o, int wave, int lane, int bad) {
+  // (LDS operands arrive as offsets into the workgroup's dynamic LDS block: pointers handed to a real function call
+  //  would be generic pointers and every access a flat one)
+  double* A = lds_base() + a_off;
+  double* D = lds_base() + d_off;
+  double* Xb = lds_base() + x_off;
+  if (wave == 0) diag16(A, D, lane, 0, bad, o);
+  SYNC();
+#pragma unroll 1
   for (int k = 0; k < NT; ++k) {
-    if (wave == 0) diag16(A + lt(k, k) * TS, D + k * TS, lane, 16 * k, bad);
-    SYNC();
     const int below = NT - 1 - k;
+    const double* dk = D + k * TS;
+#pragma unroll 1
     for (int q = wave; q < below + (WITH_INV ? k + 1 : 0); q += NW) {
       if (q < below) {                                    // panel: L_ik = A_ik inv_kk^T
         double* t = A + lt(k + 1 + q, k) * TS;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = mma<false, true>(acc, t, D + k * TS, o);
+        acc = mma<false, true>(acc, t, dk, o);
         st_tile(t, o, acc);
       } else {
         const int i = q - below;
         double* t = Xb + lt(k, i) * TS;
         if (i < k) {                                      // X_ki = inv_kk T_ki
           v4d acc = {0.0, 0.0, 0.0, 0.0};
-          acc = mma<false, false>(acc, D + k * TS, t, o);
+          acc = mma<false, false>(acc, dk, t, o);
           st_tile(t, o, acc);
         } else {
-          st_tile(t, o, ld_tile(D + k * TS, o));          // X_kk = inv_kk
+          st_tile(t, o, ld_tile(dk, o));                  // X_kk = inv_kk
         }
       }
     }
     SYNC();
-    int p = 0;
-    for (int i = k + 1; i < NT; ++i)
-      for (int j = k + 1; j <= i; ++j, ++p)
-        if (p % NW == wave) {                             // A_ij -= L_ik L_jk^T
-          double* t = A + lt(i, j) * TS;
-          v4d acc = ld_tile(t, o);
-          acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1.0);
-          st_tile(t, o, acc);
-        }
-    if (WITH_INV) {
-      for (int j = k + 1; j < NT; ++j)
-        for (int i = 0; i <= k; ++i, ++p)
-          if (p % NW == wave) {                           // T_ji -= L_jk X_ki   (first touched at k == i)
-            double* t = Xb + lt(j, i) * TS;
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            if (k > i) acc = ld_tile(t, o);
-            acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1.0);
+    if (below == 0) break;
+    if (wave == 0) {                                      // look-ahead: next diagonal tile first, then its factorisation
+      double* t = A + lt(k + 1, k + 1) * TS;
+      v4d acc = ld_tile(t, o);
+      acc = mma<false, true>(acc, A + lt(k + 1, k) * TS, A + lt(k + 1, k) * TS, o, -1.0);
+      st_tile(t, o, acc);
+      diag16(t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
+    } else {
+      int p = 0;
+#pragma unroll 1
+      for (int i = k + 1; i < NT; ++i)
+#pragma unroll 1
+        for (int j = k + 1; j <= i; ++j) {
+          if (i == k + 1) continue;                       // (k+1, k+1) is wave 0's
+          if (p++ % (NW - 1) == wave - 1) {               // A_ij -= L_ik L_jk^T
+            double* t = A + lt(i, j) * TS;
+            v4d acc = ld_tile(t, o);
+            acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1.0);
             st_tile(t, o, acc);
           }
+        }
+      if (WITH_INV) {
+#pragma unroll 1
+        for (int j = k + 1; j < NT; ++j)
+#pragma unroll 1
+          for (int i = 0; i <= k; ++i)
+            if (p++ % (NW - 1) == wave - 1) {             // T_ji -= L_jk X_ki   (first touched at k == i)
+              double* t = Xb + lt(j, i) * TS;
+              v4d acc = {0.0, 0.0, 0.0, 0.0};
+              if (k > i) acc = ld_tile(t, o);
+              acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1.0);
+              st_tile(t, o, acc);
+            }
+      }
     }
     SYNC();
   }
+  return bad;
 }
 
 // ---- Lb holds a lower factor L with the inverses D of its diagonal tiles; on return it holds L^-1.  Columns from the
 // last to the first: X_ij = -(sum_{j<k<=i} X_ik L_kj) inv_jj reads column j of L and finished tiles only.  The sum is
 // accumulated TRANSPOSED (L_kj^T X_ik^T), so that the accumulator registers are the A operand of the product with inv_jj.
 template <int NT>
-__device__ __forceinline__ void invert_in_place(double* Lb, const double* D, const Lane& o, int wave) {
+__device__ __forceinline__ void invert_in_place(int l_off, int d_off, const Lane& o, int wave) {
+  double* Lb = lds_base() + l_off;
+  const double* D = lds_base() + d_off;
+#pragma unroll 1
   for (int j = NT - 1; j >= 0; --j) {
     const int i = j + 1 + wave;          // NT - 1 - j <= 5 tiles below the diagonal: one per wave
     v4d x = {0.0, 0.0, 0.0, 0.0};
     const bool has = i < NT;
     if (has) {
       v4d tt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
       for (int k = j + 1; k <= i; ++k) tt = mma<true, true>(tt, Lb + lt(k, j) * TS, Lb + lt(i, k) * TS, o);
       const double* dj = D + j * TS;
 #pragma unroll
@@ -247,6 +373,7 @@ __device__ __forceinline__ void invert_in_place(double* Lb, const double* D, con
 template <int NT>
 __device__ __forceinline__ double mv_lower(const double* Lb, const double* x, int i, const Lane& o) {     // (L x)[16 i + lr]
   double s = 0.0;
+#pragma unroll 1
   for (int k = 0; k <= i; ++k) {
     const double* t = Lb + lt(i, k) * TS;
 #pragma unroll
@@ -259,6 +386,7 @@ __device__ __forceinline__ double mv_lower(const double* Lb, const double* x, in
 template <int NT>
 __device__ __forceinline__ double mv_lower_t(const double* Lb, const double* x, int j, const Lane& o) {   // (L^T x)[16 j + lr]
   double s = 0.0;
+#pragma unroll 1
   for (int k = j; k < NT; ++k) {
     const double* t = Lb + lt(k, j) * TS;
 #pragma unroll
@@ -271,6 +399,7 @@ __device__ __forceinline__ double mv_lower_t(const double* Lb, const double* x, 
 template <int NT>
 __device__ __forceinline__ double mv_sym(const double* Sb, const double* x, int i, const Lane& o) {       // (S x)[16 i + lr]
   double s = 0.0;
+#pragma unroll 1
   for (int k = 0; k < NT; ++k) {
     const double* t = Sb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
 #pragma unroll
@@ -281,20 +410,32 @@ __device__ __forceinline__ double mv_sym(const double* Sb, const double* x, int 
   return s;
 }
 
-// squared distances of tile (i, j): X~ X~^T on the matrix cores (operands straight from the member's X, scaled on the
-// fly), r2 = (-2 dot + |x_i|^2) + |x_j|^2 as GPflow / the oracle form it
-__device__ __forceinline__ v4d r2_tile(const double* X, int N, int R, double ls, const double* ssq, int i, int j, const Lane& o) {
+// squared distances of tile (i, j): X X^T on the matrix cores with operands straight from the member's X,
+// r2 = ((-2 dot + |x_i|^2) + |x_j|^2) / ls^2 - GPflow / the oracle scale X first, this scales the distance (the
+// rounding differs in the last bits only; ssq = |x_i|^2 is then a per-member constant)
+__device__ __forceinline__ v4d r2_tile(const double* X, int N, int R, double inv_ls2, const double* ssq, int i, int j, const Lane& o) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
   const int ra = 16 * i + o.lr, rb = 16 * j + o.lr;
-  for (int k0 = 0; k0 < R; k0 += 4) {
-    const int c = k0 + o.lk;
-    const double a = (ra < N && c < R) ? X[(long)ra * R + c] / ls : 0.0;
-    const double b = (rb < N && c < R) ? X[(long)rb * R + c] / ls : 0.0;
-    acc = MFMA(a, b, acc);
+  const double* xa = X + (long)(ra < N ? ra : 0) * R;
+  const double* xb = X + (long)(rb < N ? rb : 0) * R;
+  if (R <= 8) {                 // the common case: both operand pairs requested before the first MFMA
+    const int c0 = o.lk, c1 = 4 + o.lk;
+    const double a0 = (ra < N && c0 < R) ? xa[c0] : 0.0, b0 = (rb < N && c0 < R) ? xb[c0] : 0.0;
+    const double a1 = (ra < N && c1 < R) ? xa[c1] : 0.0, b1 = (rb < N && c1 < R) ? xb[c1] : 0.0;
+    acc = MFMA(a0, b0, acc);
+    if (R > 4) acc = MFMA(a1, b1, acc);
+  } else {
+#pragma unroll 2
+    for (int k0 = 0; k0 < R; k0 += 4) {
+      const int c = k0 + o.lk;
+      const double a = (ra < N && c < R) ? xa[c] : 0.0;
+      const double b = (rb < N && c < R) ? xb[c] : 0.0;
+      acc = MFMA(a, b, acc);
+    }
   }
   const double sj = ssq[16 * j + o.lr];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = (-2.0 * acc[r] + ssq[16 * i + o.lk + 4 * r]) + sj;
+  for (int r = 0; r < 4; ++r) acc[r] = ((-2.0 * acc[r] + ssq[16 * i + o.lk + 4 * r]) + sj) * inv_ls2;
   return acc;
 }
 
@@ -314,11 +455,11 @@ template <int NT>
 __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
   typedef Layout<NT> Y;
   constexpr int NTT = Y::NTT, NP = Y::NP, TPW = Y::TPW;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* lds = lds_base();
   double* Lb = lds + Y::LB;
   double* Cb = lds + Y::CB;
   double* Wb = lds + Y::WB;
-  double* DLi = lds + Y::DL;
+  double* DLi = lds + Y::DL;            // inverted diagonal tiles of L; in the prediction also staging (odd tile rows)
   double* DCi = lds + Y::DC;            // inverted diagonal tiles of C; in the prediction: staging of one tile row of A^T S
   double* yv = lds + Y::VEC;            // y (0 in the padding)
   double* dv = yv + NP;                 // 1 / nu (1 in the padding)
@@ -326,11 +467,11 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
   double* yd = rs + NP;                 // y / nu
   double* th = yd + NP;                 // theta1
   double* mv = th + NP;                 // m
-  double* av = mv + NP;                 // a = L m - y (later: L m of the prediction)
+  double* av = mv + NP;                 // a = L m - y (later: the posterior mean)
   double* wv = av + NP;                 // a / nu
-  double* uv = wv + NP;                 // u = L^T D a (later: Linv^T m)
-  double* ssq = uv + NP;                // |x_i / ls|^2
-  double* misc = lds + Y::MISC;         // [0..7] optimiser state, [8] variance, [9] lengthscale, [16..31] reduction scratch
+  double* uv = wv + NP;                 // u = L^T D a
+  double* ssq = uv + NP;                // |x_i|^2
+  double* misc = lds + Y::MISC;         // [0..7] optimiser state, [8] variance, [9] lengthscale, [10] 1/ls^2, [16..31] reductions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Lane o;
   o.lr = lane & 15; o.lk = lane >> 4;
@@ -339,6 +480,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
   const int N = g.N, R = g.R;
   const double J = g.jitter;
 
+#pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
     const double* X = g.X + (long)b * N * R;
     int bad = 0;
@@ -348,6 +490,10 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       const double y = t < N ? g.y[(long)b * N + t] : 0.0;
       yv[t] = y; dv[t] = 1.0 / nu; rs[t] = 1.0 / sqrt(nu); yd[t] = y / nu;
       th[t] = 0.0; mv[t] = 0.0;
+      double sq = 0.0;                  // fma chain in k order = the diagonal of the MFMA product: r2_ii is exactly 0
+      if (t < N)
+        for (int d = 0; d < R; ++d) { const double v = X[(long)t * R + d]; sq = fma(v, v, sq); }
+      ssq[t] = sq;
     }
     if (tid < 8) misc[tid] = tid < 2 ? 0.5413248546129181 /* softplus^-1(1) = log(e - 1) */ : 0.0;
     v4d lam[TPW], gt[TPW];
@@ -363,31 +509,28 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     }
     SYNC();
 
-    // hyper-parameters of the coming kernel matrix -> misc[8], misc[9]; |x~|^2
+    // hyper-parameters of the coming kernel matrix -> misc[8..10]
     auto refresh_hypers = [&]() {
-      if (tid == 0) { misc[8] = softplus_d(misc[0]); misc[9] = softplus_d(misc[1]); }
-      SYNC();
-      const double ls = misc[9];
-      for (int t = tid; t < NP; t += NTH) {
-        double s = 0.0;
-        if (t < N)
-          for (int d = 0; d < R; ++d) { const double v = X[(long)t * R + d] / ls; s += v * v; }
-        ssq[t] = s;
+      if (tid == 0) {
+        const double ls = softplus_d(misc[1]);
+        misc[8] = softplus_d(misc[0]); misc[9] = ls; misc[10] = 1.0 / (ls * ls);
       }
       SYNC();
     };
     // Lb <- tril(K0) + J I (identity in the padding)
     auto kmat = [&]() {
-      const double var = misc[8], ls = misc[9];
+      const double var = misc[8], inv_ls2 = misc[10];
+#pragma unroll 1
       for (int p = wave; p < NTT; p += NW) {
         int i, j;
         unpack_lower(p, i, j);
-        v4d r2 = r2_tile(X, N, R, ls, ssq, i, j, o);
+        v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
-          double K, dK;
-          kern_eval(g.kernel, var, ls, r2[r], K, dK);
+          double k1, k2;
+          kern_unit<false>(g.kernel, r2[r], k1, k2);
+          double K = var * k1;
           if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
           else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
           r2[r] = K;
@@ -397,10 +540,60 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       SYNC();
     };
 
+    // -ELBO (the training loss the reference samples after iterations 0, 25, 50, ..., models.py:211-215; GPflow VGP.elbo with
+    // the heteroskedastic Gaussian expectations of models.py:142-149) at the hypers whose factor L is in Lb, with the
+    // (m, S) of the last natural-gradient step (S in Cb, log det C in misc[11]):
+    //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + (|m|^2 - N + 2 log det C + tr S) / 2
+    // (L S L^T)_tt = sum_j (L S)_tj L_tj: wave i forms the tiles (i, j <= i) of L S and folds them against L.
+    auto neg_elbo = [&](int slot) {
+      if (wave < NT) {
+        const int i = wave;
+        const double s = mv_lower<NT>(Lb, mv, i, o);
+        if (o.lk == 0) av[16 * i + o.lr] = s - yv[16 * i + o.lr];
+        double fr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int j = 0; j <= i; ++j) {
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          acc = acc_run(acc, 0, i + 1, [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; },
+                        [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
+          const v4d lt_ = ld_tile(Lb + lt(i, j) * TS, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fr[r] = fma(acc[r], lt_[r], fr[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = fr[r];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          if (o.lr == 0) wv[16 * i + o.lk + 4 * r] = v;                    // f_t
+        }
+      }
+      SYNC();
+      double part = 0.0;
+      for (int t = tid; t < N; t += NTH) {
+        const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
+        const double stt = Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)];
+        part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
+      }
+      part = wave_sum(part);
+      if (lane == 0) misc[16 + wave] = part;
+      SYNC();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += misc[16 + w];
+        g.loss[(long)b * g.loss_stride + slot] = tot - 0.5 * N + misc[11];
+      }
+      SYNC();
+    };
+
+#pragma unroll 1
     for (int it = 0; it < g.n_iters; ++it) {
+      STAMP(0);
       refresh_hypers();
       kmat();                                                              // K0 + J I at the current hypers  (models.py:209)
-      potrf_lds<NT, false>(Lb, DLi, nullptr, o, wave, lane, bad);          // L
+      STAMP(1);
+      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);     // L
+      if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
+      STAMP(2);
       // ---- natural-gradient step: G = L^T D L, Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
@@ -409,15 +602,9 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           int i, j;
           unpack_lower(p, i, j);
           v4d acc = {0.0, 0.0, 0.0, 0.0};
-          for (int k = i; k < NT; ++k) {
-            const double* ta = Lb + lt(k, i) * TS;
-            const double* tb = Lb + lt(k, j) * TS;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const double sc = rs[16 * k + 4 * q + o.lk];
-              acc = MFMA(ta[o.cr[q]] * sc, tb[o.cr[q]] * sc, acc);
-            }
-          }
+          acc = acc_run(acc, i, NT,
+                        [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]] * rs[16 * k + 4 * q + o.lk]; },
+                        [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]] * rs[16 * k + 4 * q + o.lk]; });
           gt[s] = acc;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -430,7 +617,21 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (o.lk == 0) th[16 * wave + o.lr] = (1.0 - g.gamma) * th[16 * wave + o.lr] + g.gamma * s;
       }
       SYNC();
-      potrf_lds<NT, true>(Cb, DCi, Wb, o, wave, lane, bad);                // C = chol(Lam) in Cb, C^-1 in Wb
+      STAMP(3);
+      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::WB, o, wave, lane, bad);  // C = chol(Lam) in Cb, C^-1 in Wb
+      STAMP(4);
+      if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
+        double s = 0.0;
+        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
+        s = wave_sum(s);
+        if (lane == 0) misc[32 + wave] = s;
+        SYNC();
+        if (tid == 0) {
+          double tot = 0.0;
+          for (int w = 0; w < NW; ++w) tot += misc[32 + w];
+          misc[11] = tot;
+        }
+      }
       // ---- S = C^-T C^-1 (registers), then over C in Cb
       v4d st[TPW];
 #pragma unroll
@@ -440,7 +641,8 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
-          for (int k = i; k < NT; ++k) st[s] = mma<true, false>(st[s], Wb + lt(k, i) * TS, Wb + lt(k, j) * TS, o);
+          st[s] = acc_run(st[s], i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
         }
       }
       SYNC();
@@ -450,6 +652,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) { st_tile(Cb + p * TS, o, st[s]); st_tile(Wb + p * TS, o, gt[s]); }     // S -> Cb, G -> Wb
       }
       SYNC();
+      STAMP(5);
       // ---- m = S theta1 ; a = L m - y ; u = L^T D a
       if (wave < NT) {
         const double s = mv_sym<NT>(Cb, th, wave, o);
@@ -470,6 +673,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (o.lk == 0) uv[16 * wave + o.lr] = s;
       }
       SYNC();
+      STAMP(6);
       // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal   (G in Wb, S in Cb, both symmetric from lower tiles)
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
@@ -478,12 +682,9 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           int i, j;
           unpack_lower(p, i, j);
           v4d acc = {0.0, 0.0, 0.0, 0.0};
-          for (int k = 0; k < NT; ++k) {
-            const double* ta = Wb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
-            const double* tb = Cb + (k >= j ? lt(k, j) : lt(j, k)) * TS;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = MFMA(ta[k <= i ? o.rc[q] : o.cr[q]], tb[k >= j ? o.cr[q] : o.rc[q]], acc);
-          }
+          acc = acc_run(acc, 0, NT,
+                        [&](int k, int q) { return k <= i ? Wb[lt(i, k) * TS + o.rc[q]] : Wb[lt(k, i) * TS + o.cr[q]]; },
+                        [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rl = o.lk + 4 * r;
@@ -500,7 +701,9 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         const int p = wave + s * NW;
         if (p < NTT) st_tile(Wb + p * TS, o, st[s]);                        // Phi -> Wb
       }
-      invert_in_place<NT>(Lb, DLi, o, wave);                               // Lb = L^-1   (its first barrier publishes Phi)
+      STAMP(7);
+      invert_in_place<NT>(Y::LB, Y::DL, o, wave);                          // Lb = L^-1   (its first barrier publishes Phi)
+      STAMP(8);
       // ---- W = Phi L^-1 (lower) -> Wb
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
@@ -509,7 +712,8 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
-          for (int k = j; k <= i; ++k) st[s] = mma<false, false>(st[s], Wb + lt(i, k) * TS, Lb + lt(k, j) * TS, o);
+          st[s] = acc_run(st[s], j, i + 1, [&](int k, int q) { return Wb[lt(i, k) * TS + o.rc[q]]; },
+                          [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
         }
       }
       SYNC();
@@ -519,21 +723,30 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) st_tile(Wb + p * TS, o, st[s]);
       }
       SYNC();
-      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210)
+      STAMP(9);
+      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric, so
+      // the tiles (i, j) and (j, i) of Kbar meet the same kernel values: Kbar_ij and Kbar_ji^T = sum_k W_ki^T Linv_kj
+      // are accumulated together and the kernel function is evaluated once per unordered pair.
       {
-        const double var = misc[8], ls = misc[9];
+        const double var = misc[8], ls = misc[9], inv_ls2 = misc[10];
         double gv = 0.0, gl = 0.0;
-        for (int q = wave; q < NT * NT; q += NW) {
-          const int i = q / NT, j = q - i * NT;
+#pragma unroll 1
+        for (int p = wave; p < NTT; p += NW) {
+          int i, j;
+          unpack_lower(p, i, j);
           v4d acc = {0.0, 0.0, 0.0, 0.0};
-          for (int k = (i > j ? i : j); k < NT; ++k) acc = mma<true, false>(acc, Lb + lt(k, i) * TS, Wb + lt(k, j) * TS, o);
-          const v4d r2 = r2_tile(X, N, R, ls, ssq, i, j, o);
+          acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
+                        [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+          if (i != j)
+            acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
+          const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
-            double K, dK;
-            kern_eval(g.kernel, var, ls, r2[r], K, dK);
-            if (row < N && col < N) { gv = fma(acc[r], K, gv); gl = fma(acc[r], dK, gl); }
+            double k1, k2;
+            kern_unit<true>(g.kernel, r2[r], k1, k2);
+            if (row < N && col < N) { gv = fma(acc[r], k1, gv); gl = fma(acc[r], k2, gl); }
           }
         }
         gv = wave_sum(gv);
@@ -545,8 +758,8 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           for (int w = 0; w < NW; ++w) { sv += misc[16 + w]; sl += misc[24 + w]; }
           double* u = misc;
           double gg[2];
-          gg[0] = (sv / var) * (1.0 - exp(-var));     // softplus'(u) = 1 - exp(-softplus(u))
-          gg[1] = sl * (1.0 - exp(-ls));
+          gg[0] = sv * (1.0 - exp(-var));                               // d/d variance = <Kbar, K0> / variance = <Kbar, k1>
+          gg[1] = sl * (kern_cl(g.kernel) * var / ls) * (1.0 - exp(-ls));  // softplus'(u) = 1 - exp(-softplus(u))
           const double t = u[6] + 1.0;
           u[6] = t;
           const double lr_t = g.lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t));
@@ -558,63 +771,62 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         }
         SYNC();
       }
+      STAMP(10);
     }
 
     // ---- prediction at the final hypers with the (m, S) of the last step    (models.py:217-220)
+    STAMP(11);
     refresh_hypers();
     kmat();
-    potrf_lds<NT, false>(Lb, DLi, nullptr, o, wave, lane, bad);
+    bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);
+    if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
+    STAMP(12);
     for (int p = wave; p < NTT; p += NW) st_tile(Wb + p * TS, o, ld_tile(Lb + p * TS, o));
     SYNC();
-    invert_in_place<NT>(Wb, DLi, o, wave);                                  // Wb = L^-1, Lb = L, Cb = S
+    invert_in_place<NT>(Y::WB, Y::DL, o, wave);                             // Wb = L^-1, Lb = L, Cb = S
+    STAMP(13);
     // mu = A^T m with A^T = K0 L^-T = L - J L^-T
     if (wave < NT) {
       const double s1 = mv_lower<NT>(Lb, mv, wave, o);
       const double s2 = mv_lower_t<NT>(Wb, mv, wave, o);
       if (o.lk == 0) av[16 * wave + o.lr] = s1 - J * s2;                    // av = mu (padded part 0)
     }
+    // (av is read after the barriers of the covariance loop)
+    STAMP(14);
+    // cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T S) A, one tile row at a time.  E_i* = A^T_i* S is staged in LDS,
+    // alternately in DCi and DLi (both dead here), so that the tile row i of cov and the staging of row i+1 share a
+    // phase: E tile l of the next row is dealt to wave NW-1-l, cov tile (i, j) to wave j.
+    auto at_a = [&](int i, int k, int q) -> double {       // A-operand element of A^T(i, k): [lr][4q + lk]
+      if (k < i) return Lb[lt(i, k) * TS + o.rc[q]];
+      if (k > i) return -J * Wb[lt(k, i) * TS + o.cr[q]];
+      return Lb[lt(i, i) * TS + o.rc[q]] - J * Wb[lt(i, i) * TS + o.cr[q]];
+    };
+    auto stage_row = [&](int i, double* Eb) {
+      const int l = NW - 1 - wave;
+      if (l < NT) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = acc_run(acc, 0, NT, [&](int k, int q) { return at_a(i, k, q); },
+                      [&](int k, int q) { return k >= l ? Cb[lt(k, l) * TS + o.cr[q]] : Cb[lt(l, k) * TS + o.rc[q]]; });
+        st_tile(Eb + l * TS, o, acc);
+      }
+    };
+    stage_row(0, DCi);
     SYNC();
-    if (g.mu)
-      for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = av[t];
-    // cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T S) A, one tile row at a time: E_i* = A^T_i* S staged in LDS (DCi)
     v4d covt[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (wave < NT) {
-        const int l = wave;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k = 0; k < NT; ++k) {
-          const double* tb = Cb + (k >= l ? lt(k, l) : lt(l, k)) * TS;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            double a;
-            if (k < i) a = Lb[lt(i, k) * TS + o.rc[q]];
-            else if (k > i) a = -J * Wb[lt(k, i) * TS + o.cr[q]];
-            else a = Lb[lt(i, i) * TS + o.rc[q]] - J * Wb[lt(i, i) * TS + o.cr[q]];
-            acc = MFMA(a, tb[k >= l ? o.cr[q] : o.rc[q]], acc);
-          }
-        }
-        st_tile(DCi + l * TS, o, acc);
-      }
-      SYNC();
+      double* Eb = (i & 1) ? DLi : DCi;
       covt[i] = v4d{0.0, 0.0, 0.0, 0.0};
       if (wave <= i) {
         const int j = wave;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k = i; k < NT; ++k) acc = mma<true, false>(acc, Wb + lt(k, i) * TS, Wb + lt(k, j) * TS, o);
+        acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                      [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= -J * J;
-        for (int l = 0; l < NT; ++l) {
-          const double* ta = DCi + l * TS;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            double bb;      // B[kq][col] = A^T(j, l)[col][kq]
-            if (l < j) bb = Lb[lt(j, l) * TS + o.rc[q]];
-            else if (l > j) bb = -J * Wb[lt(l, j) * TS + o.cr[q]];
-            else bb = Lb[lt(j, j) * TS + o.rc[q]] - J * Wb[lt(j, j) * TS + o.cr[q]];
-            acc = MFMA(ta[o.rc[q]], bb, acc);
-          }
-        }
+        // B[kq][col] = A^T(j, l)[col][kq]: the same element function with the roles of the tile indices as for A
+        acc = acc_run(acc, 0, NT, [&](int l, int q) { return Eb[l * TS + o.rc[q]]; },
+                      [&](int l, int q) { return at_a(j, l, q); });
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
@@ -631,8 +843,11 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         }
         covt[i] = acc;
       }
+      if (i + 1 < NT) stage_row(i + 1, (i & 1) ? DCi : DLi);
       SYNC();
     }
+    if (g.mu)
+      for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = av[t];
     // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -653,15 +868,18 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       }
     }
     SYNC();
+    STAMP(15);
     if (g.cov) {      // exact symmetry inside the diagonal tiles: upper element = lower element
       for (int e = tid; e < NT * 256; e += NTH) {
         const int i = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
         const int row = 16 * i + rr, col = 16 * i + cc;
         if (cc > rr && row < N && col < N) g.cov[((long)b * N + row) * N + col] = Lb[lt(i, i) * TS + swz(cc, rr)];
       }
+      SYNC();       // (the factorisation below overwrites the diagonal tiles)
     }
     if (g.chol || g.logdet || g.basis) {
-      potrf_lds<NT, false>(Lb, DLi, nullptr, o, wave, lane, bad);           // Distribution.__post_init__ (data.py:38-39)
+      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);   // Distribution.__post_init__ (data.py:38-39)
+      STAMP(16);
       if (g.chol) {
         for (int e = tid; e < NT * NT * 256; e += NTH) {
           const int tt = e >> 8, i = tt / NT, j = tt - i * NT, rr = (e >> 4) & 15, cc = e & 15;
@@ -692,6 +910,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       if (g.hyp) { g.hyp[(long)b * 2] = misc[8]; g.hyp[(long)b * 2 + 1] = misc[9]; }
     }
     if (wave == 0 && lane == 0) g.info[b] = bad;
+    STAMP(17);
     SYNC();                                                                 // LDS is re-initialised for the next member
   }
 }

@@ -101,6 +101,17 @@ int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         double* mu, double* cov, double* cov_chol, double* logdet,
                         double* hyp, double* loss_trace, int* info, double* ll_basis);
 
+/* Small members (N <= 94, e.g. the reference's annual series N = 86, experiments/full_experiment_script.py:57,70, and
+ * BASELINE.json config 5's per-gridpoint fits) are fitted by bayens_gp_fit_batch in ONE fused kernel, one workgroup per
+ * member with every matrix resident in LDS (csrc/small.hip; BAYENS_NO_SMALL=1 forces the general path).  This entry is
+ * the same fit with the REDUCED export the weighting path needs and nothing else: mu [B][N], var [B][N] = diag(cov)
+ * (_dist.variance(), ensemble_scheme.py:64-65), logdet [B], hyp [B][2], ll_basis [B][2][N] (weights.py:98-100) - 2.8 KB
+ * per member instead of the 59.9 KB of a full covariance.  N <= 94 only. */
+int bayens_gp_fit_batch_reduced(bayens_ctx* ctx, int loc, int B, int N, int R,
+                                const double* X, const double* y_mean, const double* y_var,
+                                int kernel, int n_iters, double gamma, double lr, double jitter,
+                                double* mu, double* var, double* logdet, double* hyp, int* info, double* ll_basis);
+
 /* The same fit in fp32 (BASELINE.json config 3; SURVEY 8(b) "dtype enum"): float arrays in and out, fp32 storage
  * and fp32 MFMA products throughout.  Kept in fp64: the hyper-parameters and Adam state (hyp), the squared
  * distances inside the kernel matrix, the 64x64 diagonal-block factorisations, and every reduction (logdet,
@@ -239,6 +250,10 @@ int bayens_bench_mfma_peak(bayens_ctx* ctx, int waves_per_simd, double* tflops);
  * two workgroups per CU).  mode bits add the rest of a K step one by one: 1 = a workgroup barrier per 64 MFMAs,
  * 2 = the eight transposing LDS stores of the next tile, 4 = eight 16-byte global loads feeding those stores. */
 int bayens_bench_mfma_lds(bayens_ctx* ctx, int mode, double* tflops);
+/* Diagnostic: phase stamps (shader cycle counter) of the fused small-member fit kernel (csrc/small.hip): enable = 1
+ * makes every later small fit record the phase boundaries of workgroup 0's last member / iteration; stamps32 (nullable)
+ * receives the 32 recorded values; enable = 0 switches the recording off again. */
+int bayens_small_stamps(bayens_ctx* ctx, int enable, unsigned long long* stamps32);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */

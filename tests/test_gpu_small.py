@@ -1,0 +1,104 @@
+"""The fused small-member fit kernel (csrc/small.hip; BASELINE.json config 5: per-gridpoint fits at the reference's
+annual horizon N = 86, experiments/full_experiment_script.py:57,70) against the oracle.  Every fit with N <= 94 that goes
+through bayens_gp_fit_batch takes this kernel, so tests/test_gpu_fit_parity.py covers it at the small shapes too; here:
+the batch scale of config 5, the reduced export, the boundaries of the tile grid and the general path as cross-check."""
+import numpy as np
+import pytest
+from threadpoolctl import threadpool_limits
+
+from bayesian_ensembling_amd import _lib as L
+from conftest import member_inputs, relerr
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(B, N, R, seed):
+    """B independent members (one per grid point in config 5): quadratic trend + integrated noise, seeded."""
+    rng = np.random.default_rng(seed)
+    tau = np.linspace(0, 1, N)
+    amp = 0.8 + 0.4 * rng.random((B, 1, 1))
+    data = 1.5 * amp * tau ** 2 + 0.036 * rng.standard_normal((B, R, N)).cumsum(axis=2)
+    return member_inputs(data)
+
+
+def test_config5_batch_scale(ctx):
+    """B = 8192 members of N = 86 (1/54 of config 5's 442 368 point-fits): every member factorises (info == 0), a
+    sample of members matches the oracle to 1e-10, the outputs are exactly symmetric / lower triangular."""
+    B, N, R, T = 8192, 86, 8, 2
+    X, y, nu = _batch(B, N, R, seed=5)
+    dX, dy, dnu = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu)
+    dmu, dcov, dchol = ctx.empty((B, N)), ctx.empty((B, N, N)), ctx.empty((B, N, N))
+    dld, dhyp, dbasis = ctx.empty((B,)), ctx.empty((B, 2)), ctx.empty((B, 2, N))
+    bufs = [dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis]
+    try:
+        info = ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
+        assert not info.any()
+        mu, cov, chol = dmu.download(), dcov.download(), dchol.download()
+        ld, hyp, basis = dld.download(), dhyp.download(), dbasis.download()
+    finally:
+        for b in bufs:
+            b.free()
+    assert np.isfinite(cov).all() and np.isfinite(mu).all()
+    assert np.array_equal(cov, np.swapaxes(cov, 1, 2))
+    assert not np.triu(chol, 1).any()
+    assert relerr(np.einsum("bij,bkj->bik", chol[::512], chol[::512]), cov[::512]) < 1e-12      # chol chol^T == cov
+    with threadpool_limits(1):
+        for m in list(range(0, B, 683)) + [B - 1]:        # 13 members spread over the grid's workgroups
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T)
+            Lc, ldo = go.mvn_factor(co)
+            assert relerr(mu[m], mo) < 1e-10 and relerr(cov[m], co) < 1e-10 and relerr(chol[m], Lc) < 1e-10, m
+            assert relerr(hyp[m], ho) < 1e-10 and abs(ld[m] - ldo) < 1e-9 * abs(ldo), m
+    # reduced export (mu, diag, logdet, hyp, basis) of the same members: bit-identical to the full export's
+    red = ctx.gp_fit_batch_reduced(X[:300], y[:300], nu[:300], T)
+    assert np.array_equal(red["mu"], mu[:300]) and np.array_equal(red["var"], np.einsum("bii->bi", cov[:300]))
+    assert np.array_equal(red["logdet"], ld[:300]) and np.array_equal(red["hyp"], hyp[:300])
+    assert np.array_equal(red["basis"], basis[:300])
+
+
+@pytest.mark.parametrize("N,R,T,kernel", [(94, 8, 2, 0), (93, 3, 1, 0), (62, 4, 2, 0), (63, 4, 2, 0), (30, 5, 3, 0), (31, 5, 1, 1),
+                                          (16, 2, 2, 0), (14, 9, 2, 2), (86, 25, 2, 0), (86, 3, 40, 0)])
+def test_tile_grid_boundaries_against_the_oracle(ctx, N, R, T, kernel):
+    """N at the edges of the 2 / 4 / 6-tile grids (30, 62 and 94 leave exactly the two padded rows the bordered Cholesky
+    needs), R not a multiple of 4 and above 8, 40 iterations - each against the oracle."""
+    data, _ = go.synthetic_ensemble(3, N, R=R, seed=100 + N + R)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T, kernel=kernel)
+    assert not out["info"].any()
+    tight = 1e-10 if kernel == 0 else 1e-6
+    with threadpool_limits(1):
+        for m in range(3):
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel)
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m], mo) < tight and relerr(out["cov"][m], co) < tight and relerr(out["chol"][m], Lc) < tight
+            assert relerr(out["hyp"][m], ho) < tight and abs(out["logdet"][m] - ld) < 1e-9 * max(1.0, abs(ld))
+
+
+def test_small_and_general_paths_agree(ctx):
+    """The same member through the fused kernel (N = 94) and, with one more time point appended, through the general
+    path (N = 95): two different programs for the same arithmetic - both must sit on the oracle."""
+    data, _ = go.synthetic_ensemble(2, 95, R=6, seed=77)
+    X, y, nu = member_inputs(data)
+    big = ctx.gp_fit_batch(X, y, nu, 2)
+    small = ctx.gp_fit_batch(X[:, :94], y[:, :94], nu[:, :94], 2)
+    for m in range(2):
+        mo, co, _ = go.gp_fit(X[m], y[m], nu[m], 2)
+        ms, cs, _ = go.gp_fit(X[m, :94], y[m, :94], nu[m, :94], 2)
+        assert relerr(big["cov"][m], co) < 1e-10 and relerr(small["cov"][m], cs) < 1e-10
+        assert relerr(big["mu"][m], mo) < 1e-10 and relerr(small["mu"][m], ms) < 1e-10
+
+
+def test_failed_pivot_is_reported_per_member(ctx):
+    data, _ = go.synthetic_ensemble(3, 40, R=3, seed=1)
+    X, y, nu = member_inputs(data)
+    nu[1, :] = 0.0                    # zero variance across realisations: 1 / nu is infinite (the reference fails too)
+    with pytest.raises(L.BayensError) as e:
+        ctx.gp_fit_batch(X, y, nu, 1)
+    assert e.value.code == -2 and e.value.info[1] > 0 and e.value.info[0] == 0 and e.value.info[2] == 0
+
+
+def test_reduced_export_rejects_large_members(ctx):
+    X = np.zeros((1, 95, 2))
+    with pytest.raises(L.BayensError) as e:
+        ctx.gp_fit_batch_reduced(X, np.zeros((1, 95)), np.ones((1, 95)), 1)
+    assert e.value.code == -1
