@@ -60,6 +60,7 @@ def load():
     lib.bayens_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
     lib.bayens_memcpy_d2h.argtypes = [_vp, _vp, _vp, C.c_size_t]
     lib.bayens_sync.argtypes = [_vp]
+    lib.bayens_memcpy_d2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
     lib.bayens_timer_start.argtypes = [_vp]
     lib.bayens_timer_stop.argtypes = [_vp, _dp]
     lib.bayens_profile_enable.argtypes = [_vp, C.c_int]
@@ -81,6 +82,7 @@ def load():
     lib.bayens_extract_diag_f32.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_widen_f32.argtypes = [_vp, C.c_int, C.c_size_t, _vp, _vp]
     lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_mvn_log_prob.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_weights_normalise.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]
     lib.bayens_w2_temporal.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
@@ -122,7 +124,7 @@ def _f64(a):
 def _ptr(a):
     if a is None:
         return None
-    if isinstance(a, DeviceBuffer):
+    if isinstance(a, (DeviceBuffer, DeviceView)):
         return a.ptr
     if isinstance(a, int):
         return a
@@ -156,10 +158,33 @@ class DeviceBuffer:
     def offset(self, nbytes):
         return self.ptr + int(nbytes)
 
+    def download_rows(self, first, count=1):
+        """Rows [first, first + count) of the leading axis as a host array of shape (count,) + shape[1:]."""
+        sub = tuple(self.shape[1:])
+        out = np.empty((count,) + sub, dtype=self.dtype)
+        row_bytes = int(np.prod(sub, dtype=np.int64)) * self.dtype.itemsize if sub else self.dtype.itemsize
+        self.ctx._check(self.ctx.lib.bayens_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + first * row_bytes, out.nbytes))
+        return out
+
+    def copy_rows_from(self, dst_first, src, src_first, count=1):
+        """Device-to-device copy of `count` leading-axis rows of `src` into this buffer (queued, no host wait)."""
+        sub = tuple(self.shape[1:])
+        row_bytes = int(np.prod(sub, dtype=np.int64)) * self.dtype.itemsize if sub else self.dtype.itemsize
+        self.ctx._check(self.ctx.lib.bayens_memcpy_d2d(self.ctx.h, self.ptr + dst_first * row_bytes,
+                                                       src.ptr + src_first * row_bytes, count * row_bytes))
+
     def free(self):
         if self.ptr:
             self.ctx.lib.bayens_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class DeviceView:
+    """A pointer into somebody else's DeviceBuffer (no ownership): what a device-resident argument of a Context call
+    needs - `.ptr` and `.shape`."""
+
+    def __init__(self, ptr, shape):
+        self.ptr, self.shape = int(ptr), tuple(shape)
 
 
 class Context:
@@ -273,14 +298,18 @@ class Context:
                 "loss": loss}
 
     def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
-                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, f32=False):
-        """Device-resident buffers; f32=True: X, y_mean, y_var, mu, cov, chol, basis are float32 buffers."""
+                         kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, f32=False, loss=None):
+        """Device-resident buffers; f32=True: X, y_mean, y_var, mu, cov, chol, basis are float32 buffers.
+        loss: device buffer [B][ceil(n_iters / 25)] of float64 for the training-loss samples, or None."""
         info = np.zeros(B, dtype=np.int32)
         fn = self.lib.bayens_gp_fit_batch_f32 if f32 else self.lib.bayens_gp_fit_batch
         rc = fn(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                           int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
-                                          _ptr(logdet), _ptr(hyp), None, _ptr(info), _ptr(basis))
-        self._check(rc)
+                                          _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
         return info
 
     def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
@@ -356,6 +385,31 @@ class Context:
         self._check(self.lib.bayens_loglik_rows(self.h, DEVICE, B, N, R_obs, _ptr(mu), _ptr(chol), _ptr(logdet),
                                                 _ptr(obs), _ptr(ll_mean)))
 
+    def mvn_log_prob(self, mu, chol, logdet, x, loc=HOST):
+        """log N(x_r; mu_b, L_b L_b^T): mu [B,N], chol [B,N,N], logdet [B]; x [n_x,N] (shared) or [B,n_x,N] -> [B,n_x].
+        loc=DEVICE: mu / chol / logdet are device buffers (x and the result stay host arrays)."""
+        x = _f64(x)
+        shared = x.ndim == 2
+        if loc == HOST:
+            mu, chol, logdet = _f64(mu), _f64(chol), _f64(logdet)
+            B, N = mu.shape
+        else:
+            B, N = mu.shape[0], mu.shape[-1]
+        n_x = x.shape[-2]
+        out = np.empty((B, n_x))
+        if loc == HOST:
+            self._check(self.lib.bayens_mvn_log_prob(self.h, HOST, B, N, n_x, 1 if shared else 0, _ptr(mu), _ptr(chol),
+                                                     _ptr(logdet), _ptr(x), _ptr(out)))
+            return out
+        dx_, dout = self.to_device(x), self.empty((B, n_x))
+        try:
+            self._check(self.lib.bayens_mvn_log_prob(self.h, DEVICE, B, N, n_x, 1 if shared else 0, _ptr(mu), _ptr(chol),
+                                                     _ptr(logdet), _ptr(dx_), _ptr(dout)))
+            return dout.download()
+        finally:
+            dx_.free()
+            dout.free()
+
     def normal_loglik_rows(self, mu, scale, obs):
         mu, scale, obs = _f64(mu), _f64(scale), _f64(obs)
         B, N = mu.shape
@@ -383,6 +437,13 @@ class Context:
         w = np.empty((M, P))
         self._check(self.lib.bayens_w2_temporal(self.h, HOST, M, P, _ptr(mean), _ptr(var), _ptr(w)))
         return w
+
+    def w2_temporal_dev(self, M, P, mean, var, w):
+        self._check(self.lib.bayens_w2_temporal(self.h, DEVICE, M, P, _ptr(mean), _ptr(var), _ptr(w)))
+
+    def w2_single_dev(self, M, N, mu, chol, w, D):
+        """Full-covariance posteriors resident in HBM: mu [M][N], chol [M][N][N] device buffers."""
+        self._check(self.lib.bayens_w2_single(self.h, DEVICE, M, N, _ptr(mu), _ptr(chol), None, _ptr(w), _ptr(D)))
 
     def w2_single(self, mu, chol=None, sd=None):
         """ModelSimilarityWeight(mode='single'): (w [M], D [M][M]) from full-covariance factors or stddevs."""

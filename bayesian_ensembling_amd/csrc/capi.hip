@@ -313,6 +313,12 @@ int bayens_memcpy_d2h(bayens_ctx* c, void* dst, const void* src, size_t bytes) {
     return 0;
   });
 }
+int bayens_memcpy_d2d(bayens_ctx* c, void* dst, const void* src, size_t bytes) {
+  return guarded(c, [&]() {
+    BAYENS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+  });
+}
 int bayens_sync(bayens_ctx* c) {
   return guarded(c, [&]() { BAYENS_HIP(hipStreamSynchronize(c->stream)); return 0; });
 }
@@ -631,6 +637,27 @@ int bayens_extract_diag_f32(bayens_ctx* c, int loc, int B, int N, const float* c
   });
 }
 
+namespace {
+// rows <- rows L^-T for a caller-supplied compact lower factor (device): the factor is padded into the fit workspace
+// (lower 64-blocks only), its 64x64 diagonal blocks are inverted in one launch, and the rows ride through the blocked
+// right-side solve of the fit (trsm_rlt) - one pass over the factor at the GEMM's pace instead of a serial substitution.
+// Returns the 64-row right-hand-side block (ws.T1's first rows) for the caller to fill BEFORE calling `solve`.
+struct FactorSolve {
+  bayens_ctx* c;
+  FitWorkspace w;
+  int B, N, Np;
+  FactorSolve(bayens_ctx* c_, int B_, int N_, const double* dchol) : c(c_), B(B_), N(N_), Np(pad_to_leaf(N_)) {
+    ensure_ws(c, B, Np);
+    w = ws_view(c, 0, B);
+    BAYENS_HIP(hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), c->stream));
+    c->prims->pad_lower(B, N, Np, dchol, w.T2);
+    c->prims->tri_inv64(B, Np, w.T2, w.invL, w.inv_stride(), w.info);
+  }
+  Mat rows() const { return w.T1; }
+  void solve() { trsm_rlt(*c->prims, B, LEAF, Np, w.T2, w.invL, w.inv_stride(), w.T1); }
+};
+}  // namespace
+
 int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* mu, const double* cov_chol,
                        const double* logdet, const double* obs, double* ll_mean) {
   return guarded(c, [&]() {
@@ -642,8 +669,41 @@ int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const do
     const double* dld = st.in(logdet, (size_t)B);
     const double* dobs = st.in(obs, (size_t)R_obs * N);
     double* dll = st.out(ll_mean, (size_t)B * N);
-    double* ac = st.scratch<double>((size_t)B * 2 * N);
-    c->prims->loglik_rows(B, N, R_obs, dmu, dch, dld, dobs, dll, ac);
+    // the basis (L^-1 1, L^-1 mu) from the factor: two rows through the blocked solve, then the basis path
+    FactorSolve fs(c, B, N, dch);
+    c->prims->solve_rows_set(B, N, fs.Np, 2, 1, nullptr, 0, dmu, fs.rows());
+    fs.solve();
+    double* dots = c->small_scratch((size_t)B * 3 + 2 + (size_t)B * 2 * N);
+    double* basis = dots + (size_t)B * 3 + 2;
+    c->prims->basis_rows_get(B, N, fs.Np, fs.rows(), basis);
+    c->prims->loglik_rows_basis(B, N, R_obs, basis, dld, dobs, dll, dots);
+    st.finish();
+    return 0;
+  });
+}
+
+int bayens_mvn_log_prob(bayens_ctx* c, int loc, int B, int N, int n_x, int shared_x, const double* mu, const double* cov_chol,
+                        const double* logdet, const double* x, double* log_prob) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || n_x <= 0 || !mu || !cov_chol || !logdet || !x || !log_prob)
+      return fail(c, BAYENS_E_ARG, "mvn_log_prob: bad argument");
+    Stage st(c, loc);
+    const double* dmu = st.in(mu, (size_t)B * N);
+    const double* dch = st.in(cov_chol, (size_t)B * N * N);
+    const double* dld = st.in(logdet, (size_t)B);
+    const double* dx = st.in(x, (size_t)(shared_x ? 1 : B) * n_x * N);
+    double* dout = st.out(log_prob, (size_t)B * n_x);
+    FactorSolve fs(c, B, N, dch);
+    double* tmp = st.scratch<double>((size_t)B * LEAF);
+    for (int r0 = 0; r0 < n_x; r0 += LEAF) {           // 64 arguments per pass of the factor
+      const int nr = n_x - r0 < LEAF ? n_x - r0 : LEAF;
+      c->prims->solve_rows_set(B, N, fs.Np, nr, 0, dx + (size_t)r0 * N, shared_x ? 0 : (long)n_x * N, dmu, fs.rows());
+      fs.solve();
+      c->prims->rows_logprob(B, N, nr, fs.rows(), dld, tmp);
+      for (int b = 0; b < B; ++b)
+        BAYENS_HIP(hipMemcpyAsync(dout + (size_t)b * n_x + r0, tmp + (size_t)b * nr, (size_t)nr * sizeof(double),
+                                  hipMemcpyDeviceToDevice, c->stream));
+    }
     st.finish();
     return 0;
   });

@@ -124,12 +124,16 @@ struct HipPrims : Prims {
 
   // not part of the driver interface: pad a compact [nb][N][N] matrix into a padded Mat (identity pad)
   void pad_in(int nb, int N, int Np, const double* src, Mat dst);
+  // a caller-supplied compact lower factor as the operand of the blocked solves: padded lower image, inverted 64x64
+  // diagonal blocks, right-hand-side rows (mode 0: x - mu, mode 1: the pair (1, mu)), log-density of solved rows
+  void pad_lower(int nb, int N, int Np, const double* src, Mat dst);
+  void tri_inv64(int nb, int Np, Mat Lp, real* inv, long inv_stride, int* info);
+  void solve_rows_set(int nb, int N, int Np, int nrows, int mode, const double* x, long x_stride, const double* mu, Mat rows);
+  void rows_logprob(int nb, int N, int nrows, Mat rows, const double* logdet, double* out);
   void fill_random(double* dst, size_t count, unsigned seed);           // uniform [-1, 1), diagnostics only
   void pad_vec(int nb, int N, int Np, const double* src, double* dst);   // [nb][N] -> [nb][Np], zero pad
 
   // weights / weighted-posterior kernels (compact layouts, see include/bayens.h)
-  void loglik_rows(int B, int N, int R_obs, const double* mu, const double* chol, const double* logdet,
-                   const double* obs, double* ll_mean, double* scratch_ac /*[B][2][N]*/);
   // same rows from the precomputed basis [B][2][N] (L_c^-1 1, L_c^-1 mu); dots: scratch [B][3]
   void loglik_rows_basis(int B, int N, int R_obs, const double* basis, const double* logdet, const double* obs,
                          double* ll_mean, double* dots);

@@ -849,63 +849,91 @@ __global__ void aug_get_kernel(int n, Mat rows, real* vec) {
 // LogLikelihoodWeight (weights.py:88-104): the MVN is evaluated at the constant vector x_t * 1_N,
 // log N = -1/2 || x_t a - c ||^2 - logdet - N/2 log 2pi with a = Lc^-1 1, c = Lc^-1 mu.
 // ------------------------------------------------------------------------------------------------
-// forward substitution with the two right-hand sides (1, mu) on a compact [N][N] lower factor, any N;
-// one workgroup per member: 64-row blocks, GEMV part by all 4 waves, the 64x64 diagonal solve by wave 0.
-__global__ __launch_bounds__(256) void trsv_fwd2_kernel(int N, const double* chol, const double* mu, double* ac) {
-  extern __shared__ double lds[];
-  double* xa = lds;            // [Npad]
-  double* xc = lds + ((N + 63) / 64) * 64;
-  __shared__ double D[64][65];
-  __shared__ double ra[64], rc[64];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double* l = chol + (long)b * N * N;
-  const int nl = (N + 63) / 64;
-  for (int jb = 0; jb < nl; ++jb) {
-    const int base = jb * 64;
-    const int rows = N - base < 64 ? N - base : 64;
-    for (int rr = 0; rr < 16; ++rr) {
-      const int rl = w * 16 + rr, row = base + rl;
-      double sa = 0.0, sc = 0.0;
-      if (rl < rows) {
-        for (int k = lane; k < base; k += 64) {
-          const double v = l[(long)row * N + k];
-          sa += v * xa[k];
-          sc += v * xc[k];
-        }
-      }
-      sa = wave_sum(sa);
-      sc = wave_sum(sc);
-      if (lane == 0) {
-        ra[rl] = rl < rows ? 1.0 - sa : 0.0;
-        rc[rl] = rl < rows ? mu[(long)b * N + row] - sc : 0.0;
-      }
-      // diagonal block into LDS (identity outside the matrix)
-      {
-        double v = 0.0;
-        if (rl < rows && base + lane < N && lane <= rl) v = l[(long)row * N + base + lane];
-        if (rl >= rows && lane == rl) v = 1.0;
-        D[rl][lane] = v;
-      }
+// ---- a caller-supplied lower factor (compact [N][N], any N) as the operand of the blocked solves ----------------
+// tile (by, bx <= by) of the padded lower image: the compact factor's lower part, identity in the padding, zeros above
+// the diagonal inside the diagonal blocks (the 64-blocks above the block diagonal are never read by the solves)
+__global__ void pad_lower_kernel(int N, int Np, const double* src, Mat dst) {
+  const int b = blockIdx.z;
+  if (blockIdx.x > blockIdx.y) return;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const double* s = src + (long)b * N * N;
+  real* d = dst.p + b * dst.stride;
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    v[q] = (i < N && j < N) ? (j <= i ? s[(long)i * N + j] : 0.0) : (i == j ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
+}
+// inverse of every 64x64 diagonal block of the padded factor: one workgroup per (block, member).  The block T is
+// re-factored from T T^T by the leaf routine of the blocked Cholesky, which returns the factor AND its inverse.
+__global__ __launch_bounds__(256) void tri_inv64_kernel(Mat Lp, real* inv, long inv_stride, int* info) {
+  __shared__ double T[64][LS];
+  __shared__ double S[64][LS];
+  __shared__ double Mi[64][LS];
+  __shared__ double Tt[4][16][LT];
+  const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const real* a = Lp.p + b * Lp.stride + (long)(64 * blk) * Lp.ld + 64 * blk;
+  {
+    const int c = tid & 63, r0 = tid >> 6;
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      T[r][c] = c <= r ? (double)a[(long)r * Lp.ld + c] : 0.0;
+      Mi[r][c] = 0.0;
     }
-    __syncthreads();
-    if (w == 0) {
-      double va = ra[lane], vc = rc[lane];
-      for (int k = 0; k < 64; ++k) {
-        const double dk = D[k][k];
-        const double xak = __shfl(va, k, 64) / dk, xck = __shfl(vc, k, 64) / dk;
-        if (lane == k) { va = xak; vc = xck; }
-        else if (lane > k) { const double lv = D[lane][k]; va -= lv * xak; vc -= lv * xck; }
-      }
-      xa[base + lane] = va;
-      xc[base + lane] = vc;
+  }
+  __syncthreads();
+  for (int rb = 0; rb < 4; ++rb) {          // S = T T^T (wave w: tile column w of every tile row; lower tiles are used)
+    const int cb = wave;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    if (cb <= rb) {
+      for (int kb = 0; kb <= cb; ++kb) acc = tile_mma<true>(acc, T, 16 * rb, 16 * kb, T, 16 * cb, 16 * kb, lane, 1.0);
     }
+    tile_store(S, 16 * rb, 16 * cb, lane, acc);
+  }
+  __syncthreads();
+  leaf_factor(S, Mi, Tt, b, tid, 64 * blk, info, nullptr);
+  real* iv = inv + b * inv_stride + (long)blk * 4096;
+  {
+    const int c = tid & 63, r0 = tid >> 6;
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q;
+      iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+    }
+  }
+}
+// right-hand-side rows of a solve with the factor: rows[b][r][:] = x[b or 0][r][:] - mu[b][:] (mode 0: log_prob
+// arguments, x_stride = 0 shares the arguments between the members) or the pair (1, mu) (mode 1: the log-likelihood
+// basis); 64 rows per member, the unused ones and the padded columns zero
+__global__ void solve_rows_set_kernel(int N, int Np, int nrows, int mode, const double* x, long x_stride, const double* mu,
+                                      Mat rows) {
+  const int b = blockIdx.z, r = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Np) return;
+  double v = 0.0;
+  if (j < N && r < nrows) {
+    if (mode == 1) v = r == 0 ? 1.0 : mu[(long)b * N + j];
+    else v = x[b * x_stride + (long)r * N + j] - mu[(long)b * N + j];
+  }
+  rows.p[b * rows.stride + (long)r * rows.ld + j] = v;
+}
+// log N(x_r; mu, L L^T) = -|z_r|^2 / 2 - logdet - N log(2 pi) / 2 from the solved rows z_r = L^-1 (x_r - mu)
+__global__ __launch_bounds__(256) void rows_logprob_kernel(int N, int nrows, Mat rows, const double* logdet, double* out) {
+  __shared__ double red[256];
+  const int b = blockIdx.y, r = blockIdx.x;
+  const real* z = rows.p + b * rows.stride + (long)r * rows.ld;
+  double s = 0.0;
+  for (int j = threadIdx.x; j < N; j += 256) s += (double)z[j] * (double)z[j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < N; i += 256) {
-    ac[((long)b * 2) * N + i] = xa[i];
-    ac[((long)b * 2 + 1) * N + i] = xc[i];
-  }
+  if (threadIdx.x == 0) out[(long)b * nrows + r] = -0.5 * red[0] - logdet[b] - 0.5 * N * LOG2PI;
 }
 
 // rows appended to the covariance factorisation (prims.h basis_rows_set / _get)
@@ -970,41 +998,6 @@ __global__ void loglik_basis_kernel(int N, int R_obs, const double* dots, const 
     acc += -0.5 * ((x * x) * aa - 2.0 * x * ac + cc) + cst;
   }
   ll_mean[(long)b * N + t] = acc / R_obs;
-}
-
-constexpr int MAX_ROBS = 4;
-// thread per (member, t): q_r = sum_i (x_rt a_i - c_i)^2 for every observation realisation (chunks of 4)
-__global__ __launch_bounds__(256) void loglik_rows_kernel(int N, int R_obs, const double* ac, const double* logdet,
-                                                          const double* obs, double* ll_mean) {
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const double* a = ac + ((long)b * 2) * N;
-  const double* c = ac + ((long)b * 2 + 1) * N;
-  const double cst = -logdet[b] - 0.5 * N * LOG2PI;
-  double acc_ll = 0.0;
-  for (int r0 = 0; r0 < R_obs; r0 += MAX_ROBS) {
-    const int nr = R_obs - r0 < MAX_ROBS ? R_obs - r0 : MAX_ROBS;
-    double x[MAX_ROBS], q[MAX_ROBS];
-#pragma unroll
-    for (int r = 0; r < MAX_ROBS; ++r) {
-      x[r] = (r < nr && t < N) ? obs[(long)(r0 + r) * N + t] : 0.0;
-      q[r] = 0.0;
-    }
-    for (int i = 0; i < N; ++i) {
-      const double ai = a[i], ci = c[i];
-#pragma unroll
-      for (int r = 0; r < MAX_ROBS; ++r) {
-        if (r < nr) {
-          const double zz = x[r] * ai - ci;
-          q[r] += zz * zz;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < MAX_ROBS; ++r)
-      if (r < nr) acc_ll += -0.5 * q[r] + cst;
-  }
-  if (t < N) ll_mean[(long)b * N + t] = acc_ll / R_obs;
 }
 
 // dx.Normal branch (weights.py:95-96): elementwise log N(x; mu, scale), mean over realisations
@@ -1576,6 +1569,25 @@ void HipPrims::pad_in(int nb, int N, int Np, const double* src, Mat dst) {
   LAUNCH_CHECK();
 }
 
+void HipPrims::pad_lower(int nb, int N, int Np, const double* src, Mat dst) {
+  hipLaunchKernelGGL(pad_lower_kernel, tile_grid(Np, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::tri_inv64(int nb, int Np, Mat Lp, real* inv, long inv_stride, int* info) {
+  hipLaunchKernelGGL(tri_inv64_kernel, dim3(Np / 64, nb), dim3(256), 0, stream, Lp, inv, inv_stride, info);
+  LAUNCH_CHECK();
+}
+void HipPrims::solve_rows_set(int nb, int N, int Np, int nrows, int mode, const double* x, long x_stride, const double* mu,
+                              Mat rows) {
+  hipLaunchKernelGGL(solve_rows_set_kernel, dim3((Np + 255) / 256, 64, nb), dim3(256), 0, stream, N, Np, nrows, mode, x,
+                     x_stride, mu, rows);
+  LAUNCH_CHECK();
+}
+void HipPrims::rows_logprob(int nb, int N, int nrows, Mat rows, const double* logdet, double* out) {
+  hipLaunchKernelGGL(rows_logprob_kernel, dim3(nrows, nb), dim3(256), 0, stream, N, nrows, rows, logdet, out);
+  LAUNCH_CHECK();
+}
+
 void HipPrims::fill_random(double* dst, size_t count, unsigned seed) {
   hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, stream, dst, count, seed);
   LAUNCH_CHECK();
@@ -1585,18 +1597,6 @@ void HipPrims::pad_vec(int nb, int N, int Np, const double* src, double* dst) {
   LAUNCH_CHECK();
 }
 
-void HipPrims::loglik_rows(int B, int N, int R_obs, const double* mu, const double* chol, const double* logdet,
-                           const double* obs, double* ll_mean, double* scratch_ac) {
-  const int Npad = ((N + 63) / 64) * 64;
-  size_t lds = (size_t)2 * Npad * sizeof(double);
-  if (lds > 96 * 1024) throw HipError{-1, "loglik_rows: N too large for the LDS-resident substitution"};
-  if (lds > 16 * 1024)
-    BAYENS_HIP(hipFuncSetAttribute((const void*)trsv_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(trsv_fwd2_kernel, dim3(B), dim3(256), lds, stream, N, chol, mu, scratch_ac);
-  hipLaunchKernelGGL(loglik_rows_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, scratch_ac, logdet,
-                     obs, ll_mean);
-  LAUNCH_CHECK();
-}
 void HipPrims::normal_loglik_rows(int B, int N, int R_obs, const double* mu, const double* scale, const double* obs,
                                   double* ll_mean) {
   hipLaunchKernelGGL(normal_loglik_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, mu, scale, obs,

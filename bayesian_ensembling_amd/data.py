@@ -9,7 +9,7 @@ from __future__ import annotations
 import pickle
 import typing as tp
 import warnings
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -17,21 +17,54 @@ from . import distributions as dx
 from .labelled import DataArray
 
 
-@dataclass
 class Distribution:
-    """ensembles/data.py:18-143.  `dist_type(mu, covariance)` is called positionally (data.py:39)."""
-    mu: np.ndarray
-    covariance: np.ndarray
-    dim_array: DataArray
-    dist_type: tp.Any
-    _factor: tp.Any = field(default=None, repr=False)   # (chol, logdet, basis) handed over by the GPU fit
+    """ensembles/data.py:18-143.  `dist_type(mu, covariance)` is called positionally (data.py:39).
+
+    Same constructor and attributes as the reference's dataclass.  A posterior that came out of a GPU fit is *resident*:
+    `_resident = (ResidentBatch, index)` and `mu` / `covariance` are downloaded from HBM the first time they are read."""
+
+    def __init__(self, mu=None, covariance=None, dim_array=None, dist_type=None, _factor=None, _resident=None):
+        self._mu, self._covariance = mu, covariance
+        self.dim_array, self.dist_type, self._factor, self._resident = dim_array, dist_type, _factor, _resident
+        self.__post_init__()
 
     def __post_init__(self):
-        if self.dist_type is dx.MultivariateNormalFullCovariance and self._factor is not None:
-            self._dist = self.dist_type(self.mu, self.covariance, _chol=self._factor[0], _logdet=self._factor[1],
+        if self._resident is not None:
+            assert self.dist_type is dx.MultivariateNormalFullCovariance
+            self._dist = self.dist_type._from_resident(*self._resident)
+        elif self.dist_type is dx.MultivariateNormalFullCovariance and self._factor is not None:
+            self._dist = self.dist_type(self._mu, self._covariance, _chol=self._factor[0], _logdet=self._factor[1],
                                         _basis=self._factor[2])
         else:
-            self._dist = self.dist_type(self.mu, self.covariance)
+            self._dist = self.dist_type(self._mu, self._covariance)
+
+    @property
+    def mu(self):
+        if self._mu is None:
+            self._mu = self._dist.mean()
+        return self._mu
+
+    @property
+    def covariance(self):
+        if self._covariance is None:
+            self._covariance = self._dist.covariance()
+        return self._covariance
+
+    def __getstate__(self):
+        """Pickling (ModelCollection.save, data.py:397-399) takes the posterior to the host."""
+        state = dict(self.__dict__)
+        if self._resident is not None:
+            d = self._dist
+            state.update(_mu=np.array(self.mu), _covariance=np.array(self.covariance), _resident=None,
+                         _factor=(np.array(d._scale_tri), float(d._logdet), np.array(d._basis)))
+            del state["_dist"]
+        return state
+
+    def __setstate__(self, state):
+        rebuild = "_dist" not in state
+        self.__dict__.update(state)
+        if rebuild:
+            self.__post_init__()
 
     def reshape(self, vals, name=False):
         """data.py:41-55"""

@@ -86,17 +86,56 @@ class MultivariateNormalFullCovariance:
     bayens_mvn_factor_batch."""
 
     def __init__(self, loc, covariance_matrix, _chol=None, _logdet=None, _basis=None):
-        self.loc = np.asarray(loc, dtype=np.float64).reshape(-1)
-        self._cov = np.asarray(covariance_matrix, dtype=np.float64)
-        N = self.loc.size
-        assert self._cov.shape == (N, N), "covariance must be (N, N)"
+        self._resident = None
+        self._loc = np.asarray(loc, dtype=np.float64).reshape(-1)
+        self._cov_h = np.asarray(covariance_matrix, dtype=np.float64)
+        N = self._loc.size
+        assert self._cov_h.shape == (N, N), "covariance must be (N, N)"
         if _chol is None or _logdet is None or _basis is None:
-            chol, logdet, basis = _lib.default_context().mvn_factor_batch(self._cov[None], self.loc[None])
+            chol, logdet, basis = _lib.default_context().mvn_factor_batch(self._cov_h[None], self._loc[None])
             _chol, _logdet, _basis = chol[0], float(logdet[0]), basis[0]
-        self._scale_tri = np.asarray(_chol, dtype=np.float64)
-        self._logdet = float(_logdet)
+        self._chol_h = np.asarray(_chol, dtype=np.float64)
+        self._logdet_h = float(_logdet)
         # (L^-1 1, L^-1 loc): by-products of the bordered factorisation; all a constant-vector log_prob needs
-        self._basis = np.asarray(_basis, dtype=np.float64)
+        self._basis_h = np.asarray(_basis, dtype=np.float64)
+        self._var_h = None
+
+    @classmethod
+    def _from_resident(cls, batch, j):
+        """Member j of a ResidentBatch (resident.py): nothing is copied; each piece is fetched from HBM when first read."""
+        self = cls.__new__(cls)
+        self._resident = (batch, j)
+        self._loc = self._cov_h = self._chol_h = self._logdet_h = self._basis_h = self._var_h = None
+        return self
+
+    def _row(self, attr, buf_name):
+        if getattr(self, attr) is None:
+            batch, j = self._resident
+            setattr(self, attr, batch.row(getattr(batch, buf_name), j))
+        return getattr(self, attr)
+
+    @property
+    def loc(self):
+        return self._row("_loc", "mu64")
+
+    @property
+    def _cov(self):
+        return self._row("_cov_h", "cov")
+
+    @property
+    def _scale_tri(self):
+        return self._row("_chol_h", "chol")
+
+    @property
+    def _basis(self):
+        return self._row("_basis_h", "basis64")
+
+    @property
+    def _logdet(self):
+        if self._logdet_h is None:
+            batch, j = self._resident
+            self._logdet_h = float(batch.row(batch.logdet, j))
+        return self._logdet_h
 
     def mean(self):
         return self.loc
@@ -105,18 +144,25 @@ class MultivariateNormalFullCovariance:
         return self._cov
 
     def variance(self):
-        return np.ascontiguousarray(np.diagonal(self._cov))
+        if self._var_h is None:
+            if self._resident is not None:
+                batch, j = self._resident
+                self._var_h = batch.row(batch.var64, j)
+            else:
+                self._var_h = np.ascontiguousarray(np.diagonal(self._cov_h))
+        return self._var_h
 
     def stddev(self):
         return np.sqrt(self.variance())
 
     def log_prob(self, x):
-        """The form the reference uses (weights.py:98-100): x of shape (T, 1) broadcasts against the event
-        shape N, i.e. the density is evaluated at the constant vector x_t * 1 for every t -> (T,)."""
+        """distrax semantics: x broadcasts against the event shape (N,).  (N,) -> scalar, (..., N) -> (...); the
+        (T, 1) form the reference's weight uses (weights.py:98-100) evaluates the density at the constant vector
+        x_t * 1 for every t -> (T,) and runs from the basis alone (no pass over the factor)."""
         x = np.asarray(x, dtype=np.float64)
-        if x.ndim == 2 and x.shape[1] == 1:
-            ctx = _lib.default_context()
-            N = self.loc.size
+        ctx = _lib.default_context()
+        N = self._resident[0].N if self._resident is not None else self._loc.size
+        if x.ndim == 2 and x.shape[1] == 1 and N != 1:
             out = np.empty(x.shape[0])
             # the kernel takes observation rows of length N; feed the T values in chunks of N
             vals = x[:, 0]
@@ -127,9 +173,18 @@ class MultivariateNormalFullCovariance:
                 ll = ctx.loglik_rows_basis(self._basis[None], np.array([self._logdet]), chunk[None])
                 out[s:s + seg.size] = ll[0, :seg.size]
             return out
-        raise NotImplementedError(
-            "MultivariateNormalFullCovariance.log_prob: only the (T, 1) broadcast form used by "
-            "LogLikelihoodWeight (ensembles/weights.py:98-100) runs on the device in this version")
+        if x.shape[-1] != N:
+            raise ValueError(f"log_prob: the last axis of x must be the event size {N} (or x of shape (T, 1))")
+        flat = np.ascontiguousarray(x.reshape(-1, N))
+        if self._resident is not None:          # the factor never leaves HBM
+            batch, j = self._resident
+            if batch.dtype == np.float64:
+                view = _lib.DeviceView(batch.mu.offset(j * N * 8), (1, N)), _lib.DeviceView(batch.chol.offset(j * N * N * 8), (1, N, N)), \
+                    _lib.DeviceView(batch.logdet.offset(j * 8), (1,))
+                out = ctx.mvn_log_prob(*view, flat, loc=_lib.DEVICE)[0]
+                return out.reshape(x.shape[:-1]) if x.ndim > 1 else float(out[0])
+        out = ctx.mvn_log_prob(self.loc[None], self._scale_tri[None], np.array([self._logdet]), flat)[0]
+        return out.reshape(x.shape[:-1]) if x.ndim > 1 else float(out[0])
 
     def sample(self, seed=0):
         rng = np.random.default_rng(int(seed))

@@ -10,6 +10,7 @@ from . import _lib
 from . import distributions as dx
 from .data import Distribution, ModelCollection
 from .labelled import DataArray, ones_like
+from .resident import resident_tables
 
 
 class AbstractEnsembleScheme:
@@ -45,9 +46,22 @@ class Barycentre(AbstractEnsembleScheme):
         w = np.asarray(getattr(weights, "values", weights), dtype=np.float64).reshape(M, -1)
         if w.shape[1] != n_points:
             raise ValueError(f"weights have {w.shape[1]} points per model, the posteriors {n_points}")
-        mean = np.stack([np.asarray(pm.distribution._dist.mean()).reshape(-1) for pm in process_models.models])
-        var = np.stack([np.asarray(pm.distribution._dist.variance()).reshape(-1) for pm in process_models.models])
-        mu, v, bad = _lib.default_context().barycentre(w, mean, var)
+        ds = [pm.distribution._dist for pm in process_models.models]
+        if all(getattr(d, "_resident", None) is not None for d in ds):
+            # resident posteriors: the [M, P] marginals are read in HBM; the weights go up, mu* / sigma*^2 come down
+            ctx = _lib.default_context()
+            _, _, mean, var, _, owned = resident_tables(ctx, ds)
+            dw, dmu, dv = ctx.to_device(w), ctx.empty((n_points,)), ctx.empty((n_points,))
+            try:
+                bad = ctx.barycentre_dev(M, n_points, dw, mean, var, dmu, dv)
+                mu, v = dmu.download(), dv.download()
+            finally:
+                for d in [dw, dmu, dv] + owned:
+                    d.free()
+        else:
+            mean = np.stack([np.asarray(d.mean()).reshape(-1) for d in ds])
+            var = np.stack([np.asarray(d.variance()).reshape(-1) for d in ds])
+            mu, v, bad = _lib.default_context().barycentre(w, mean, var)
         if bad:
             import warnings
             warnings.warn(f"Barycentre not converged for {bad} time step(s)")

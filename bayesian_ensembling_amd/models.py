@@ -16,6 +16,7 @@ from . import _lib
 from . import distributions as dx
 from .data import Distribution
 from .labelled import ones_like
+from .resident import ResidentBatch
 
 
 def _blank_array(process_model):
@@ -69,6 +70,7 @@ class GPDTW1D:
         for i, (X, _, _) in enumerate(pro):
             groups.setdefault(X.shape, []).append(i)
         dists = [None] * len(process_models)
+        f32 = self.dtype != np.float64
         for shape, idxs in groups.items():
             X = np.stack([pro[i][0] for i in idxs])
             if self.target == "dba":
@@ -76,18 +78,28 @@ class GPDTW1D:
             else:
                 y = np.stack([pro[i][1] for i in idxs])
             nu = np.stack([pro[i][2] for i in idxs])
-            out = ctx.gp_fit_batch(X, y, nu, n_optim_nits, kernel=_lib.KERNEL_IDS[self.kernel],
-                                   want_loss=bool(progress_bar), dtype=self.dtype)
-            if self.dtype != np.float64:   # the containers, weights and schemes work on float64 tables
-                out = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
-                       for k, v in out.items()}
+            B, N, R = X.shape
+            # the posteriors stay in HBM (resident.py): inputs go up (a few MB), the fit runs on resident buffers, and
+            # only the hyper-parameters and loss samples come back; mu / cov / chol are fetched if somebody reads them
+            batch = ResidentBatch(ctx, B, N, self.dtype)
+            n_loss = (int(n_optim_nits) + 24) // 25 if progress_bar else 0
+            dX, dy, dnu = ctx.to_device(X, self.dtype), ctx.to_device(y, self.dtype), ctx.to_device(nu, self.dtype)
+            dloss = ctx.empty((B, n_loss)) if n_loss else None
+            try:
+                ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol, batch.logdet,
+                                     batch.hyp, kernel=_lib.KERNEL_IDS[self.kernel], basis=batch.basis, f32=f32, loss=dloss)
+                batch.finish()
+                hyp = batch.hyp.download()
+                loss = dloss.download() if dloss is not None else None
+            finally:
+                for d in (dX, dy, dnu, dloss):
+                    if d is not None:
+                        d.free()
             for j, i in enumerate(idxs):
-                dists[i] = Distribution(mu=out["mu"][j], covariance=out["cov"][j],
-                                        dim_array=_blank_array(process_models[i]),
-                                        dist_type=dx.MultivariateNormalFullCovariance,
-                                        _factor=(out["chol"][j], float(out["logdet"][j]), out["basis"][j]))
-                dists[i].hyperparameters = {"variance": float(out["hyp"][j, 0]), "lengthscale": float(out["hyp"][j, 1])}
-                dists[i].losses = None if out["loss"] is None else out["loss"][j].copy()
+                dists[i] = Distribution(dim_array=_blank_array(process_models[i]),
+                                        dist_type=dx.MultivariateNormalFullCovariance, _resident=(batch, j))
+                dists[i].hyperparameters = {"variance": float(hyp[j, 0]), "lengthscale": float(hyp[j, 1])}
+                dists[i].losses = None if loss is None else loss[j].copy()
         return dists
 
     def fit(self, model, n_optim_nits: int = 500, compile_objective: bool = False, progress_bar: bool = True):

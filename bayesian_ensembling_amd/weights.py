@@ -13,6 +13,7 @@ from . import _lib
 from . import distributions as dx
 from .data import ModelCollection, ProcessModel
 from .labelled import DataArray, concat
+from .resident import resident_tables
 
 __all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight", "InverseSquareWeight", "UniformWeight",
            "KSDWeight", "CRPSWeight"]
@@ -66,6 +67,20 @@ class LogLikelihoodWeight(AbstractWeight):
                 for i in full:   # MultivariateNormalDiag etc.: generic log_prob with the (N,1) broadcast
                     d = models[i].distribution._dist
                     ll_mean[i] = np.mean([d.log_prob(o[:, None]) for o in obs], axis=0)
+            elif len(full) == M and all(getattr(d, "_resident", None) is not None for d in ds) and \
+                    (standardisation_scheme is None or standardisation_scheme == "exp" or standardisation_scheme is np.exp):
+                # every posterior is resident in HBM (resident.py): rows, normalisation and the raw likelihoods are
+                # computed from the resident basis / log-determinants; only obs goes up and the [M, P] tables come down
+                basis, logdet, _, _, _, owned = resident_tables(ctx, ds)
+                dobs, dll, dw, draw = ctx.to_device(obs), ctx.empty((M, P)), ctx.empty((M, P)), ctx.empty((M, P))
+                try:
+                    ctx.loglik_rows_basis_dev(M, P, obs.shape[0], basis, logdet, dobs, dll)
+                    ctx.weights_normalise_dev(M, P, dll, standardisation_constant, dw, draw)
+                    w, raw = dw.download(), draw.download()
+                finally:
+                    for d in [dobs, dll, dw, draw] + owned:
+                        d.free()
+                return self._finish(process_models, observations, models, w, raw, return_lls)
             else:
                 basis = np.stack([d._basis for d in ds])
                 logdet = np.array([d._logdet for d in ds])
@@ -82,6 +97,10 @@ class LogLikelihoodWeight(AbstractWeight):
             with np.errstate(all="ignore"):
                 w = raw / raw.sum(axis=0, keepdims=True)
 
+        return self._finish(process_models, observations, models, w, raw, return_lls)
+
+    @staticmethod
+    def _finish(process_models, observations, models, w, raw, return_lls):
         def to_da(vals, name):
             rows = []
             for i, m in enumerate(models):
@@ -107,9 +126,21 @@ class ModelSimilarityWeight(AbstractWeight):
         reference."""
         if mode == "temporal":
             ctx = _lib.default_context()
-            mean = np.stack([np.asarray(m.distribution._dist.mean()).reshape(-1) for m in process_models.models])
-            var = np.stack([np.asarray(m.distribution._dist.variance()).reshape(-1) for m in process_models.models])
-            w = ctx.w2_temporal(mean, var)
+            ds = [m.distribution._dist for m in process_models.models]
+            if all(getattr(d, "_resident", None) is not None for d in ds):
+                _, _, mean, var, _, owned = resident_tables(ctx, ds)     # marginals straight from HBM
+                M, P = len(ds), ds[0]._resident[0].N
+                dw = ctx.empty((M, P))
+                try:
+                    ctx.w2_temporal_dev(M, P, mean, var, dw)
+                    w = dw.download()
+                finally:
+                    for d in [dw] + owned:
+                        d.free()
+            else:
+                mean = np.stack([np.asarray(d.mean()).reshape(-1) for d in ds])
+                var = np.stack([np.asarray(d.variance()).reshape(-1) for d in ds])
+                w = ctx.w2_temporal(mean, var)
             out = DataArray(w, ("model", "time"),
                             {"model": np.asarray(process_models.model_names),
                              "time": process_models[0].model_data.coords["time"]},
@@ -118,6 +149,22 @@ class ModelSimilarityWeight(AbstractWeight):
         if mode == "single":
             ctx = _lib.default_context()
             dists = [m.distribution._dist for m in process_models.models]
+            if all(getattr(d, "_resident", None) is not None for d in dists):
+                _, _, mean, _, chol, owned = resident_tables(ctx, dists, want_chol=True)
+                if chol is not None:                       # fp64 factors: they never leave HBM
+                    M, N = len(dists), dists[0]._resident[0].N
+                    dw, dD = ctx.empty((M,)), ctx.empty((M, M))
+                    try:
+                        ctx.w2_single_dev(M, N, mean, chol, dw, dD)
+                        w = dw.download()
+                    finally:
+                        for d in [dw, dD] + owned:
+                            d.free()
+                    return DataArray(w[:, None], ("model", "time"),
+                                     {"model": np.asarray(process_models.model_names), "time": np.asarray([0])},
+                                     "Model similarity weights")
+                for d in owned:
+                    d.free()
             mu = np.stack([np.asarray(d.mean()).reshape(-1) for d in dists])
             if all(isinstance(d, dx.MultivariateNormalFullCovariance) for d in dists):
                 w, _ = ctx.w2_single(mu, chol=np.stack([d._scale_tri for d in dists]))

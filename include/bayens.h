@@ -50,6 +50,8 @@ int bayens_malloc(bayens_ctx* ctx, size_t bytes, void** dptr);
 int bayens_free(bayens_ctx* ctx, void* dptr);
 int bayens_memcpy_h2d(bayens_ctx* ctx, void* dst, const void* src, size_t bytes);
 int bayens_memcpy_d2h(bayens_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* device-to-device copy queued on the ctx stream (no host wait) */
+int bayens_memcpy_d2d(bayens_ctx* ctx, void* dst, const void* src, size_t bytes);
 int bayens_sync(bayens_ctx* ctx);
 /* HIP-event timer on the ctx stream (the stream every kernel of this library is launched on) */
 int bayens_timer_start(bayens_ctx* ctx);
@@ -138,6 +140,12 @@ int bayens_widen_f32(bayens_ctx* ctx, int loc, size_t n, const float* src, doubl
 int bayens_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                        const double* mu, const double* cov_chol, const double* logdet,
                        const double* obs, double* ll_mean);
+
+/* distrax MultivariateNormalFullCovariance.log_prob for ordinary arguments (the reference evaluates it with an (N,)
+ * sample at ensembles/utils.py:139-155 on the diagonal type; this is the full-covariance form): log_prob[b][r] =
+ * log N(x_r ; mu_b, L_b L_b^T), L = cov_chol.  x [B][n_x][N], or [n_x][N] shared by every member when shared_x != 0. */
+int bayens_mvn_log_prob(bayens_ctx* ctx, int loc, int B, int N, int n_x, int shared_x, const double* mu,
+                        const double* cov_chol, const double* logdet, const double* x, double* log_prob);
 
 /* the same rows from the basis a fit / factorisation returned (no triangular solve, no pass over chol) */
 int bayens_loglik_rows_basis(bayens_ctx* ctx, int loc, int B, int N, int R_obs, const double* ll_basis,

@@ -243,6 +243,14 @@ def mvn_constvec_loglik(mu, Lc, logdet, obs):
     return -0.5 * q - logdet - 0.5 * N * LOG2PI
 
 
+def mvn_logprob(mu, Lc, logdet, x):
+    """distrax MultivariateNormalFullCovariance.log_prob for ordinary arguments x (..., N):
+    -|Lc^-1 (x - mu)|^2 / 2 - sum(log diag Lc) - N log(2 pi) / 2   [distrax 0.1.2; data.py:38-39 builds the object]."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    z = sla.solve_triangular(Lc, (x - mu).T, lower=True)
+    return -0.5 * np.sum(z * z, axis=0) - logdet - 0.5 * mu.shape[0] * LOG2PI
+
+
 def normal_loglik(mu, scale, obs):
     """dx.Normal(loc, scale).log_prob(x) elementwise                  [weights.py:95-96].
 
