@@ -76,6 +76,7 @@ def load():
                                                 C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+    lib.bayens_loglik_rows_basis_grouped.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_extract_diag.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_weighted_posterior.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
                                               C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_int)]
@@ -362,6 +363,17 @@ class Context:
     def loglik_rows_basis_dev(self, B, N, R_obs, basis, logdet, obs, ll_mean):
         self._check(self.lib.bayens_loglik_rows_basis(self.h, DEVICE, B, N, R_obs, _ptr(basis), _ptr(logdet),
                                                       _ptr(obs), _ptr(ll_mean)))
+
+    def loglik_rows_basis_grouped(self, basis, logdet, obs, loc=HOST, out=None):
+        """Field of posteriors [M][G]: basis [B,2,N], logdet [B], obs [G,R_obs,N] -> ll_mean [B,N] (B = M * G)."""
+        if loc == HOST:
+            basis, logdet, obs = _f64(basis), _f64(logdet), _f64(obs)
+            out = np.empty((basis.shape[0], basis.shape[2]))
+        B, N = basis.shape[0], basis.shape[-1]
+        G, R_obs = obs.shape[0], obs.shape[1]
+        self._check(self.lib.bayens_loglik_rows_basis_grouped(self.h, loc, B, N, R_obs, G, _ptr(basis), _ptr(logdet),
+                                                              _ptr(obs), _ptr(out)))
+        return out
 
     def extract_diag(self, cov):
         cov = _f64(cov)

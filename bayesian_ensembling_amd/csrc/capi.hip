@@ -725,6 +725,22 @@ int bayens_loglik_rows_basis(bayens_ctx* c, int loc, int B, int N, int R_obs, co
   });
 }
 
+int bayens_loglik_rows_basis_grouped(bayens_ctx* c, int loc, int B, int N, int R_obs, int n_groups, const double* ll_basis,
+                                     const double* logdet, const double* obs, double* ll_mean) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R_obs <= 0 || n_groups <= 0 || B % n_groups || !ll_basis || !logdet || !obs || !ll_mean)
+      return fail(c, BAYENS_E_ARG, "loglik_rows_basis_grouped: bad argument (B must be a multiple of n_groups)");
+    Stage st(c, loc);
+    const double* db = st.in(ll_basis, (size_t)B * 2 * N);
+    const double* dld = st.in(logdet, (size_t)B);
+    const double* dobs = st.in(obs, (size_t)n_groups * R_obs * N);
+    double* dll = st.out(ll_mean, (size_t)B * N);
+    c->prims->loglik_rows_basis(B, N, R_obs, db, dld, dobs, dll, c->small_scratch((size_t)B * 3), n_groups);
+    st.finish();
+    return 0;
+  });
+}
+
 int bayens_normal_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* mu,
                               const double* scale, const double* obs, double* ll_mean) {
   return guarded(c, [&]() {

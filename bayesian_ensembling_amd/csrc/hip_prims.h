@@ -135,8 +135,9 @@ struct HipPrims : Prims {
 
   // weights / weighted-posterior kernels (compact layouts, see include/bayens.h)
   // same rows from the precomputed basis [B][2][N] (L_c^-1 1, L_c^-1 mu); dots: scratch [B][3]
+  // n_groups > 1: posterior b is evaluated at the observation set b % n_groups (obs [n_groups][R_obs][N])
   void loglik_rows_basis(int B, int N, int R_obs, const double* basis, const double* logdet, const double* obs,
-                         double* ll_mean, double* dots);
+                         double* ll_mean, double* dots, int n_groups = 1);
   void normal_loglik_rows(int B, int N, int R_obs, const double* mu, const double* scale,
                           const double* obs, double* ll_mean);
   void weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw);

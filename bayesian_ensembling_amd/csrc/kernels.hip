@@ -985,11 +985,12 @@ __global__ __launch_bounds__(256) void basis_dots_kernel(int N, const double* ba
 }
 
 // weights.py:98-104 from the basis: ||x a - c||^2 = x^2 a.a - 2 x a.c + c.c ; mean over realisations
-__global__ void loglik_basis_kernel(int N, int R_obs, const double* dots, const double* logdet, const double* obs,
-                                    double* ll_mean) {
-  const int b = blockIdx.y;
+__global__ void loglik_basis_kernel(int N, int R_obs, const double* dots, const double* logdet, const double* obs_all,
+                                    int n_groups, int b0, double* ll_mean) {
+  const int b = b0 + blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
+  const double* obs = obs_all + (long)(b % n_groups) * R_obs * N;       // one observation set per group of posteriors
   const double aa = dots[b * 3], ac = dots[b * 3 + 1], cc = dots[b * 3 + 2];
   const double cst = -logdet[b] - 0.5 * N * LOG2PI;
   double acc = 0.0;
@@ -1464,10 +1465,13 @@ void HipPrims::basis_rows_get(int nb, int N, int Np, Mat rows, real* basis) {
   LAUNCH_CHECK();
 }
 void HipPrims::loglik_rows_basis(int B, int N, int R_obs, const double* basis, const double* logdet,
-                                 const double* obs, double* ll_mean, double* dots) {
+                                 const double* obs, double* ll_mean, double* dots, int n_groups) {
   hipLaunchKernelGGL(basis_dots_kernel, dim3(B), dim3(256), 0, stream, N, basis, dots);
-  hipLaunchKernelGGL(loglik_basis_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, N, R_obs, dots, logdet, obs,
-                     ll_mean);
+  for (int b0 = 0; b0 < B; b0 += 32768) {          // (gridDim.y is limited to 65535)
+    const int nb = B - b0 < 32768 ? B - b0 : 32768;
+    hipLaunchKernelGGL(loglik_basis_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, R_obs, dots, logdet, obs,
+                       n_groups, b0, ll_mean);
+  }
   LAUNCH_CHECK();
 }
 void HipPrims::resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) {

@@ -209,6 +209,141 @@ class Workload:
                         "this kernel from the rocprofv3 --pmc passes named in traffic_source (not measured in this run)"}
 
 
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy)
+
+
+class FieldWorkload:
+    """BASELINE.json config 5: one independent GP per (member, grid point) - M = 32 members x G grid points per GPU
+    (96 x 144 = 13 824 points over 8 GPUs = 1 728 per GPU), N = 86 annual steps, R = 8.  One step = ONE launch of the
+    fused small-member kernel over the B = M * G fits (reduced export: mu, diag(cov), basis, logdet; or the full
+    covariance) -> per-gridpoint LogLikelihoodWeight rows -> normalisation over the members -> barycentre per point."""
+
+    def __init__(self, ctx, M, G, N, R, T, export, R_obs=3, seed=0xC5):
+        self.ctx, self.M, self.G, self.N, self.R, self.T, self.export, self.R_obs = ctx, M, G, N, R, T, export, R_obs
+        B = self.B = M * G
+        rng = np.random.default_rng(seed)
+        tau = np.linspace(0.0, 1.0, N)
+        amp = 0.8 + 0.4 * rng.random((M, 1, 1, 1))                      # member signal, shared by its grid points
+        loc = 1.0 + 0.2 * rng.standard_normal((1, G, 1, 1))             # grid-point offset of the trend
+        data = 1.5 * amp * loc * tau ** 2 + 0.036 * rng.standard_normal((M, G, R, N)).cumsum(axis=3)
+        obs = 1.5 * loc[0] * tau ** 2 + 0.036 * rng.standard_normal((G, R_obs, N)).cumsum(axis=2)
+        data = data.reshape(B, R, N)
+        X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
+        self.dX, self.dy, self.dnu = ctx.to_device(X), ctx.to_device(data.mean(axis=1)), ctx.to_device(data.var(axis=1))
+        self.dobs = ctx.to_device(obs)
+        self.dmu, self.dvar, self.dld, self.dhyp = ctx.empty((B, N)), ctx.empty((B, N)), ctx.empty((B,)), ctx.empty((B, 2))
+        self.dbasis, self.dll, self.dw = ctx.empty((B, 2, N)), ctx.empty((B, N)), ctx.empty((B, N))
+        self.dcov = ctx.empty((B, N, N)) if export == "full" else None
+        self.dbmu, self.dbvar = ctx.empty((G * N,)), ctx.empty((G * N,))
+        self.bufs = [b for b in (self.dX, self.dy, self.dnu, self.dobs, self.dmu, self.dvar, self.dld, self.dhyp, self.dbasis,
+                                 self.dll, self.dw, self.dcov, self.dbmu, self.dbvar) if b is not None]
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+    def fit(self):
+        c = self.ctx
+        if self.export == "full":
+            info = c.gp_fit_batch_dev(self.B, self.N, self.R, self.dX, self.dy, self.dnu, self.T, self.dmu, self.dcov, None,
+                                      self.dld, self.dhyp, basis=self.dbasis)
+            c.extract_diag_dev(self.B, self.N, self.dcov, self.dvar)
+            return info
+        return c.gp_fit_batch_reduced_dev(self.B, self.N, self.R, self.dX, self.dy, self.dnu, self.T, self.dmu, self.dvar,
+                                          self.dld, self.dhyp, self.dbasis)
+
+    def weighted_posterior(self):
+        c, P = self.ctx, self.G * self.N
+        c.loglik_rows_basis_grouped(self.dbasis, self.dld, self.dobs, loc=1, out=self.dll)
+        c.weights_normalise_dev(self.M, P, self.dll, 1e-3, self.dw)
+        return c.barycentre_dev(self.M, P, self.dw, self.dmu, self.dvar, self.dbmu, self.dbvar)
+
+    def step(self):
+        self.fit()
+        return self.weighted_posterior()
+
+    def measure(self, steps, warmup):
+        c = self.ctx
+        for _ in range(warmup):
+            self.step()
+        c.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        c.sync()
+        elapsed = time.perf_counter() - t0
+        c.timer_start(); self.fit(); fit_ms = c.timer_stop()          # the dominant kernel: HIP events on its stream
+        c.timer_start(); bad = self.weighted_posterior(); wp_ms = c.timer_stop()
+        N, R = self.N, self.R
+        in_b = 8.0 * (N * R + 2 * N)
+        out_b = 8.0 * (N * N + N) if self.export == "full" else 8.0 * (4 * N + 3)
+        gbs = self.B * (in_b + out_b) / (fit_ms * 1e-3) / 1e9
+        tfl = self.B * fit_flops(N, R, self.T) / (fit_ms * 1e-3) / 1e12
+        return {"value": round(self.B * steps / elapsed, 1), "unit": "member-fits/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "fits_per_step": self.B, "export": self.export, "fit_kernel_ms": round(fit_ms, 3),
+                "weighted_posterior_latency_ms": round(wp_ms, 4), "barycentre_not_converged": int(bad),
+                "roofline": {"bound": "hbm", "kernel": "bayens::smalln::small_fit_kernel<6>", "achieved": round(gbs, 2),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                             "algorithmic_bytes_per_fit": in_b + out_b, "launches_per_step": 1,
+                             "avg_launch_us": round(fit_ms * 1e3, 1),
+                             "note": "SURVEY 8(d) prices config 5 against HBM; with every matrix resident in LDS the kernel is "
+                                     "bound by the fp64 matrix / vector pipes and its serial 16x16 factorisations, not by "
+                                     "HBM - see roofline_mfma"},
+                "roofline_mfma": {"bound": "mfma", "achieved": round(tfl, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tfl / F64_MFMA_PEAK_TFLOPS, 4),
+                                  "algorithmic_flop_per_fit": fit_flops(N, R, self.T)}}
+
+
+def cpu_baseline_small(N, R, T, fits):
+    from threadpoolctl import threadpool_info
+    from oracle import gp_oracle as go
+    data, _ = go.synthetic_ensemble(fits, N, R=R, seed=0xC5)
+    t0 = time.time()
+    for m in range(fits):
+        X, y, nu = go.prologue(data[m])
+        mu, cov, _ = go.gp_fit(X, y, nu, T)
+        go.mvn_factor(cov)
+    dt = time.time() - t0
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    return {"value": fits / dt, "unit": "member-fits/s", "cores": int(threads), "kind": "port",
+            "sample": f"{fits} fits of the same shape (N={N}, R={R}, n_optim_nits={T}), NumPy/LAPACK oracle, {dt:.1f} s"}
+
+
+def api_path(ctx, M, N, R, T, reps=3):
+    """The same step through the plug-in classes a user of the reference calls: ModelCollection.fit(GPDTW1D) ->
+    LogLikelihoodWeight -> Barycentre (ensembles/data.py:385-395, weights.py:87-131, ensemble_scheme.py:43-81), host
+    arrays in, posteriors resident in HBM (resident.py).  Includes the PCIe upload of the realisations, the Python
+    containers and the download of the [M, N] weight table and the barycentre."""
+    import warnings
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    from bayesian_ensembling_amd.synthetic import synthetic_ensemble
+    data, obs = synthetic_ensemble(M, N, R=R, R_obs=3, seed=0xB4E5)
+    tcoord = np.arange(N)
+    mk = lambda a: DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": tcoord})
+    mc = es.ModelCollection([es.ProcessModel(mk(data[m]), f"member{m}") for m in range(M)])
+    ob = es.ProcessModel(mk(obs), "obs")
+    times = {}
+    for bar in (False, True):
+        best = None
+        for _ in range(reps + 1):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t0 = time.perf_counter()
+                mc.fit(model=es.GPDTW1D(), n_optim_nits=T, progress_bar=bar)
+                w = es.LogLikelihoodWeight()(mc, ob, standardisation_constant=1e-3)
+                post = es.Barycentre()(mc, w)
+                dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        times[bar] = best
+    assert np.isfinite(post.mu).all()
+    return {"api_path_fits_per_s": round(M / times[False], 2), "api_path_ms_per_step": round(times[False] * 1e3, 2),
+            "api_path_fits_per_s_with_loss_samples": round(M / times[True], 2),
+            "api_path_note": "ModelCollection.fit(GPDTW1D, progress_bar=False) + LogLikelihoodWeight + Barycentre through the "
+                             "Python classes, best of %d; *_with_loss_samples = progress_bar=True (the reference default: one "
+                             "-ELBO sample per 25 iterations)" % reps}
+
+
 def spawn_ranks(args):
     """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
     rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
@@ -236,14 +371,58 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+def run_config5(args, ctx, rank, world, exchange, rdzv):
+    """--config c5: grid points shard over the ranks with no data-path collective; each rank runs its own
+    32 x grid-points field.  value = all ranks' fits / max-over-ranks time."""
+    M, G, N, R, T = args.members, args.grid_points, 86, args.realisations, args.nits
+    fw = FieldWorkload(ctx, M, G, N, R, T, args.export, seed=0xC5 + rank)
+    for _ in range(args.warmup):
+        fw.step()
+    ctx.sync()
+    if exchange is not None:
+        exchange.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fw.step()
+    ctx.sync()
+    if exchange is not None:
+        exchange.barrier()
+    elapsed = time.perf_counter() - t0
+    if exchange is not None:
+        elapsed = exchange.max_float(elapsed)
+        exchange.close()
+        rdzv.close()
+    if rank != 0:
+        return
+    d = fw.measure(1, 0)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_small(N, R, T, 400)
+    out = {"metric": METRIC, "value": round(fw.B * world * args.steps / elapsed, 1), "unit": "member-fits/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 5: {M} members x {G} grid points per GPU of independent GP fits (N={N} annual "
+                                  f"steps, R={R}, matern32, n_optim_nits={T}, {args.export} export) + per-gridpoint "
+                                  "LogLikelihoodWeight(c=1e-3) + Barycentre",
+                      "preset": "c5", "members": M, "grid_points_per_gpu": G, "fits_per_gpu": fw.B, "timesteps": N,
+                      "realisations": R, "n_optim_nits": T, "export": args.export,
+                      "parallelism": f"grid points sharded x{world}, no collective" if world > 1 else "single GPU"},
+           "roofline": d["roofline"], "roofline_mfma": d["roofline_mfma"], "cpu_baseline": cpu,
+           "fit_kernel_ms": d["fit_kernel_ms"], "weighted_posterior_latency_ms": d["weighted_posterior_latency_ms"]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json preset: c2 = 32 members/GPU fp64 matern32 (headline); c3 = fp32 matern52; "
-                         "c4 = 16 members/GPU (128 members sharded 8-way)")
+                         "c4 = 16 members/GPU (128 members sharded 8-way); c5 = 32 members x 1728 grid points/GPU of "
+                         "independent N=86 fits (96x144 points sharded 8-way, no collective)")
+    ap.add_argument("--grid-points", type=int, default=1728, help="config 5: grid points per GPU")
+    ap.add_argument("--export", default="reduced", choices=["reduced", "full"], help="config 5: what a fit exports")
     ap.add_argument("--members", type=int, default=None, help="members per GPU (default: the preset's)")
     ap.add_argument("--timesteps", type=int, default=2000)
     ap.add_argument("--realisations", type=int, default=8)
@@ -258,7 +437,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (T=500, config 3, RBF)")
     ap.add_argument("--cpu-members", type=int, default=2)
     args = ap.parse_args()
-    preset = {"c2": (32, "matern32", "f64"), "c3": (32, "matern52", "f32"), "c4": (16, "matern32", "f64")}[args.config]
+    preset = {"c2": (32, "matern32", "f64"), "c3": (32, "matern52", "f32"), "c4": (16, "matern32", "f64"),
+              "c5": (32, "matern32", "f64")}[args.config]
     args.members = args.members or preset[0]
     args.kernel = args.kernel or preset[1]
     args.dtype = args.dtype or preset[2]
@@ -285,6 +465,9 @@ def main():
         rdzv = parallel.FileRendezvous(parallel.FileRendezvous.directory_from_env(), rank, world)
         exchange = parallel.RcclExchange(ctx, rdzv) if args.exchange == "rccl" else parallel.HostStagedExchange(ctx, rdzv)
 
+    if args.config == "c5":
+        run_config5(args, ctx, rank, world, exchange, rdzv)
+        return
     M, N, R, T = args.members, args.timesteps, args.realisations, args.nits
     f32 = args.dtype == "f32"
     wl = Workload(ctx, M, N, R, T, args.kernel, f32, rank, world, exchange, args.groups)
@@ -324,6 +507,18 @@ def main():
             "fit_algorithmic_tflops": round(M * fit_flops(N, R, 500) / (t500_ms * 1e-3) / 1e12, 3),
             "note": "the API default n_optim_nits=500 (ensembles/models.py:167), same 32 x 2000 batch, one fit batch"}
         wl.free()
+        extra.update(api_path(ctx, M, N, R, T))
+        extra["api_path_vs_resident_step"] = round(extra["api_path_ms_per_step"] / ms_per_step, 3)
+        fw = FieldWorkload(ctx, 32, 1728, 86, 8, T, "reduced")
+        c5 = fw.measure(3, 1)
+        fw.free()
+        fw = FieldWorkload(ctx, 32, 432, 86, 8, T, "full")
+        c5f = fw.measure(3, 1)
+        fw.free()
+        c5["full_export"] = {k: c5f[k] for k in ("value", "fits_per_step", "fit_kernel_ms", "roofline")}
+        c5["workload"] = ("BASELINE config 5, one GPU's share: 32 members x 1728 grid points (96x144 over 8 GPUs) of "
+                          "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
+        extra["config5"] = c5
         for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):
             w2 = Workload(ctx, M, N, R, T, kern, is32, 0, 1, None)
             el = w2.timed(3, 1)

@@ -151,6 +151,13 @@ int bayens_mvn_log_prob(bayens_ctx* ctx, int loc, int B, int N, int n_x, int sha
 int bayens_loglik_rows_basis(bayens_ctx* ctx, int loc, int B, int N, int R_obs, const double* ll_basis,
                              const double* logdet, const double* obs, double* ll_mean);
 
+/* the same for a FIELD of posteriors (BASELINE.json config 5: one GP per grid point and member):
+ * B = M * n_groups posteriors laid out [M][n_groups], posterior b is evaluated at the observations of its own grid
+ * point b % n_groups, obs [n_groups][R_obs][N]; ll_mean [B][N] is then the [M][n_groups * N] table that
+ * bayens_weights_normalise / bayens_barycentre take with P = n_groups * N. */
+int bayens_loglik_rows_basis_grouped(bayens_ctx* ctx, int loc, int B, int N, int R_obs, int n_groups,
+                                     const double* ll_basis, const double* logdet, const double* obs, double* ll_mean);
+
 /* same, dx.Normal branch (ensembles/weights.py:95-96): elementwise log N(obs; mu, scale) */
 int bayens_normal_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                               const double* mu, const double* scale, const double* obs, double* ll_mean);
