@@ -8,12 +8,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-BAYENS_PRINT_STAGES=1 timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_stage_profile.txt || exit 1
+BAYENS_PRINT_STAGES=1 timeout -k 10 500 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_stage_profile.txt || exit 1
+timeout -k 10 300 python3 bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err || exit 1
+timeout -k 10 300 python3 tools/small_phases.py > $OUT/${TAG}_small_phases.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1 || exit 2
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pf.log 2>&1 || exit 3
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pw.log 2>&1 || exit 4
-timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pm.log 2>&1 || exit 5
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_kt.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pf.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pw.log 2>&1 || exit 4
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pm.log 2>&1 || exit 5
 cd $R
 python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util.txt > /dev/null
 rm -rf $OUT/${TAG}_pm
@@ -23,4 +25,10 @@ python3 tools/rocpd_pmc.py $PF FETCH_SIZE $OUT/${TAG}_pmc_fetch_size.txt > /dev/
 python3 tools/rocpd_pmc.py $PW WRITE_SIZE $OUT/${TAG}_pmc_write_size.txt > /dev/null
 python3 tools/pmc_traffic.py $PF $PW $OUT/${TAG}_pmc_traffic.json > /dev/null
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw
+# config 5 (the fused small-member kernel): kernel trace of the same command as the bench line
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt5 -o kt5 -- python3 $R/bench.py --config c5 --no-cpu-baseline > $OUT/${TAG}_kt5.log 2>&1 || exit 6
+cd $R
+python3 tools/rocpd_stats.py $(find $OUT/${TAG}_kt5 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_c5.txt > /dev/null
+rm -rf $OUT/${TAG}_kt5
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
