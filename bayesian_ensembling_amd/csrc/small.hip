@@ -71,14 +71,20 @@ __device__ __forceinline__ void st_tile(double* t, const Lane& o, v4d a) {
   for (int r = 0; r < 4; ++r) t[o.cr[r]] = a[r];
 }
 // acc += sa * op(A) op(B), tiles in LDS; TA / TB: use the transposed tile
+// (two accumulator chains, q = 0, 1 and q = 2, 3: a dependent v_mfma_f64_16x16x4 waits ~20 cycles longer than the 64
+//  its predecessor occupies the pipe; with one wave per SIMD nobody else fills that gap)
 template <bool TA, bool TB>
 __device__ __forceinline__ v4d mma(v4d acc, const double* A, const double* B, const Lane& o, double sa = 1.0) {
+  double a[4], b[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double a = sa * A[TA ? o.cr[q] : o.rc[q]];
-    const double b = B[TB ? o.rc[q] : o.cr[q]];
-    acc = MFMA(a, b, acc);
-  }
+  for (int q = 0; q < 4; ++q) { a[q] = sa * A[TA ? o.cr[q] : o.rc[q]]; b[q] = B[TB ? o.rc[q] : o.cr[q]]; }
+  v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+  acc = MFMA(a[0], b[0], acc);
+  acc2 = MFMA(a[2], b[2], acc2);
+  acc = MFMA(a[1], b[1], acc);
+  acc2 = MFMA(a[3], b[3], acc2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
   return acc;
 }
 
@@ -90,17 +96,22 @@ __device__ __forceinline__ v4d acc_run(v4d acc, int k0, int k1, LoadA la, LoadB 
   double a[4], b[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { a[q] = la(k0, q); b[q] = lb(k0, q); }
+  v4d acc2 = {0.0, 0.0, 0.0, 0.0};           // second chain (q = 2, 3): see mma()
 #pragma unroll 1
   for (int k = k0; k < k1; ++k) {
     const int kn = k + 1 < k1 ? k + 1 : k;
     double an[4], bn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { an[q] = la(kn, q); bn[q] = lb(kn, q); }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc = MFMA(a[q], b[q], acc);
+    acc = MFMA(a[0], b[0], acc);
+    acc2 = MFMA(a[2], b[2], acc2);
+    acc = MFMA(a[1], b[1], acc);
+    acc2 = MFMA(a[3], b[3], acc2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
   return acc;
 }
 
@@ -189,11 +200,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const unsigned hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double((int)hi, (int)lo);
 }
+// 1/sqrt(d): v_rsq_f64 seed (relative error e0 ~ 2^-26) and ONE third-order correction y = y0 (1 + e/2 + 3 e^2/8),
+// e = 1 - d y0^2: the error drops to ~e0^3, full double precision, in four dependent operations (two Newton steps take six)
 __device__ __forceinline__ double rsqrt_refined(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  const double e = fma(-d * r, r, 1.0);
-  return fma(0.5 * r, e, r);
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y0), y0, 1.0);
+  return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
 __device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
   v4d acc, fac;
@@ -213,21 +225,20 @@ __device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivo
                  d31 = readlane_f64(v, 48 + 4 * s + 1), d22 = readlane_f64(v, 32 + 4 * s + 2), d32 = readlane_f64(v, 48 + 4 * s + 2),
                  d33 = readlane_f64(v, 48 + 4 * s + 3);
     const int pb = pivot_base + 4 * s;
-    double t = d00;
-    if (!(t > 0.0)) { bad = bad == 0 ? pb + 1 : bad; t = 1.0; }
-    const double r0 = rsqrt_refined(t);
+    // (a non-positive pivot is recorded, not replaced: the NaNs it produces stay inside this member, every later pivot
+    //  test fails too and the first one is what info[] reports - the test is then off the dependent chain)
+    const double t0 = d00;
+    const double r0 = rsqrt_refined(t0);
     const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
-    t = fma(-l10, l10, d11);
-    if (!(t > 0.0)) { bad = bad == 0 ? pb + 2 : bad; t = 1.0; }
-    const double r1 = rsqrt_refined(t);
+    const double t1 = fma(-l10, l10, d11);
+    const double r1 = rsqrt_refined(t1);
     const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
-    t = fma(-l21, l21, fma(-l20, l20, d22));
-    if (!(t > 0.0)) { bad = bad == 0 ? pb + 3 : bad; t = 1.0; }
-    const double r2 = rsqrt_refined(t);
+    const double t2 = fma(-l21, l21, fma(-l20, l20, d22));
+    const double r2 = rsqrt_refined(t2);
     const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
-    t = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    if (!(t > 0.0)) { bad = bad == 0 ? pb + 4 : bad; t = 1.0; }
-    const double r3 = rsqrt_refined(t);
+    const double t3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+    const double r3 = rsqrt_refined(t3);
+    if (bad == 0) bad = !(t0 > 0.0) ? pb + 1 : (!(t1 > 0.0) ? pb + 2 : (!(t2 > 0.0) ? pb + 3 : (!(t3 > 0.0) ? pb + 4 : 0)));
     // M4 = L4^-1 (lower): m_aa = r_a
     const double m10 = -l10 * r0 * r1;
     const double m21 = -l21 * r1 * r2;
@@ -268,8 +279,13 @@ __device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivo
 // hides the whole trailing update.
 // (not inlined: the factorisation keeps ~110 registers busy; as a function of its own it is compiled without the
 //  caller's register tiles in the way, which are saved and restored once per call instead of spilling all along)
-template <int NT, bool WITH_INV>
-__device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const Lane& o, int wave, int lane, int bad) {
+// `extra(k)`: work that only needs block row k of the finished factor (and of its inverse, WITH_INV).  Waves 1..7 run it
+// behind their share of the trailing update of step k, i.e. in the shadow of wave 0's serial factorisation of the next
+// diagonal tile; row NT-1 after the last panel.  (The callers accumulate L^T D L and C^-T C^-1 this way.)
+struct NoExtra { __device__ __forceinline__ void operator()(int) const {} };
+template <int NT, bool WITH_INV, class Extra = NoExtra>
+__device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const Lane& o, int wave, int lane, int bad,
+                                         Extra extra = Extra()) {
   // (LDS operands arrive as offsets into the workgroup's dynamic LDS block: pointers handed to a real function call
   //  would be generic pointers and every access a flat one)
   double* A = lds_base() + a_off;
@@ -335,9 +351,11 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
               st_tile(t, o, acc);
             }
       }
+      extra(k);
     }
     SYNC();
   }
+  if (wave != 0) extra(NT - 1);
   return bad;
 }
 
@@ -348,22 +366,30 @@ template <int NT>
 __device__ __forceinline__ void invert_in_place(int l_off, int d_off, const Lane& o, int wave) {
   double* Lb = lds_base() + l_off;
   const double* D = lds_base() + d_off;
+  constexpr int PER = (NT - 1 + NW - 1) / NW;         // tiles of one column per wave
 #pragma unroll 1
   for (int j = NT - 1; j >= 0; --j) {
-    const int i = j + 1 + wave;          // NT - 1 - j <= 5 tiles below the diagonal: one per wave
-    v4d x = {0.0, 0.0, 0.0, 0.0};
-    const bool has = i < NT;
-    if (has) {
-      v4d tt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-      for (int k = j + 1; k <= i; ++k) tt = mma<true, true>(tt, Lb + lt(k, j) * TS, Lb + lt(i, k) * TS, o);
-      const double* dj = D + j * TS;
+    v4d x[PER];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x = MFMA(-tt[q], dj[o.cr[q]], x);
+    for (int u = 0; u < PER; ++u) {
+      const int i = j + 1 + wave + u * NW;
+      x[u] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (i < NT) {
+        v4d tt = {0.0, 0.0, 0.0, 0.0};
+        tt = acc_run(tt, j + 1, i + 1, [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; },
+                     [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; });
+        const double* dj = D + j * TS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[u] = MFMA(-tt[q], dj[o.cr[q]], x[u]);
+      }
     }
     if (wave == NW - 1) st_tile(Lb + lt(j, j) * TS, o, ld_tile(D + j * TS, o));   // (the diagonal tile is not read above)
     SYNC();
-    if (has) st_tile(Lb + lt(i, j) * TS, o, x);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = j + 1 + wave + u * NW;
+      if (i < NT) st_tile(Lb + lt(i, j) * TS, o, x[u]);
+    }
     SYNC();
   }
 }
@@ -443,7 +469,7 @@ template <int NT>
 struct Layout {
   static constexpr int NTT = NT * (NT + 1) / 2;
   static constexpr int NP = 16 * NT;
-  static constexpr int TPW = (NTT + NW - 1) / NW;       // register tiles per wave
+  static constexpr int TPW = (NTT + NW - 2) / (NW - 1);  // register tiles per wave: dealt over waves 1..NW-1 (wave 0 runs the serial chains)
   static constexpr int LB = 0, CB = NTT * TS, WB = 2 * NTT * TS, DL = 3 * NTT * TS, DC = DL + NT * TS;
   static constexpr int VEC = DC + NT * TS;               // vectors of NP doubles
   static constexpr int NVEC = 10;
@@ -499,7 +525,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     v4d lam[TPW], gt[TPW];
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
-      const int p = wave + s * NW;
+      const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
       int i = 0, j = 0;
       unpack_lower(p < NTT ? p : 0, i, j);
 #pragma unroll
@@ -546,8 +572,8 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + (|m|^2 - N + 2 log det C + tr S) / 2
     // (L S L^T)_tt = sum_j (L S)_tj L_tj: wave i forms the tiles (i, j <= i) of L S and folds them against L.
     auto neg_elbo = [&](int slot) {
-      if (wave < NT) {
-        const int i = wave;
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower<NT>(Lb, mv, i, o);
         if (o.lk == 0) av[16 * i + o.lr] = s - yv[16 * i + o.lr];
         double fr[4] = {0.0, 0.0, 0.0, 0.0};
@@ -591,34 +617,64 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       refresh_hypers();
       kmat();                                                              // K0 + J I at the current hypers  (models.py:209)
       STAMP(1);
-      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);     // L
+      // L = chol(K0 + J I); G = L^T D L = sum_k (D^1/2 L)_k*^T (D^1/2 L)_k* is accumulated block row by block row behind
+      // the factorisation (registers gt[], tiles dealt over waves 1..7)
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) gt[s] = v4d{0.0, 0.0, 0.0, 0.0};
+      auto g_rows = [&](int k) {
+#pragma unroll
+        for (int s = 0; s < TPW; ++s) {
+          const int p = (wave - 1) + s * (NW - 1);
+          int i = 0, j = 0;
+          unpack_lower(p < NTT ? p : 0, i, j);
+          if (p < NTT && i <= k) {
+            const double* ta = Lb + lt(k, i) * TS;
+            const double* tb = Lb + lt(k, j) * TS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double sc = rs[16 * k + 4 * q + o.lk];
+              gt[s] = MFMA(ta[o.cr[q]] * sc, tb[o.cr[q]] * sc, gt[s]);
+            }
+          }
+        }
+      };
+      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, g_rows);
       if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
       STAMP(2);
-      // ---- natural-gradient step: G = L^T D L, Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
+      // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
-          v4d acc = {0.0, 0.0, 0.0, 0.0};
-          acc = acc_run(acc, i, NT,
-                        [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]] * rs[16 * k + 4 * q + o.lk]; },
-                        [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]] * rs[16 * k + 4 * q + o.lk]; });
-          gt[s] = acc;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            lam[s][r] = (1.0 - g.gamma) * lam[s][r] + g.gamma * (acc[r] + ((i == j && o.lk + 4 * r == o.lr) ? 1.0 : 0.0));
+            lam[s][r] = (1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.lk + 4 * r == o.lr) ? 1.0 : 0.0));
           st_tile(Cb + p * TS, o, lam[s]);
         }
       }
-      if (wave < NT) {
-        const double s = mv_lower_t<NT>(Lb, yd, wave, o);
-        if (o.lk == 0) th[16 * wave + o.lr] = (1.0 - g.gamma) * th[16 * wave + o.lr] + g.gamma * s;
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) {
+        const double s = mv_lower_t<NT>(Lb, yd, i, o);
+        if (o.lk == 0) th[16 * i + o.lr] = (1.0 - g.gamma) * th[16 * i + o.lr] + g.gamma * s;
       }
       SYNC();
       STAMP(3);
-      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::WB, o, wave, lane, bad);  // C = chol(Lam) in Cb, C^-1 in Wb
+      // C = chol(Lam) in Cb, C^-1 in Wb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
+      v4d st[TPW];
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) st[s] = v4d{0.0, 0.0, 0.0, 0.0};
+      auto s_rows = [&](int k) {
+#pragma unroll
+        for (int s = 0; s < TPW; ++s) {
+          const int p = (wave - 1) + s * (NW - 1);
+          int i = 0, j = 0;
+          unpack_lower(p < NTT ? p : 0, i, j);
+          if (p < NTT && i <= k) st[s] = mma<true, false>(st[s], Wb + lt(k, i) * TS, Wb + lt(k, j) * TS, o);
+        }
+      };
+      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::WB, o, wave, lane, bad, s_rows);
       STAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
@@ -632,52 +688,43 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           misc[11] = tot;
         }
       }
-      // ---- S = C^-T C^-1 (registers), then over C in Cb
-      v4d st[TPW];
-#pragma unroll
-      for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
-        st[s] = v4d{0.0, 0.0, 0.0, 0.0};
-        if (p < NTT) {
-          int i, j;
-          unpack_lower(p, i, j);
-          st[s] = acc_run(st[s], i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
-        }
-      }
+      // ---- S over C in Cb, G over C^-1 in Wb
       SYNC();
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         if (p < NTT) { st_tile(Cb + p * TS, o, st[s]); st_tile(Wb + p * TS, o, gt[s]); }     // S -> Cb, G -> Wb
       }
       SYNC();
       STAMP(5);
       // ---- m = S theta1 ; a = L m - y ; u = L^T D a
-      if (wave < NT) {
-        const double s = mv_sym<NT>(Cb, th, wave, o);
-        if (o.lk == 0) mv[16 * wave + o.lr] = s;
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) {
+        const double s = mv_sym<NT>(Cb, th, i, o);
+        if (o.lk == 0) mv[16 * i + o.lr] = s;
       }
       SYNC();
-      if (wave < NT) {
-        const double s = mv_lower<NT>(Lb, mv, wave, o);
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) {
+        const double s = mv_lower<NT>(Lb, mv, i, o);
         if (o.lk == 0) {
-          const int t = 16 * wave + o.lr;
+          const int t = 16 * i + o.lr;
           const double a = s - yv[t];
           av[t] = a; wv[t] = a * dv[t];
         }
       }
       SYNC();
-      if (wave < NT) {
-        const double s = mv_lower_t<NT>(Lb, wv, wave, o);
-        if (o.lk == 0) uv[16 * wave + o.lr] = s;
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) {
+        const double s = mv_lower_t<NT>(Lb, wv, i, o);
+        if (o.lk == 0) uv[16 * i + o.lr] = s;
       }
       SYNC();
       STAMP(6);
       // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal   (G in Wb, S in Cb, both symmetric from lower tiles)
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
@@ -698,7 +745,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       SYNC();
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         if (p < NTT) st_tile(Wb + p * TS, o, st[s]);                        // Phi -> Wb
       }
       STAMP(7);
@@ -707,7 +754,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       // ---- W = Phi L^-1 (lower) -> Wb
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         st[s] = v4d{0.0, 0.0, 0.0, 0.0};
         if (p < NTT) {
           int i, j;
@@ -719,7 +766,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       SYNC();
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
-        const int p = wave + s * NW;
+        const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
         if (p < NTT) st_tile(Wb + p * TS, o, st[s]);
       }
       SYNC();
@@ -786,24 +833,30 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     invert_in_place<NT>(Y::WB, Y::DL, o, wave);                             // Wb = L^-1, Lb = L, Cb = S
     STAMP(13);
     // mu = A^T m with A^T = K0 L^-T = L - J L^-T
-    if (wave < NT) {
-      const double s1 = mv_lower<NT>(Lb, mv, wave, o);
-      const double s2 = mv_lower_t<NT>(Wb, mv, wave, o);
-      if (o.lk == 0) av[16 * wave + o.lr] = s1 - J * s2;                    // av = mu (padded part 0)
+#pragma unroll 1
+    for (int i = wave; i < NT; i += NW) {
+      const double s1 = mv_lower<NT>(Lb, mv, i, o);
+      const double s2 = mv_lower_t<NT>(Wb, mv, i, o);
+      if (o.lk == 0) av[16 * i + o.lr] = s1 - J * s2;                       // av = mu (padded part 0)
     }
     // (av is read after the barriers of the covariance loop)
     STAMP(14);
     // cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T S) A, one tile row at a time.  E_i* = A^T_i* S is staged in LDS,
     // alternately in DCi and DLi (both dead here), so that the tile row i of cov and the staging of row i+1 share a
     // phase: E tile l of the next row is dealt to wave NW-1-l, cov tile (i, j) to wave j.
-    auto at_a = [&](int i, int k, int q) -> double {       // A-operand element of A^T(i, k): [lr][4q + lk]
-      if (k < i) return Lb[lt(i, k) * TS + o.rc[q]];
-      if (k > i) return -J * Wb[lt(k, i) * TS + o.cr[q]];
-      return Lb[lt(i, i) * TS + o.rc[q]] - J * Wb[lt(i, i) * TS + o.cr[q]];
+    // A-operand element [lr][4q + lk] of A^T(i, k) = L_ik (k < i), -J (L^-1)_ki^T (k > i), L_ii - J (L^-1)_ii^T (k = i),
+    // without branches: one read from the tile that applies (L normal or L^-1 transposed) plus the diagonal L^-1 tile
+    // scaled by -J or 0, so that the operand loads of the next step can be issued ahead
+    auto at_a = [&](int i, int k, int q) -> double {
+      const bool low = k <= i;
+      const double* t1 = low ? Lb + lt(i, k) * TS : Wb + lt(k, i) * TS;
+      const double v1 = t1[low ? o.rc[q] : o.cr[q]];
+      const double v2 = Wb[lt(i, i) * TS + o.cr[q]];
+      return fma(k == i ? -J : 0.0, v2, (low ? 1.0 : -J) * v1);
     };
     auto stage_row = [&](int i, double* Eb) {
-      const int l = NW - 1 - wave;
-      if (l < NT) {
+#pragma unroll 1
+      for (int l = NW - 1 - wave; l < NT; l += NW) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         acc = acc_run(acc, 0, NT, [&](int k, int q) { return at_a(i, k, q); },
                       [&](int k, int q) { return k >= l ? Cb[lt(k, l) * TS + o.cr[q]] : Cb[lt(l, k) * TS + o.rc[q]]; });
@@ -812,13 +865,16 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     };
     stage_row(0, DCi);
     SYNC();
-    v4d covt[NT];
+    constexpr int CPW = (NT + NW - 1) / NW;        // cov tiles of one tile row per wave
+    v4d covt[NT][CPW];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       double* Eb = (i & 1) ? DLi : DCi;
-      covt[i] = v4d{0.0, 0.0, 0.0, 0.0};
-      if (wave <= i) {
-        const int j = wave;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) {
+      const int j = wave + u * NW;
+      covt[i][u] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (j <= i) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
                       [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
@@ -841,7 +897,8 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
             if (g.var && row == col) g.var[(long)b * N + row] = acc[r];
           }
         }
-        covt[i] = acc;
+        covt[i][u] = acc;
+      }
       }
       if (i + 1 < NT) stage_row(i + 1, (i & 1) ? DCi : DLi);
       SYNC();
@@ -851,9 +908,11 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (wave <= i) {
-        const int j = wave;
-        v4d t = covt[i];
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) {
+      const int j = wave + u * NW;
+      if (j <= i) {
+        v4d t = covt[i][u];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
@@ -865,6 +924,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           }
         }
         st_tile(Lb + lt(i, j) * TS, o, t);
+      }
       }
     }
     SYNC();

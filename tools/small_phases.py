@@ -38,3 +38,4 @@ for k, nme in enumerate(names):
 print("iteration total", tot_it, "predict total", st[17] - st[11])
 
 
+
