@@ -10,9 +10,11 @@
 //     Cholesky), lower triangles stored tile-packed: NT(NT+1)/2 tiles of 2 KB; THREE such buffers (Lb, Cb, Wb) plus
 //     the inverted diagonal tiles and the vectors fill the 160 KB of LDS; Lam and G live in registers (accumulator
 //     layout, tiles dealt over the 8 waves);
-//   * triangular solves become products with EXPLICIT triangular inverses (the inverse rides along with the blocked
-//     factorisation as a forward substitution, or is formed in place column by column) - every N^3 term is then a
-//     tile product on the fp64 matrix cores with no serial dependency beyond the 16x16 diagonal factorisations;
+//   * triangular solves become products with EXPLICIT triangular inverses: L^-1 and C^-1 ride along with their blocked
+//     factorisations as block forward substitutions whose products run in the shadow of the serial diagonal tiles, as
+//     do G = L^T D L and S = C^-T C^-1 (accumulated block row by block row).  Since u = L^T D (L m - y) = G m - L^T (y/nu),
+//     L is dead once theta1 is updated and C^-1 takes its buffer.  Every N^3 term is a tile product on the fp64 matrix
+//     cores with no serial dependency beyond the 16x16 diagonal factorisations;
 //   * tiles are XOR-swizzled (column ^ 2*(row>>1)): A-operand reads, B-operand reads and accumulator stores of
 //     v_mfma_f64_16x16x4_f64 are all bank-conflict free without padding.
 // HBM traffic per fit is the inputs and the exported posterior only (6.9 KB in, 59.9 KB out with the
@@ -359,41 +361,6 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
   return bad;
 }
 
-// ---- Lb holds a lower factor L with the inverses D of its diagonal tiles; on return it holds L^-1.  Columns from the
-// last to the first: X_ij = -(sum_{j<k<=i} X_ik L_kj) inv_jj reads column j of L and finished tiles only.  The sum is
-// accumulated TRANSPOSED (L_kj^T X_ik^T), so that the accumulator registers are the A operand of the product with inv_jj.
-template <int NT>
-__device__ __forceinline__ void invert_in_place(int l_off, int d_off, const Lane& o, int wave) {
-  double* Lb = lds_base() + l_off;
-  const double* D = lds_base() + d_off;
-  constexpr int PER = (NT - 1 + NW - 1) / NW;         // tiles of one column per wave
-#pragma unroll 1
-  for (int j = NT - 1; j >= 0; --j) {
-    v4d x[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int i = j + 1 + wave + u * NW;
-      x[u] = v4d{0.0, 0.0, 0.0, 0.0};
-      if (i < NT) {
-        v4d tt = {0.0, 0.0, 0.0, 0.0};
-        tt = acc_run(tt, j + 1, i + 1, [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; },
-                     [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; });
-        const double* dj = D + j * TS;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[u] = MFMA(-tt[q], dj[o.cr[q]], x[u]);
-      }
-    }
-    if (wave == NW - 1) st_tile(Lb + lt(j, j) * TS, o, ld_tile(D + j * TS, o));   // (the diagonal tile is not read above)
-    SYNC();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int i = j + 1 + wave + u * NW;
-      if (i < NT) st_tile(Lb + lt(i, j) * TS, o, x[u]);
-    }
-    SYNC();
-  }
-}
-
 // ---- matrix-vector products on tile-packed buffers: wave w < NT owns the 16 outputs of tile row / column w, lane
 // (lr, lk) walks the columns == lk mod 4, the four partial sums meet through two shuffles.  Valid in lanes lk == 0.
 template <int NT>
@@ -493,9 +460,9 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
   double* yd = rs + NP;                 // y / nu
   double* th = yd + NP;                 // theta1
   double* mv = th + NP;                 // m
-  double* av = mv + NP;                 // a = L m - y (later: the posterior mean)
-  double* wv = av + NP;                 // a / nu
-  double* uv = wv + NP;                 // u = L^T D a
+  double* av = mv + NP;                 // loss samples: L m - y; prediction: the posterior mean
+  double* wv = av + NP;                 // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
+  double* uv = wv + NP;                 // u = L^T D (L m - y) = G m - L^T (y / nu)
   double* ssq = uv + NP;                // |x_i|^2
   double* misc = lds + Y::MISC;         // [0..7] optimiser state, [8] variance, [9] lengthscale, [10] 1/ls^2, [16..31] reductions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -638,7 +605,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           }
         }
       };
-      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, g_rows);
+      bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, g_rows);      // L in Lb, L^-1 rides along into Wb
       if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
       STAMP(2);
       // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
@@ -657,11 +624,14 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower_t<NT>(Lb, yd, i, o);
-        if (o.lk == 0) th[16 * i + o.lr] = (1.0 - g.gamma) * th[16 * i + o.lr] + g.gamma * s;
+        if (o.lk == 0) {
+          th[16 * i + o.lr] = (1.0 - g.gamma) * th[16 * i + o.lr] + g.gamma * s;
+          wv[16 * i + o.lr] = s;               // L^T (y / nu): u = L^T D (L m - y) = G m - L^T (y / nu) needs it, and L dies here
+        }
       }
       SYNC();
       STAMP(3);
-      // C = chol(Lam) in Cb, C^-1 in Wb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
+      // C = chol(Lam) in Cb, C^-1 in Lb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
       v4d st[TPW];
 #pragma unroll
       for (int s = 0; s < TPW; ++s) st[s] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -671,10 +641,10 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           const int p = (wave - 1) + s * (NW - 1);
           int i = 0, j = 0;
           unpack_lower(p < NTT ? p : 0, i, j);
-          if (p < NTT && i <= k) st[s] = mma<true, false>(st[s], Wb + lt(k, i) * TS, Wb + lt(k, j) * TS, o);
+          if (p < NTT && i <= k) st[s] = mma<true, false>(st[s], Lb + lt(k, i) * TS, Lb + lt(k, j) * TS, o);
         }
       };
-      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::WB, o, wave, lane, bad, s_rows);
+      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::LB, o, wave, lane, bad, s_rows);      // (L is dead: C^-1 takes its buffer)
       STAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
@@ -688,16 +658,16 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           misc[11] = tot;
         }
       }
-      // ---- S over C in Cb, G over C^-1 in Wb
+      // ---- S over C in Cb, G over C^-1 in Lb
       SYNC();
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
-        if (p < NTT) { st_tile(Cb + p * TS, o, st[s]); st_tile(Wb + p * TS, o, gt[s]); }     // S -> Cb, G -> Wb
+        if (p < NTT) { st_tile(Cb + p * TS, o, st[s]); st_tile(Lb + p * TS, o, gt[s]); }     // S -> Cb, G -> Lb
       }
       SYNC();
       STAMP(5);
-      // ---- m = S theta1 ; a = L m - y ; u = L^T D a
+      // ---- m = S theta1 ; u = L^T D (L m - y) = G m - L^T (y / nu)
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_sym<NT>(Cb, th, i, o);
@@ -706,22 +676,12 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       SYNC();
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
-        const double s = mv_lower<NT>(Lb, mv, i, o);
-        if (o.lk == 0) {
-          const int t = 16 * i + o.lr;
-          const double a = s - yv[t];
-          av[t] = a; wv[t] = a * dv[t];
-        }
-      }
-      SYNC();
-#pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mv_lower_t<NT>(Lb, wv, i, o);
-        if (o.lk == 0) uv[16 * i + o.lr] = s;
+        const double s = mv_sym<NT>(Lb, mv, i, o);
+        if (o.lk == 0) uv[16 * i + o.lr] = s - wv[16 * i + o.lr];
       }
       SYNC();
       STAMP(6);
-      // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal   (G in Wb, S in Cb, both symmetric from lower tiles)
+      // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal   (G in Lb, S in Cb, both symmetric from lower tiles)
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
@@ -730,7 +690,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           unpack_lower(p, i, j);
           v4d acc = {0.0, 0.0, 0.0, 0.0};
           acc = acc_run(acc, 0, NT,
-                        [&](int k, int q) { return k <= i ? Wb[lt(i, k) * TS + o.rc[q]] : Wb[lt(k, i) * TS + o.cr[q]]; },
+                        [&](int k, int q) { return k <= i ? Lb[lt(i, k) * TS + o.rc[q]] : Lb[lt(k, i) * TS + o.cr[q]]; },
                         [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -746,12 +706,12 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
-        if (p < NTT) st_tile(Wb + p * TS, o, st[s]);                        // Phi -> Wb
+        if (p < NTT) st_tile(Lb + p * TS, o, st[s]);                        // Phi -> Lb (over G)
       }
+      SYNC();
       STAMP(7);
-      invert_in_place<NT>(Y::LB, Y::DL, o, wave);                          // Lb = L^-1   (its first barrier publishes Phi)
       STAMP(8);
-      // ---- W = Phi L^-1 (lower) -> Wb
+      // ---- W = Phi L^-1 (lower; L^-1 in Wb since the factorisation) -> Lb
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
@@ -759,19 +719,19 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
-          st[s] = acc_run(st[s], j, i + 1, [&](int k, int q) { return Wb[lt(i, k) * TS + o.rc[q]]; },
-                          [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
+          st[s] = acc_run(st[s], j, i + 1, [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; },
+                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
         }
       }
       SYNC();
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
-        if (p < NTT) st_tile(Wb + p * TS, o, st[s]);
+        if (p < NTT) st_tile(Lb + p * TS, o, st[s]);
       }
       SYNC();
       STAMP(9);
-      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric, so
+      // ---- Kbar = L^-T W (L^-1 in Wb, W in Lb) ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric, so
       // the tiles (i, j) and (j, i) of Kbar meet the same kernel values: Kbar_ij and Kbar_ji^T = sum_k W_ki^T Linv_kj
       // are accumulated together and the kernel function is evaluated once per unordered pair.
       {
@@ -782,11 +742,11 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           int i, j;
           unpack_lower(p, i, j);
           v4d acc = {0.0, 0.0, 0.0, 0.0};
-          acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
-                        [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+          acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                        [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
           if (i != j)
-            acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                          [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
+            acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
           const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -825,12 +785,10 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     STAMP(11);
     refresh_hypers();
     kmat();
-    bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);
+    bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad);       // Lb = L, Wb = L^-1 (riding along), Cb = S
+    SYNC();
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     STAMP(12);
-    for (int p = wave; p < NTT; p += NW) st_tile(Wb + p * TS, o, ld_tile(Lb + p * TS, o));
-    SYNC();
-    invert_in_place<NT>(Y::WB, Y::DL, o, wave);                             // Wb = L^-1, Lb = L, Cb = S
     STAMP(13);
     // mu = A^T m with A^T = K0 L^-T = L - J L^-T
 #pragma unroll 1

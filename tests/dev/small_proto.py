@@ -157,8 +157,8 @@ def fit(X, y_in, nu_in, T, kernel=0, gamma=0.5, lr=0.01, jitter=1e-6):
     for it in range(T):
         var, ls = go.softplus(u[0]), go.softplus(u[1])
         K0, dK = kmat_tiles(Lb, X, N, var, ls, kernel, jitter)             # P1
-        potrf(Lb, DL)                                                      # P2
-        G = Buf(NT)                                                        # P3 (registers)
+        potrf(Lb, DL, X=Wb)                                                # P2: L in Lb, L^-1 rides along into Wb
+        G = Buf(NT)                                                        # P3 (registers; accumulated behind P2)
         for i in range(NT):
             for j in range(i + 1):
                 acc = np.zeros((16, 16))
@@ -168,49 +168,49 @@ def fit(X, y_in, nu_in, T, kernel=0, gamma=0.5, lr=0.01, jitter=1e-6):
                 G[i, j] = acc
                 lam[i, j] = (1 - gamma) * lam[i, j] + gamma * ((np.eye(16) if i == j else 0) + acc)
                 Cb[i, j] = lam[i, j].copy()
-        th = (1 - gamma) * th + gamma * matvec_lower(Lb, y / nu, trans=True)
-        potrf(Cb, DC, X=Wb)                                                # P4: C in Cb, Cinv in Wb
-        S = Buf(NT)                                                        # P5 (registers, then -> Cb)
+        ly = matvec_lower(Lb, y / nu, trans=True)                          # L^T (y / nu): kept, u needs it
+        th = (1 - gamma) * th + gamma * ly
+        Lb.t[:] = np.nan                                                   # L is dead from here on
+        potrf(Cb, DC, X=Lb)                                                # P4: C in Cb, C^-1 rides along into Lb
+        S = Buf(NT)                                                        # P5 (registers, accumulated behind P4)
         for i in range(NT):
             for j in range(i + 1):
                 acc = np.zeros((16, 16))
                 for k in range(i, NT):
-                    acc += Wb[k, i].T @ Wb[k, j]
+                    acc += Lb[k, i].T @ Lb[k, j]
                 S[i, j] = acc
         Cb.t[:] = S.t
         have_S = True
+        Lb.t[:] = G.t                                                      # G -> Lb (C^-1 dead)
         m = matvec_sym(Cb, th)                                             # P6
-        a = matvec_lower(Lb, m) - y
-        uvec = matvec_lower(Lb, a / nu, trans=True)
-        Wb.t[:] = G.t                                                      # P7: G -> Wb ; GS lower ; Phi -> Wb
-        Phi = Buf(NT)
+        uvec = matvec_sym(Lb, m) - ly                                      # u = L^T D (L m - y) = G m - L^T (y / nu)
+        Phi = Buf(NT)                                                      # P7
         for i in range(NT):
             for j in range(i + 1):
                 acc = np.zeros((16, 16))
                 for k in range(NT):
-                    acc += Wb.sym(i, k) @ Cb.sym(k, j)
+                    acc += Lb.sym(i, k) @ Cb.sym(k, j)
                 r0, c0 = 16 * i, 16 * j
                 v = np.outer(uvec[r0:r0 + 16], m[c0:c0 + 16]) + acc
                 if i == j:
                     v = np.tril(v)
                     v[np.diag_indices(16)] *= 0.5
                 Phi[i, j] = v
-        Wb.t[:] = Phi.t
-        invert_in_place(Lb, DL)                                            # P8: Lb = Linv
-        Wn = Buf(NT)                                                       # P9
+        Lb.t[:] = Phi.t                                                    # Phi -> Lb
+        Wn = Buf(NT)                                                       # P9: W = Phi Linv (Linv in Wb)
         for i in range(NT):
             for j in range(i + 1):
                 acc = np.zeros((16, 16))
                 for k in range(j, i + 1):
-                    acc += Wb[i, k] @ Lb[k, j]
+                    acc += Lb[i, k] @ Wb[k, j]
                 Wn[i, j] = acc
-        Wb.t[:] = Wn.t
+        Lb.t[:] = Wn.t                                                     # W -> Lb
         gv = gl = 0.0                                                      # P10
         for i in range(NT):
             for j in range(NT):
                 acc = np.zeros((16, 16))
                 for k in range(max(i, j), NT):
-                    acc += Lb[k, i].T @ Wb[k, j]
+                    acc += Wb[k, i].T @ Lb[k, j]                           # Kbar = Linv^T W
                 rr = np.arange(16 * i, 16 * i + 16)[:, None]
                 cc = np.arange(16 * j, 16 * j + 16)[None, :]
                 msk = (rr < N) & (cc < N)
@@ -229,9 +229,7 @@ def fit(X, y_in, nu_in, T, kernel=0, gamma=0.5, lr=0.01, jitter=1e-6):
             for j in range(i + 1):
                 Cb[i, j] = np.eye(16) if i == j else np.zeros((16, 16))
     kmat_tiles(Lb, X, N, var, ls, kernel, jitter)
-    potrf(Lb, DL)
-    Wb.t[:] = Lb.t
-    invert_in_place(Wb, DL)                                                # Wb = Linv
+    potrf(Lb, DL, X=Wb)                                                    # Lb = L, Wb = Linv (riding along)
 
     def At(i, k):
         if k < i:

@@ -26,8 +26,8 @@ ctx.small_stamps(True)
 ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, 2, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
 st = ctx.small_stamps(True, read=True).astype(np.int64)
 ctx.small_stamps(False)
-names = ["hypers+kmat", "potrf L", "G, Lam, theta1", "potrf+inv C", "S", "m, a, u", "G S -> Phi", "invert L", "W = Phi Linv", "Kbar, grad, Adam",
-         "(to predict)", "P: kmat+potrf", "P: copy+invert", "P: mu", "P: cov rows", "P: bordered", "P: potrf cov", "P: outputs"]
+names = ["hypers+kmat", "potrf L (+L^-1, G)", "Lam, theta1", "potrf C (+C^-1, S)", "S, G -> LDS", "m, u", "G S -> Phi", "-", "W = Phi Linv", "Kbar, grad, Adam",
+         "(to predict)", "P: kmat+potrf (+L^-1)", "-", "P: mu", "P: cov rows", "P: potrf cov", "P: outputs", "-"]
 d = np.diff(st[:18])
 clk = 100e6   # s_memtime / readcyclecounter ticks at 100 MHz on gfx950? reported in ticks; print raw and the share
 tot_it = st[10] - st[0]
