@@ -113,6 +113,7 @@ def load():
     lib.bayens_bench_mfma_lds.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_small_stamps.argtypes = [_vp, C.c_int, _vp]
+    lib.bayens_bench_diag16.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     _lib = lib
     return lib
@@ -639,6 +640,11 @@ class Context:
         us = C.c_double()
         self._check(self.lib.bayens_bench_potrf(self.h, nb, n, reps, C.byref(us)))
         return us.value
+
+    def bench_diag16(self, variant=0, waves=1, reps=200):
+        cyc = C.c_double()
+        self._check(self.lib.bayens_bench_diag16(self.h, variant, waves, reps, C.byref(cyc)))
+        return cyc.value
 
     def small_stamps(self, enable=True, read=False):
         """Phase stamps of the fused small-member kernel (diagnostic); returns 32 uint64 when read=True."""

@@ -1151,6 +1151,17 @@ int bayens_comm_max(bayens_ctx* c, double* value) {
   });
 }
 
+int bayens_bench_diag16(bayens_ctx* c, int variant, int waves, int reps, double* cycles) {
+  return guarded(c, [&]() {
+    if (waves < 1 || waves > 16 || reps < 1 || !cycles) return fail(c, BAYENS_E_ARG, "bench_diag16: bad argument");
+    double* d = c->small_scratch(4);
+    smalln::diag_bench(c->stream, variant, waves, reps, d);
+    BAYENS_HIP(hipMemcpyAsync(cycles, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  });
+}
+
 int bayens_small_stamps(bayens_ctx* c, int enable, unsigned long long* stamps32) {
   return guarded(c, [&]() {
     if (enable && !c->small_stamps) {

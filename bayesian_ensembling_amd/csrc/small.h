@@ -30,6 +30,8 @@ struct SmallArgs {
 bool small_fit_supported(int N, int R);
 // queues the fit of all B members on `stream` (grid = resident workgroups, members dealt round-robin)
 void small_fit(hipStream_t stream, const SmallArgs& args, int n_cus);
+// diagnostic micro-benchmark of the 16x16 diagonal factorisation and of the dependent chains it consists of
+void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* out_dev);
 
 }  // namespace smalln
 }  // namespace bayens

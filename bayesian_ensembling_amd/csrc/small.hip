@@ -90,27 +90,33 @@ __device__ __forceinline__ v4d mma(v4d acc, const double* A, const double* B, co
   return acc;
 }
 
-// acc += sum_{k0 <= k < k1} A_k B_k with the operands of step k+1 requested before the MFMAs of step k are issued:
-// la(k, q) / lb(k, q) return this lane's A / B operand of MFMA q of step k (LDS reads)
+// acc += sum_{k0 <= k < k1} A_k B_k.  la(k, q) / lb(k, q) return this lane's A / B operand of MFMA q of step k (LDS
+// reads).  Two steps per trip: the sixteen operand reads of a pair of steps are requested together and their eight
+// MFMAs run as two accumulator chains (a dependent v_mfma_f64_16x16x4 waits 78 cycles, its predecessor holds the pipe
+// for 64), so a trip has one exposed LDS latency for 512 cycles of matrix-pipe work.
 template <class LoadA, class LoadB>
 __device__ __forceinline__ v4d acc_run(v4d acc, int k0, int k1, LoadA la, LoadB lb) {
-  if (k0 >= k1) return acc;
-  double a[4], b[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { a[q] = la(k0, q); b[q] = lb(k0, q); }
-  v4d acc2 = {0.0, 0.0, 0.0, 0.0};           // second chain (q = 2, 3): see mma()
+  v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+  int k = k0;
 #pragma unroll 1
-  for (int k = k0; k < k1; ++k) {
-    const int kn = k + 1 < k1 ? k + 1 : k;
-    double an[4], bn[4];
+  for (; k + 1 < k1; k += 2) {
+    double a[8], b[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { an[q] = la(kn, q); bn[q] = lb(kn, q); }
+    for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); a[4 + q] = la(k + 1, q); b[4 + q] = lb(k + 1, q); }
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      acc = MFMA(a[q], b[q], acc);
+      acc2 = MFMA(a[q + 1], b[q + 1], acc2);
+    }
+  }
+  if (k < k1) {
+    double a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); }
     acc = MFMA(a[0], b[0], acc);
-    acc2 = MFMA(a[2], b[2], acc2);
-    acc = MFMA(a[1], b[1], acc);
+    acc2 = MFMA(a[1], b[1], acc2);
+    acc = MFMA(a[2], b[2], acc);
     acc2 = MFMA(a[3], b[3], acc2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
@@ -209,15 +215,32 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   const double e = fma(-(d * y0), y0, 1.0);
   return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
-__device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
-  v4d acc, fac;
+// symmetric image of a diagonal tile (only its lower triangle is trusted) in accumulator layout
+__device__ __forceinline__ v4d ld_tile_sym(const double* T, const Lane& o) {
+  v4d acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = o.lk + 4 * r, col = o.lr;
-    acc[r] = T[row >= col ? swz(row, col) : swz(col, row)];      // symmetric image from the lower triangle
-    fac[r] = row == col ? 1.0 : 0.0;
+    acc[r] = T[row >= col ? swz(row, col) : swz(col, row)];
   }
+  return acc;
+}
+// acc: the symmetric tile (accumulator layout, registers); the factor goes to T, its inverse to Dk
+__device__ __forceinline__ void diag16(v4d acc, double* T, double* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
+  __builtin_amdgcn_s_setprio(3);        // the serial chain of the workgroup: win issue arbitration on its SIMD
+  v4d fac;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) fac[r] = o.lk + 4 * r == o.lr ? 1.0 : 0.0;
   double lcol[4], xrow[4];
+  // sel[e] = 1 in the one lane (lr < 4, lk <= lr) that holds entry e of the lower 4x4 block, in the order
+  // (0,0) (1,1) (1,0) (2,2) (2,1) (2,0) (3,3) (3,2) (3,1) (3,0)
+  double sel[10];
+  {
+    const int code = o.lr < 4 ? 4 * o.lr + o.lk : -1;
+    const int at[10] = {0, 5, 4, 10, 9, 8, 15, 14, 13, 12};
+#pragma unroll
+    for (int e = 0; e < 10; ++e) sel[e] = code == at[e] ? 1.0 : 0.0;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const double v = acc[s];
@@ -248,12 +271,11 @@ __device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivo
     const double m32 = -l32 * r2 * r3;
     const double m31 = -fma(l32, m21, l31 * r1) * r3;
     const double m30 = -fma(l32, m20, fma(l31, m10, l30 * r0)) * r3;
-    // this lane's entry of the zero-padded 16x4 A operand: M4[lr][lk] for lr < 4
-    double ia = 0.0;
-    if (o.lr == 0) ia = o.lk == 0 ? r0 : 0.0;
-    else if (o.lr == 1) ia = o.lk == 0 ? m10 : (o.lk == 1 ? r1 : 0.0);
-    else if (o.lr == 2) ia = o.lk == 0 ? m20 : (o.lk == 1 ? m21 : (o.lk == 2 ? r2 : 0.0));
-    else if (o.lr == 3) ia = o.lk == 0 ? m30 : (o.lk == 1 ? m31 : (o.lk == 2 ? m32 : r3));
+    // this lane's entry of the zero-padded 16x4 A operand: M4[lr][lk] for lr < 4, picked WITHOUT branches: the ten
+    // candidates are multiplied by 0/1 lane constants (a select tree compiles to ten divergent branches, ~3x the cost
+    // of the arithmetic of the whole sub-step)
+    const double ia = fma(sel[9], m30, fma(sel[8], m31, fma(sel[7], m32, fma(sel[6], r3,
+                      fma(sel[5], m20, fma(sel[4], m21, fma(sel[3], r2, fma(sel[2], m10, fma(sel[1], r1, sel[0] * r0)))))))));
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
     const v4d pt = MFMA(ia, v, zero);                          // register 0 at lane (lr, lk): P[lr][lk] = L[lr][4s+lk]
     const double pm = o.lr >= 4 * s + o.lk ? pt[0] : 0.0;      // rows above the diagonal (and finished rows) are zero
@@ -271,6 +293,7 @@ __device__ __forceinline__ void diag16(double* T, double* Dk, int lane, int pivo
     T[o.rc[s]] = lcol[s];
     Dk[o.cr[s]] = xrow[s];
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- blocked Cholesky of the lower-packed buffer A in place; D[k] = inverse of diagonal tile k.  WITH_INV: the
@@ -293,7 +316,7 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
   double* A = lds_base() + a_off;
   double* D = lds_base() + d_off;
   double* Xb = lds_base() + x_off;
-  if (wave == 0) diag16(A, D, lane, 0, bad, o);
+  if (wave == 0) diag16(ld_tile_sym(A, o), A, D, lane, 0, bad, o);
   SYNC();
 #pragma unroll 1
   for (int k = 0; k < NT; ++k) {
@@ -322,10 +345,9 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
     if (below == 0) break;
     if (wave == 0) {                                      // look-ahead: next diagonal tile first, then its factorisation
       double* t = A + lt(k + 1, k + 1) * TS;
-      v4d acc = ld_tile(t, o);
+      v4d acc = ld_tile_sym(t, o);                        // (the updated tile goes straight into the factorisation)
       acc = mma<false, true>(acc, A + lt(k + 1, k) * TS, A + lt(k + 1, k) * TS, o, -1.0);
-      st_tile(t, o, acc);
-      diag16(t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
+      diag16(acc, t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
     } else {
       int p = 0;
 #pragma unroll 1
@@ -946,6 +968,96 @@ static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
   int grid = n_cus * per_cu;
   if (grid > g.B) grid = g.B;
   hipLaunchKernelGGL((small_fit_kernel<NT>), dim3(grid), dim3(NTH), lds, stream, g);
+  BAYENS_HIP(hipGetLastError());
+}
+
+// ---- diagnostic: the 16x16 diagonal factorisation and the raw dependent-chain latencies it is made of, in isolation
+// (one workgroup of `waves` waves; wave 0 runs the measured sequence `reps` times, the others idle at a barrier or, with
+// variant bit 8, keep the matrix pipes busy).  out[0] = shader cycles per repetition.
+__global__ void diag_bench_kernel(int variant, int reps, double* out, double seed) {
+  __shared__ double T0[TS], T[TS], D[TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Lane o;
+  o.lr = lane & 15; o.lk = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { o.rc[q] = swz(o.lr, 4 * q + o.lk); o.cr[q] = swz(4 * q + o.lk, o.lr); }
+  if (wave == 0)
+    for (int e = lane; e < 256; e += 64) {
+      const int r = e >> 4, c = e & 15;
+      T0[swz(r, c)] = (r == c ? 20.0 : 0.0) + 1.0 / (1.0 + r + c) + seed;       // SPD
+    }
+  __syncthreads();
+  const int kind = variant & 255;
+  if (kind == 7 || kind == 8) {           // every wave: `reps` tile products of 6 steps each from LDS tiles (the GS pattern)
+    __shared__ double Tl[8 * TS];
+    for (int e = tid; e < 8 * TS; e += blockDim.x) Tl[e] = 1.0 + 1e-6 * e;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int rep = 0; rep < reps; ++rep) {
+      if (kind == 7)
+        acc = acc_run(acc, 0, 6, [&](int k, int q) { return Tl[((k + wave) & 7) * TS + o.rc[q]]; },
+                      [&](int k, int q) { return Tl[((k + rep) & 7) * TS + o.cr[q]]; });
+      else {                                // registers only: the pipe-bound reference
+        const double a = 1.0 + 1e-9 * lane, b = 0.5;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) acc = MFMA(a, b, acc);
+      }
+    }
+    __syncthreads();
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) { out[0] = (double)(t1 - t0) / reps; out[1] = acc[0]; }
+    if (acc[0] == 12345.678) out[2] = acc[1];
+    return;
+  }
+  if (wave == 0) {
+    int bad = 0;
+    double x = 1.0 + seed + lane * 1e-9, y = 0.999;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int rep = 0; rep < reps; ++rep) {
+      if (kind == 0) {                     // the factorisation as the fit uses it (tile restored every time)
+        for (int e = lane; e < 256; e += 64) T[e] = T0[e];
+        diag16(ld_tile_sym(T, o), T, D, lane, 0, bad, o);
+      } else if (kind == 1) {              // 64 dependent v_fma_f64
+#pragma unroll
+        for (int i = 0; i < 64; ++i) x = fma(x, y, 1e-3);
+      } else if (kind == 2) {              // 16 dependent v_rsq_f64 (+ one fma each to keep them dependent and bounded)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x = fma(__builtin_amdgcn_rsq(x), 0.5, 1.0);
+      } else if (kind == 3) {              // 16 dependent refined rsqrt
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x = rsqrt_refined(x) + 1.0;
+      } else if (kind == 4) {              // 16 dependent MFMAs (one accumulator)
+        v4d acc = {x, x, x, x};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = MFMA(y, 1e-3, acc);
+        x = acc[0];
+      } else if (kind == 5) {              // 16 x (readlane of an MFMA result -> operand of the next MFMA)
+        v4d acc = {x, x, x, x};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double u = readlane_f64(acc[0], 5);
+          acc = MFMA(u * 1e-3, y, acc);
+        }
+        x = acc[0];
+      } else if (kind == 6) {              // tile load + store through LDS (what brackets the factorisation)
+        v4d a = ld_tile(T0, o);
+        a[0] += x;
+        st_tile(T, o, a);
+        x = T[o.rc[1]];
+      }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { out[0] = (double)(t1 - t0) / reps; out[1] = x + bad + T[3] + D[5]; }
+  } else if (variant & 256) {            // partner waves hammer the matrix pipes meanwhile
+    v4d acc = {1.0, 1.0, 1.0, 1.0};
+    for (int i = 0; i < reps * 64; ++i) acc = MFMA(1.0 + 1e-9 * lane, 0.5, acc);
+    if (acc[0] == 12345.0) out[2] = acc[0];
+  }
+}
+
+void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* out_dev) {
+  hipLaunchKernelGGL(diag_bench_kernel, dim3(1), dim3(64 * waves), 0, stream, variant, reps, out_dev, 0.0);
   BAYENS_HIP(hipGetLastError());
 }
 

@@ -265,6 +265,13 @@ int bayens_bench_mfma_peak(bayens_ctx* ctx, int waves_per_simd, double* tflops);
  * two workgroups per CU).  mode bits add the rest of a K step one by one: 1 = a workgroup barrier per 64 MFMAs,
  * 2 = the eight transposing LDS stores of the next tile, 4 = eight 16-byte global loads feeding those stores. */
 int bayens_bench_mfma_lds(bayens_ctx* ctx, int mode, double* tflops);
+/* Diagnostic: shader cycles per repetition of (variant & 255) 0 = the MFMA-based 16x16 diagonal factorisation of the fused
+ * small-member kernel, 1 = 64 dependent v_fma_f64, 2 = 16 dependent v_rsq_f64 (+fma), 3 = 16 dependent refined rsqrt,
+ * 4 = 16 dependent v_mfma_f64_16x16x4, 5 = 16 x (v_readlane of an MFMA result feeding the next MFMA), 6 = one tile
+ * through LDS; one workgroup of `waves` waves, wave 0 measured; variant | 256: the other waves keep the matrix pipes busy.
+ * 7 / 8: EVERY wave runs tile products of 6 steps (7: operands from LDS through the kernel's product loop, 8: 24 MFMAs
+ * from registers - the pipe-bound reference); cycles per product. */
+int bayens_bench_diag16(bayens_ctx* ctx, int variant, int waves, int reps, double* cycles);
 /* Diagnostic: phase stamps (shader cycle counter) of the fused small-member fit kernel (csrc/small.hip): enable = 1
  * makes every later small fit record the phase boundaries of workgroup 0's last member / iteration; stamps32 (nullable)
  * receives the 32 recorded values; enable = 0 switches the recording off again. */
