@@ -9,16 +9,26 @@
 #endif
 #include "fit_f32.h"
 
+#include <cstdlib>
 #include <vector>
 
 #include "fit_ws.h"
+#include "small.h"
 
 namespace bayens_f32 {
 struct State {
   hipStream_t stream;
   HipPrims prims;
   DeviceWs dws;
-  explicit State(hipStream_t s) : stream(s), prims(s) {}
+  int* small_info = nullptr;       // device info[] of the fused small-member path
+  int small_info_cap = 0, n_cus = 256;
+  explicit State(hipStream_t s) : stream(s), prims(s) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cus = prop.multiProcessorCount;
+  }
+  ~State() { if (small_info) (void)hipFree(small_info); }
 };
 }  // namespace bayens_f32
 
@@ -39,6 +49,23 @@ void bayens_f32_profile_add(void* state, int family, double* ms, double* flop, l
 int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
   State* st = static_cast<State*>(state);
   try {
+    static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
+    if (!no_small && smalln::small_fit_supported(a.N, a.R)) {      // small members: the fused one-kernel-per-fit path (small.hip)
+      if (st->small_info_cap < a.B) {
+        if (st->small_info) (void)hipFree(st->small_info);
+        st->small_info = nullptr;
+        BAYENS_HIP(hipMalloc((void**)&st->small_info, (size_t)a.B * sizeof(int)));
+        st->small_info_cap = a.B;
+      }
+      smalln::SmallArgs g{a.B, a.N, a.R, a.kernel, a.n_iters, a.gamma, a.lr, a.jitter, a.X, a.y_mean, a.y_var, a.mu, a.cov,
+                          nullptr, a.chol, a.logdet, a.hyp, a.basis, st->small_info};
+      g.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+      g.loss = g.loss_stride > 0 ? a.loss_trace : nullptr;
+      smalln::small_fit(st->stream, g, st->n_cus);
+      BAYENS_HIP(hipMemcpyAsync(a.info_host, st->small_info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
+      BAYENS_HIP(hipStreamSynchronize(st->stream));
+      return 0;
+    }
     const int Np = pad_to_leaf(a.N);
     st->dws.ensure(a.B, Np);
     FitWorkspace w = st->dws.view(0, a.B);

@@ -1,8 +1,11 @@
 // small.h - host interface of the fused small-member fit (small.hip): one workgroup per member, N <= SMALL_MAX_N.
+// Like the other sources of the fit it exists in two precisions (prims.h: `real`, namespace BAYENS_NS).
 #pragma once
 #include <hip/hip_runtime.h>
 
-namespace bayens {
+#include "prims.h"
+
+namespace BAYENS_NS {
 namespace smalln {
 
 // 6 tiles of 16 per side, two padded rows reserved for the bordered Cholesky of the covariance (1^T, mu^T)
@@ -11,16 +14,16 @@ constexpr int SMALL_MAX_N = 94;
 struct SmallArgs {
   int B, N, R, kernel, n_iters;
   double gamma, lr, jitter;
-  const double* X;       // [B][N][R]
-  const double* y;       // [B][N]
-  const double* nu;      // [B][N]
-  double* mu;            // [B][N]
-  double* cov;           // [B][N][N] or null (reduced export)
-  double* var;           // [B][N] = diag(cov) or null
-  double* chol;          // [B][N][N] or null
+  const real* X;         // [B][N][R]
+  const real* y;         // [B][N]
+  const real* nu;        // [B][N]
+  real* mu;              // [B][N]
+  real* cov;             // [B][N][N] or null (reduced export)
+  real* var;             // [B][N] = diag(cov) or null
+  real* chol;            // [B][N][N] or null
   double* logdet;        // [B] or null
   double* hyp;           // [B][2] or null
-  double* basis;         // [B][2][N] or null
+  real* basis;           // [B][2][N] or null
   int* info;             // [B]
   double* loss = nullptr;   // [B][loss_stride]: -ELBO after iterations 0, 25, 50, ... (models.py:211-215) or null
   int loss_stride = 0;
@@ -30,8 +33,10 @@ struct SmallArgs {
 bool small_fit_supported(int N, int R);
 // queues the fit of all B members on `stream` (grid = resident workgroups, members dealt round-robin)
 void small_fit(hipStream_t stream, const SmallArgs& args, int n_cus);
+#ifndef BAYENS_F32
 // diagnostic micro-benchmark of the 16x16 diagonal factorisation and of the dependent chains it consists of
 void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* out_dev);
+#endif
 
 }  // namespace smalln
-}  // namespace bayens
+}  // namespace BAYENS_NS

@@ -25,14 +25,21 @@
 #include "hip_prims.h"
 #include "small.h"
 
-#ifndef BAYENS_F32
-namespace bayens {
+// Compiled twice, like gemm.hip / kernels.hip: `real` = double (namespace bayens, the reference precision) and, with
+// -DBAYENS_F32, `real` = float (namespace bayens_f32: fp32 tiles and v_mfma_f32_16x16x4_f32 products; the 16x16 diagonal
+// factorisations, the squared distances of the kernel matrix, the vectors and every reduction stay fp64).
+namespace BAYENS_NS {
 namespace smalln {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v4d __attribute__((ext_vector_type(4)));   // fp64 accumulator tile (diagonal factorisations, distances)
+typedef real v4r __attribute__((ext_vector_type(4)));     // accumulator tile in the fit's precision
 
-constexpr int TS = 256;            // doubles per tile
-constexpr int NW = 8;              // waves per workgroup
+constexpr int TS = 256;            // elements per tile
+// 8 waves, one workgroup per CU.  (Measured alternatives: 4 waves per workgroup leave 7 register tiles per matrix and
+// wave - fp64: 6.5e5 instead of 8.7e5 fits/s at 512 registers; with the 256 registers that two such workgroups per CU
+// would be held to - which the 80 KB fp32 footprint would allow - the kernel spills ~1900 registers and crawls.)
+constexpr int NW = 8;
+typedef double vecr;               // element type of the LDS vectors (theta1, m, u, ...): fp64 in both precisions
 constexpr int NTH = NW * 64;
 constexpr double SQRT3 = 1.7320508075688772;
 constexpr double SQRT5 = 2.23606797749979;
@@ -41,14 +48,39 @@ __device__ __forceinline__ double* lds_base() {
   extern __shared__ __attribute__((aligned(16))) double lds_block[];
   return lds_block;
 }
+__device__ __forceinline__ real* tiles_base() { return reinterpret_cast<real*>(lds_base()); }
 
+// The 16x16x4 MFMA of either precision takes lane (lr, lk)'s A element [lr][k] and B element [k][lr] with k = lk in
+// each of the four steps of a 16-deep product; its accumulator register r holds row lk + 4r (fp64) or 4lk + r (fp32) of
+// column lr.  Step q of a tile product contracts over the index set kq[q] = {4q + lk} (fp64) / {4lk + q} (fp32) - the
+// order of a sum is free - so that in BOTH precisions accumulator register q is element (kq[q], lr): an accumulator
+// tile is a B operand as it stands, and one table of offsets serves operand reads and accumulator stores.
 struct Lane {
-  int rc[4];   // rc[q] = swizzled offset of element (lr, 4q + lk)
-  int cr[4];   // cr[q] = swizzled offset of element (4q + lk, lr)   (= accumulator register q of this lane)
+  int rc[4];   // rc[q] = swizzled offset of element (lr, kq[q])
+  int cr[4];   // cr[q] = swizzled offset of element (kq[q], lr)   (= accumulator register q of this lane)
+  int kq[4];
   int lr, lk;
 };
 
+#ifdef BAYENS_F32
+#define MFMAR(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+__device__ __forceinline__ int kq_of(int lk, int q) { return 4 * lk + q; }
+// 4-byte elements, 32 banks: column ^ p(row >> 1), p over {0..3, 8..11} (never differs by 4 alone: the two k-groups of a
+// half-wave stay on distinct banks in the row-indexed reads; column-indexed reads are 2-way conflicted)
+__device__ __forceinline__ int swz(int r, int c) { const int h = r >> 1; return r * 16 + (c ^ ((h & 3) | ((h >> 2) << 3))); }
+// row of X that lane lr supplies as A row lr of the fp64 distance product, so that its result register r is row kq[r]
+__device__ __forceinline__ int dist_row(int lr) { return 4 * (lr & 3) + (lr >> 2); }
+#else
+#define MFMAR(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+__device__ __forceinline__ int kq_of(int lk, int q) { return 4 * q + lk; }
 __device__ __forceinline__ int swz(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
+__device__ __forceinline__ int dist_row(int lr) { return lr; }
+#endif
+__device__ __forceinline__ void lane_init(Lane& o, int lane) {
+  o.lr = lane & 15; o.lk = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { o.kq[q] = kq_of(o.lk, q); o.rc[q] = swz(o.lr, o.kq[q]); o.cr[q] = swz(o.kq[q], o.lr); }
+}
 __device__ __forceinline__ int lt(int i, int j) { return ((i * (i + 1)) >> 1) + j; }     // j <= i
 __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
   i = 0;
@@ -62,13 +94,13 @@ __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
 // diagnostic: wave 0 / lane 0 of workgroup 0 stamps the phase boundaries of its member (g.stamps null in production)
 #define STAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[k] = __builtin_readcyclecounter(); } while (0)
 
-__device__ __forceinline__ v4d ld_tile(const double* t, const Lane& o) {
-  v4d a;
+__device__ __forceinline__ v4r ld_tile(const real* t, const Lane& o) {
+  v4r a;
 #pragma unroll
   for (int r = 0; r < 4; ++r) a[r] = t[o.cr[r]];
   return a;
 }
-__device__ __forceinline__ void st_tile(double* t, const Lane& o, v4d a) {
+__device__ __forceinline__ void st_tile(real* t, const Lane& o, v4r a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) t[o.cr[r]] = a[r];
 }
@@ -76,15 +108,15 @@ __device__ __forceinline__ void st_tile(double* t, const Lane& o, v4d a) {
 // (two accumulator chains, q = 0, 1 and q = 2, 3: a dependent v_mfma_f64_16x16x4 waits ~20 cycles longer than the 64
 //  its predecessor occupies the pipe; with one wave per SIMD nobody else fills that gap)
 template <bool TA, bool TB>
-__device__ __forceinline__ v4d mma(v4d acc, const double* A, const double* B, const Lane& o, double sa = 1.0) {
-  double a[4], b[4];
+__device__ __forceinline__ v4r mma(v4r acc, const real* A, const real* B, const Lane& o, real sa = 1) {
+  real a[4], b[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { a[q] = sa * A[TA ? o.cr[q] : o.rc[q]]; b[q] = B[TB ? o.rc[q] : o.cr[q]]; }
-  v4d acc2 = {0.0, 0.0, 0.0, 0.0};
-  acc = MFMA(a[0], b[0], acc);
-  acc2 = MFMA(a[2], b[2], acc2);
-  acc = MFMA(a[1], b[1], acc);
-  acc2 = MFMA(a[3], b[3], acc2);
+  v4r acc2 = {0, 0, 0, 0};
+  acc = MFMAR(a[0], b[0], acc);
+  acc2 = MFMAR(a[2], b[2], acc2);
+  acc = MFMAR(a[1], b[1], acc);
+  acc2 = MFMAR(a[3], b[3], acc2);
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
   return acc;
@@ -95,28 +127,28 @@ __device__ __forceinline__ v4d mma(v4d acc, const double* A, const double* B, co
 // MFMAs run as two accumulator chains (a dependent v_mfma_f64_16x16x4 waits 78 cycles, its predecessor holds the pipe
 // for 64), so a trip has one exposed LDS latency for 512 cycles of matrix-pipe work.
 template <class LoadA, class LoadB>
-__device__ __forceinline__ v4d acc_run(v4d acc, int k0, int k1, LoadA la, LoadB lb) {
-  v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ v4r acc_run(v4r acc, int k0, int k1, LoadA la, LoadB lb) {
+  v4r acc2 = {0, 0, 0, 0};
   int k = k0;
 #pragma unroll 1
   for (; k + 1 < k1; k += 2) {
-    double a[8], b[8];
+    real a[8], b[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); a[4 + q] = la(k + 1, q); b[4 + q] = lb(k + 1, q); }
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
-      acc = MFMA(a[q], b[q], acc);
-      acc2 = MFMA(a[q + 1], b[q + 1], acc2);
+      acc = MFMAR(a[q], b[q], acc);
+      acc2 = MFMAR(a[q + 1], b[q + 1], acc2);
     }
   }
   if (k < k1) {
-    double a[4], b[4];
+    real a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); }
-    acc = MFMA(a[0], b[0], acc);
-    acc2 = MFMA(a[1], b[1], acc2);
-    acc = MFMA(a[2], b[2], acc);
-    acc2 = MFMA(a[3], b[3], acc2);
+    acc = MFMAR(a[0], b[0], acc);
+    acc2 = MFMAR(a[1], b[1], acc2);
+    acc = MFMAR(a[2], b[2], acc);
+    acc2 = MFMAR(a[3], b[3], acc2);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
@@ -215,18 +247,29 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   const double e = fma(-(d * y0), y0, 1.0);
   return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
-// symmetric image of a diagonal tile (only its lower triangle is trusted) in accumulator layout
-__device__ __forceinline__ v4d ld_tile_sym(const double* T, const Lane& o) {
-  v4d acc;
+// symmetric image of a diagonal tile (only its lower triangle is trusted): in the accumulator layout of the fit's
+// precision, and in the fp64 accumulator layout (rows lk + 4r) the factorisation below works in
+__device__ __forceinline__ v4r ld_tile_sym(const real* T, const Lane& o) {
+  v4r acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = o.lk + 4 * r, col = o.lr;
+    const int row = o.kq[r], col = o.lr;
     acc[r] = T[row >= col ? swz(row, col) : swz(col, row)];
   }
   return acc;
 }
-// acc: the symmetric tile (accumulator layout, registers); the factor goes to T, its inverse to Dk
-__device__ __forceinline__ void diag16(v4d acc, double* T, double* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
+__device__ __forceinline__ v4d ld_tile_sym64(const real* T, const Lane& o) {
+  v4d acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = o.lk + 4 * r, col = o.lr;
+    acc[r] = (double)T[row >= col ? swz(row, col) : swz(col, row)];
+  }
+  return acc;
+}
+// acc: the symmetric tile (fp64 accumulator layout, registers); the factor goes to T, its inverse to Dk (fp64 in both
+// precisions of the fit: "fp64 accumulate in chol")
+__device__ __forceinline__ void diag16(v4d acc, real* T, real* Dk, int lane, int pivot_base, int& bad, const Lane& o) {
   __builtin_amdgcn_s_setprio(3);        // the serial chain of the workgroup: win issue arbitration on its SIMD
   v4d fac;
 #pragma unroll
@@ -290,8 +333,8 @@ __device__ __forceinline__ void diag16(v4d acc, double* T, double* Dk, int lane,
   // every lane holds 4 entries of the factor (operand layout) and 4 of the inverse (accumulator layout)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    T[o.rc[s]] = lcol[s];
-    Dk[o.cr[s]] = xrow[s];
+    T[swz(o.lr, 4 * s + o.lk)] = (real)lcol[s];
+    Dk[swz(4 * s + o.lk, o.lr)] = (real)xrow[s];
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -313,27 +356,27 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
                                          Extra extra = Extra()) {
   // (LDS operands arrive as offsets into the workgroup's dynamic LDS block: pointers handed to a real function call
   //  would be generic pointers and every access a flat one)
-  double* A = lds_base() + a_off;
-  double* D = lds_base() + d_off;
-  double* Xb = lds_base() + x_off;
-  if (wave == 0) diag16(ld_tile_sym(A, o), A, D, lane, 0, bad, o);
+  real* A = tiles_base() + a_off;
+  real* D = tiles_base() + d_off;
+  real* Xb = tiles_base() + x_off;
+  if (wave == 0) diag16(ld_tile_sym64(A, o), A, D, lane, 0, bad, o);
   SYNC();
 #pragma unroll 1
   for (int k = 0; k < NT; ++k) {
     const int below = NT - 1 - k;
-    const double* dk = D + k * TS;
+    const real* dk = D + k * TS;
 #pragma unroll 1
     for (int q = wave; q < below + (WITH_INV ? k + 1 : 0); q += NW) {
       if (q < below) {                                    // panel: L_ik = A_ik inv_kk^T
-        double* t = A + lt(k + 1 + q, k) * TS;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        real* t = A + lt(k + 1 + q, k) * TS;
+        v4r acc = {0, 0, 0, 0};
         acc = mma<false, true>(acc, t, dk, o);
         st_tile(t, o, acc);
       } else {
         const int i = q - below;
-        double* t = Xb + lt(k, i) * TS;
+        real* t = Xb + lt(k, i) * TS;
         if (i < k) {                                      // X_ki = inv_kk T_ki
-          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          v4r acc = {0, 0, 0, 0};
           acc = mma<false, false>(acc, dk, t, o);
           st_tile(t, o, acc);
         } else {
@@ -344,10 +387,15 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
     SYNC();
     if (below == 0) break;
     if (wave == 0) {                                      // look-ahead: next diagonal tile first, then its factorisation
-      double* t = A + lt(k + 1, k + 1) * TS;
-      v4d acc = ld_tile_sym(t, o);                        // (the updated tile goes straight into the factorisation)
-      acc = mma<false, true>(acc, A + lt(k + 1, k) * TS, A + lt(k + 1, k) * TS, o, -1.0);
-      diag16(acc, t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
+      real* t = A + lt(k + 1, k + 1) * TS;
+      v4r acc = ld_tile_sym(t, o);
+      acc = mma<false, true>(acc, A + lt(k + 1, k) * TS, A + lt(k + 1, k) * TS, o, -1);
+#ifdef BAYENS_F32
+      st_tile(t, o, acc);                                 // (fp32 -> fp64 accumulator layout: through the wave's own LDS tile)
+      diag16(ld_tile_sym64(t, o), t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
+#else
+      diag16(acc, t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);   // the updated tile goes straight into the factorisation
+#endif
     } else {
       int p = 0;
 #pragma unroll 1
@@ -356,9 +404,9 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
         for (int j = k + 1; j <= i; ++j) {
           if (i == k + 1) continue;                       // (k+1, k+1) is wave 0's
           if (p++ % (NW - 1) == wave - 1) {               // A_ij -= L_ik L_jk^T
-            double* t = A + lt(i, j) * TS;
-            v4d acc = ld_tile(t, o);
-            acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1.0);
+            real* t = A + lt(i, j) * TS;
+            v4r acc = ld_tile(t, o);
+            acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1);
             st_tile(t, o, acc);
           }
         }
@@ -368,10 +416,10 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
 #pragma unroll 1
           for (int i = 0; i <= k; ++i)
             if (p++ % (NW - 1) == wave - 1) {             // T_ji -= L_jk X_ki   (first touched at k == i)
-              double* t = Xb + lt(j, i) * TS;
-              v4d acc = {0.0, 0.0, 0.0, 0.0};
+              real* t = Xb + lt(j, i) * TS;
+              v4r acc = {0, 0, 0, 0};
               if (k > i) acc = ld_tile(t, o);
-              acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1.0);
+              acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1);
               st_tile(t, o, acc);
             }
       }
@@ -386,39 +434,39 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
 // ---- matrix-vector products on tile-packed buffers: wave w < NT owns the 16 outputs of tile row / column w, lane
 // (lr, lk) walks the columns == lk mod 4, the four partial sums meet through two shuffles.  Valid in lanes lk == 0.
 template <int NT>
-__device__ __forceinline__ double mv_lower(const double* Lb, const double* x, int i, const Lane& o) {     // (L x)[16 i + lr]
+__device__ __forceinline__ double mv_lower(const real* Lb, const vecr* x, int i, const Lane& o) {     // (L x)[16 i + lr]
   double s = 0.0;
 #pragma unroll 1
   for (int k = 0; k <= i; ++k) {
-    const double* t = Lb + lt(i, k) * TS;
+    const real* t = Lb + lt(i, k) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[o.rc[q]], x[16 * k + 4 * q + o.lk], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[o.rc[q]], (double)x[16 * k + o.kq[q]], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
   return s;
 }
 template <int NT>
-__device__ __forceinline__ double mv_lower_t(const double* Lb, const double* x, int j, const Lane& o) {   // (L^T x)[16 j + lr]
+__device__ __forceinline__ double mv_lower_t(const real* Lb, const vecr* x, int j, const Lane& o) {   // (L^T x)[16 j + lr]
   double s = 0.0;
 #pragma unroll 1
   for (int k = j; k < NT; ++k) {
-    const double* t = Lb + lt(k, j) * TS;
+    const real* t = Lb + lt(k, j) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[o.cr[q]], x[16 * k + 4 * q + o.lk], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[o.cr[q]], (double)x[16 * k + o.kq[q]], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
   return s;
 }
 template <int NT>
-__device__ __forceinline__ double mv_sym(const double* Sb, const double* x, int i, const Lane& o) {       // (S x)[16 i + lr]
+__device__ __forceinline__ double mv_sym(const real* Sb, const vecr* x, int i, const Lane& o) {       // (S x)[16 i + lr]
   double s = 0.0;
 #pragma unroll 1
   for (int k = 0; k < NT; ++k) {
-    const double* t = Sb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
+    const real* t = Sb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[k <= i ? o.rc[q] : o.cr[q]], x[16 * k + 4 * q + o.lk], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[k <= i ? o.rc[q] : o.cr[q]], (double)x[16 * k + o.kq[q]], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -428,29 +476,30 @@ __device__ __forceinline__ double mv_sym(const double* Sb, const double* x, int 
 // squared distances of tile (i, j): X X^T on the matrix cores with operands straight from the member's X,
 // r2 = ((-2 dot + |x_i|^2) + |x_j|^2) / ls^2 - GPflow / the oracle scale X first, this scales the distance (the
 // rounding differs in the last bits only; ssq = |x_i|^2 is then a per-member constant)
-__device__ __forceinline__ v4d r2_tile(const double* X, int N, int R, double inv_ls2, const double* ssq, int i, int j, const Lane& o) {
+// (always an fp64 product; result register r is the pair (row kq[r], column lr) of the tile in either precision)
+__device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_ls2, const double* ssq, int i, int j, const Lane& o) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  const int ra = 16 * i + o.lr, rb = 16 * j + o.lr;
-  const double* xa = X + (long)(ra < N ? ra : 0) * R;
-  const double* xb = X + (long)(rb < N ? rb : 0) * R;
+  const int ra = 16 * i + dist_row(o.lr), rb = 16 * j + o.lr;
+  const real* xa = X + (long)(ra < N ? ra : 0) * R;
+  const real* xb = X + (long)(rb < N ? rb : 0) * R;
   if (R <= 8) {                 // the common case: both operand pairs requested before the first MFMA
     const int c0 = o.lk, c1 = 4 + o.lk;
-    const double a0 = (ra < N && c0 < R) ? xa[c0] : 0.0, b0 = (rb < N && c0 < R) ? xb[c0] : 0.0;
-    const double a1 = (ra < N && c1 < R) ? xa[c1] : 0.0, b1 = (rb < N && c1 < R) ? xb[c1] : 0.0;
+    const double a0 = (ra < N && c0 < R) ? (double)xa[c0] : 0.0, b0 = (rb < N && c0 < R) ? (double)xb[c0] : 0.0;
+    const double a1 = (ra < N && c1 < R) ? (double)xa[c1] : 0.0, b1 = (rb < N && c1 < R) ? (double)xb[c1] : 0.0;
     acc = MFMA(a0, b0, acc);
     if (R > 4) acc = MFMA(a1, b1, acc);
   } else {
 #pragma unroll 2
     for (int k0 = 0; k0 < R; k0 += 4) {
       const int c = k0 + o.lk;
-      const double a = (ra < N && c < R) ? xa[c] : 0.0;
-      const double b = (rb < N && c < R) ? xb[c] : 0.0;
+      const double a = (ra < N && c < R) ? (double)xa[c] : 0.0;
+      const double b = (rb < N && c < R) ? (double)xb[c] : 0.0;
       acc = MFMA(a, b, acc);
     }
   }
   const double sj = ssq[16 * j + o.lr];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = ((-2.0 * acc[r] + ssq[16 * i + o.lk + 4 * r]) + sj) * inv_ls2;
+  for (int r = 0; r < 4; ++r) acc[r] = ((-2.0 * acc[r] + ssq[16 * i + o.kq[r]]) + sj) * inv_ls2;
   return acc;
 }
 
@@ -459,67 +508,69 @@ struct Layout {
   static constexpr int NTT = NT * (NT + 1) / 2;
   static constexpr int NP = 16 * NT;
   static constexpr int TPW = (NTT + NW - 2) / (NW - 1);  // register tiles per wave: dealt over waves 1..NW-1 (wave 0 runs the serial chains)
+  // tile regions (offsets in elements of `real` from tiles_base())
   static constexpr int LB = 0, CB = NTT * TS, WB = 2 * NTT * TS, DL = 3 * NTT * TS, DC = DL + NT * TS;
-  static constexpr int VEC = DC + NT * TS;               // vectors of NP doubles
-  static constexpr int NVEC = 10;
-  static constexpr int MISC = VEC + NVEC * NP;
-  static constexpr int TOTAL = MISC + 64;                // doubles
+  static constexpr int TILE_ELEMS = DC + NT * TS;
+  // behind them (offsets in doubles): |x_i|^2 and 64 scalars in fp64, then NVEC vectors of NP elements of `vecr`
+  static constexpr int SSQ = (int)((size_t)TILE_ELEMS * sizeof(real) / sizeof(double));
+  static constexpr int MISC = SSQ + NP;
+  static constexpr int VEC = MISC + 64;
+  static constexpr int NVEC = 9;
+  static constexpr size_t BYTES = (size_t)VEC * sizeof(double) + (size_t)NVEC * NP * sizeof(vecr);
 };
 
 template <int NT>
-__global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
+__global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // two waves per SIMD: 256 registers each
   typedef Layout<NT> Y;
   constexpr int NTT = Y::NTT, NP = Y::NP, TPW = Y::TPW;
   double* lds = lds_base();
-  double* Lb = lds + Y::LB;
-  double* Cb = lds + Y::CB;
-  double* Wb = lds + Y::WB;
-  double* DLi = lds + Y::DL;            // inverted diagonal tiles of L; in the prediction also staging (odd tile rows)
-  double* DCi = lds + Y::DC;            // inverted diagonal tiles of C; in the prediction: staging of one tile row of A^T S
-  double* yv = lds + Y::VEC;            // y (0 in the padding)
-  double* dv = yv + NP;                 // 1 / nu (1 in the padding)
-  double* rs = dv + NP;                 // 1 / sqrt(nu)
-  double* yd = rs + NP;                 // y / nu
-  double* th = yd + NP;                 // theta1
-  double* mv = th + NP;                 // m
-  double* av = mv + NP;                 // loss samples: L m - y; prediction: the posterior mean
-  double* wv = av + NP;                 // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
-  double* uv = wv + NP;                 // u = L^T D (L m - y) = G m - L^T (y / nu)
-  double* ssq = uv + NP;                // |x_i|^2
-  double* misc = lds + Y::MISC;         // [0..7] optimiser state, [8] variance, [9] lengthscale, [10] 1/ls^2, [16..31] reductions
+  real* Lb = tiles_base() + Y::LB;
+  real* Cb = tiles_base() + Y::CB;
+  real* Wb = tiles_base() + Y::WB;
+  real* DLi = tiles_base() + Y::DL;     // inverted diagonal tiles of L; in the prediction also staging (odd tile rows)
+  real* DCi = tiles_base() + Y::DC;     // inverted diagonal tiles of C; in the prediction: staging of one tile row of A^T S
+  double* ssq = lds + Y::SSQ;           // |x_i|^2 (fp64: the squared distances cancel)
+  double* misc = lds + Y::MISC;         // [0..7] optimiser state, [8] variance, [9] lengthscale, [10] 1/ls^2, [16..47] reductions
+  vecr* yv = reinterpret_cast<vecr*>(lds + Y::VEC);   // y (0 in the padding)
+  vecr* dv = yv + NP;                   // 1 / nu (1 in the padding)
+  vecr* rs = dv + NP;                   // 1 / sqrt(nu)
+  vecr* yd = rs + NP;                   // y / nu
+  vecr* th = yd + NP;                   // theta1
+  vecr* mv = th + NP;                   // m
+  vecr* av = mv + NP;                   // loss samples: L m - y; prediction: the posterior mean
+  vecr* wv = av + NP;                   // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
+  vecr* uv = wv + NP;                   // u = L^T D (L m - y) = G m - L^T (y / nu)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Lane o;
-  o.lr = lane & 15; o.lk = lane >> 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { o.rc[q] = swz(o.lr, 4 * q + o.lk); o.cr[q] = swz(4 * q + o.lk, o.lr); }
+  lane_init(o, lane);
   const int N = g.N, R = g.R;
   const double J = g.jitter;
 
 #pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
-    const double* X = g.X + (long)b * N * R;
+    const real* X = g.X + (long)b * N * R;
     int bad = 0;
     // ---- member set-up ----
     for (int t = tid; t < NP; t += NTH) {
-      const double nu = t < N ? g.nu[(long)b * N + t] : 1.0;
-      const double y = t < N ? g.y[(long)b * N + t] : 0.0;
-      yv[t] = y; dv[t] = 1.0 / nu; rs[t] = 1.0 / sqrt(nu); yd[t] = y / nu;
-      th[t] = 0.0; mv[t] = 0.0;
+      const double nu = t < N ? (double)g.nu[(long)b * N + t] : 1.0;
+      const double y = t < N ? (double)g.y[(long)b * N + t] : 0.0;
+      yv[t] = (vecr)y; dv[t] = (vecr)(1.0 / nu); rs[t] = (vecr)(1.0 / sqrt(nu)); yd[t] = (vecr)(y / nu);
+      th[t] = 0; mv[t] = 0;
       double sq = 0.0;                  // fma chain in k order = the diagonal of the MFMA product: r2_ii is exactly 0
       if (t < N)
-        for (int d = 0; d < R; ++d) { const double v = X[(long)t * R + d]; sq = fma(v, v, sq); }
+        for (int d = 0; d < R; ++d) { const double v = (double)X[(long)t * R + d]; sq = fma(v, v, sq); }
       ssq[t] = sq;
     }
     if (tid < 8) misc[tid] = tid < 2 ? 0.5413248546129181 /* softplus^-1(1) = log(e - 1) */ : 0.0;
-    v4d lam[TPW], gt[TPW];
+    v4r lam[TPW], gt[TPW];
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
       int i = 0, j = 0;
       unpack_lower(p < NTT ? p : 0, i, j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lam[s][r] = (i == j && o.lk + 4 * r == o.lr) ? 1.0 : 0.0;
-      gt[s] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int r = 0; r < 4; ++r) lam[s][r] = (i == j && o.kq[r] == o.lr) ? 1 : 0;
+      gt[s] = v4r{0, 0, 0, 0};
       if (p < NTT) st_tile(Cb + p * TS, o, lam[s]);        // S = I until the first natural-gradient step (n_iters = 0)
     }
     SYNC();
@@ -539,18 +590,19 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       for (int p = wave; p < NTT; p += NW) {
         int i, j;
         unpack_lower(p, i, j);
-        v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+        const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+        v4r kt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
+          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
           double k1, k2;
           kern_unit<false>(g.kernel, r2[r], k1, k2);
           double K = var * k1;
           if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
           else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
-          r2[r] = K;
+          kt[r] = (real)K;
         }
-        st_tile(Lb + p * TS, o, r2);
+        st_tile(Lb + p * TS, o, kt);
       }
       SYNC();
     };
@@ -564,30 +616,30 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower<NT>(Lb, mv, i, o);
-        if (o.lk == 0) av[16 * i + o.lr] = s - yv[16 * i + o.lr];
+        if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s - (double)yv[16 * i + o.lr]);
         double fr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int j = 0; j <= i; ++j) {
-          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          v4r acc = {0, 0, 0, 0};
           acc = acc_run(acc, 0, i + 1, [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; },
                         [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
-          const v4d lt_ = ld_tile(Lb + lt(i, j) * TS, o);
+          const v4r lt_ = ld_tile(Lb + lt(i, j) * TS, o);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) fr[r] = fma(acc[r], lt_[r], fr[r]);
+          for (int r = 0; r < 4; ++r) fr[r] = fma((double)acc[r], (double)lt_[r], fr[r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double v = fr[r];
           v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-          if (o.lr == 0) wv[16 * i + o.lk + 4 * r] = v;                    // f_t
+          if (o.lr == 0) wv[16 * i + o.kq[r]] = (vecr)v;                   // f_t
         }
       }
       SYNC();
       double part = 0.0;
       for (int t = tid; t < N; t += NTH) {
-        const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
-        const double stt = Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)];
-        part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
+        const double nu = 1.0 / (double)dv[t], a = av[t], m = mv[t];
+        const double stt = (double)Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)];
+        part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + (double)wv[t]) * (double)dv[t] + 0.5 * (m * m + stt);
       }
       part = wave_sum(part);
       if (lane == 0) misc[16 + wave] = part;
@@ -609,7 +661,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       // L = chol(K0 + J I); G = L^T D L = sum_k (D^1/2 L)_k*^T (D^1/2 L)_k* is accumulated block row by block row behind
       // the factorisation (registers gt[], tiles dealt over waves 1..7)
 #pragma unroll
-      for (int s = 0; s < TPW; ++s) gt[s] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < TPW; ++s) gt[s] = v4r{0, 0, 0, 0};
       auto g_rows = [&](int k) {
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
@@ -617,12 +669,12 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           int i = 0, j = 0;
           unpack_lower(p < NTT ? p : 0, i, j);
           if (p < NTT && i <= k) {
-            const double* ta = Lb + lt(k, i) * TS;
-            const double* tb = Lb + lt(k, j) * TS;
+            const real* ta = Lb + lt(k, i) * TS;
+            const real* tb = Lb + lt(k, j) * TS;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const double sc = rs[16 * k + 4 * q + o.lk];
-              gt[s] = MFMA(ta[o.cr[q]] * sc, tb[o.cr[q]] * sc, gt[s]);
+              const real sc = (real)rs[16 * k + o.kq[q]];
+              gt[s] = MFMAR(ta[o.cr[q]] * sc, tb[o.cr[q]] * sc, gt[s]);
             }
           }
         }
@@ -639,7 +691,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           unpack_lower(p, i, j);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            lam[s][r] = (1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.lk + 4 * r == o.lr) ? 1.0 : 0.0));
+            lam[s][r] = (real)((1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0)));
           st_tile(Cb + p * TS, o, lam[s]);
         }
       }
@@ -647,16 +699,16 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower_t<NT>(Lb, yd, i, o);
         if (o.lk == 0) {
-          th[16 * i + o.lr] = (1.0 - g.gamma) * th[16 * i + o.lr] + g.gamma * s;
-          wv[16 * i + o.lr] = s;               // L^T (y / nu): u = L^T D (L m - y) = G m - L^T (y / nu) needs it, and L dies here
+          th[16 * i + o.lr] = (vecr)((1.0 - g.gamma) * (double)th[16 * i + o.lr] + g.gamma * s);
+          wv[16 * i + o.lr] = (vecr)s;         // L^T (y / nu): u = L^T D (L m - y) = G m - L^T (y / nu) needs it, and L dies here
         }
       }
       SYNC();
       STAMP(3);
       // C = chol(Lam) in Cb, C^-1 in Lb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
-      v4d st[TPW];
+      v4r st[TPW];
 #pragma unroll
-      for (int s = 0; s < TPW; ++s) st[s] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < TPW; ++s) st[s] = v4r{0, 0, 0, 0};
       auto s_rows = [&](int k) {
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
@@ -670,7 +722,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       STAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log((double)Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
         s = wave_sum(s);
         if (lane == 0) misc[32 + wave] = s;
         SYNC();
@@ -693,13 +745,13 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_sym<NT>(Cb, th, i, o);
-        if (o.lk == 0) mv[16 * i + o.lr] = s;
+        if (o.lk == 0) mv[16 * i + o.lr] = (vecr)s;
       }
       SYNC();
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_sym<NT>(Lb, mv, i, o);
-        if (o.lk == 0) uv[16 * i + o.lr] = s - wv[16 * i + o.lr];
+        if (o.lk == 0) uv[16 * i + o.lr] = (vecr)(s - (double)wv[16 * i + o.lr]);
       }
       SYNC();
       STAMP(6);
@@ -710,16 +762,16 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
-          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          v4r acc = {0, 0, 0, 0};
           acc = acc_run(acc, 0, NT,
                         [&](int k, int q) { return k <= i ? Lb[lt(i, k) * TS + o.rc[q]] : Lb[lt(k, i) * TS + o.cr[q]]; },
                         [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int rl = o.lk + 4 * r;
-            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], acc[r]);
+            const int rl = o.kq[r];
+            double v = fma((double)uv[16 * i + rl], (double)mv[16 * j + o.lr], (double)acc[r]);
             if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
-            acc[r] = v;
+            acc[r] = (real)v;
           }
           st[s] = acc;
         }
@@ -737,7 +789,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 #pragma unroll
       for (int s = 0; s < TPW; ++s) {
         const int p = wave == 0 ? NTT : (wave - 1) + s * (NW - 1);
-        st[s] = v4d{0.0, 0.0, 0.0, 0.0};
+        st[s] = v4r{0, 0, 0, 0};
         if (p < NTT) {
           int i, j;
           unpack_lower(p, i, j);
@@ -763,7 +815,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         for (int p = wave; p < NTT; p += NW) {
           int i, j;
           unpack_lower(p, i, j);
-          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          v4r acc = {0, 0, 0, 0};
           acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
                         [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
           if (i != j)
@@ -772,10 +824,10 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
           const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
+            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
             double k1, k2;
             kern_unit<true>(g.kernel, r2[r], k1, k2);
-            if (row < N && col < N) { gv = fma(acc[r], k1, gv); gl = fma(acc[r], k2, gl); }
+            if (row < N && col < N) { gv = fma((double)acc[r], k1, gv); gl = fma((double)acc[r], k2, gl); }
           }
         }
         gv = wave_sum(gv);
@@ -817,7 +869,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     for (int i = wave; i < NT; i += NW) {
       const double s1 = mv_lower<NT>(Lb, mv, i, o);
       const double s2 = mv_lower_t<NT>(Wb, mv, i, o);
-      if (o.lk == 0) av[16 * i + o.lr] = s1 - J * s2;                       // av = mu (padded part 0)
+      if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s1 - J * s2);               // av = mu (padded part 0)
     }
     // (av is read after the barriers of the covariance loop)
     STAMP(14);
@@ -827,17 +879,17 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     // A-operand element [lr][4q + lk] of A^T(i, k) = L_ik (k < i), -J (L^-1)_ki^T (k > i), L_ii - J (L^-1)_ii^T (k = i),
     // without branches: one read from the tile that applies (L normal or L^-1 transposed) plus the diagonal L^-1 tile
     // scaled by -J or 0, so that the operand loads of the next step can be issued ahead
-    auto at_a = [&](int i, int k, int q) -> double {
+    auto at_a = [&](int i, int k, int q) -> real {
       const bool low = k <= i;
-      const double* t1 = low ? Lb + lt(i, k) * TS : Wb + lt(k, i) * TS;
-      const double v1 = t1[low ? o.rc[q] : o.cr[q]];
-      const double v2 = Wb[lt(i, i) * TS + o.cr[q]];
-      return fma(k == i ? -J : 0.0, v2, (low ? 1.0 : -J) * v1);
+      const real* t1 = low ? Lb + lt(i, k) * TS : Wb + lt(k, i) * TS;
+      const real v1 = t1[low ? o.rc[q] : o.cr[q]];
+      const real v2 = Wb[lt(i, i) * TS + o.cr[q]];
+      return (real)fma(k == i ? -J : 0.0, (double)v2, (low ? 1.0 : -J) * (double)v1);
     };
-    auto stage_row = [&](int i, double* Eb) {
+    auto stage_row = [&](int i, real* Eb) {
 #pragma unroll 1
       for (int l = NW - 1 - wave; l < NT; l += NW) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        v4r acc = {0, 0, 0, 0};
         acc = acc_run(acc, 0, NT, [&](int k, int q) { return at_a(i, k, q); },
                       [&](int k, int q) { return k >= l ? Cb[lt(k, l) * TS + o.cr[q]] : Cb[lt(l, k) * TS + o.rc[q]]; });
         st_tile(Eb + l * TS, o, acc);
@@ -846,27 +898,27 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
     stage_row(0, DCi);
     SYNC();
     constexpr int CPW = (NT + NW - 1) / NW;        // cov tiles of one tile row per wave
-    v4d covt[NT][CPW];
+    v4r covt[NT][CPW];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      double* Eb = (i & 1) ? DLi : DCi;
+      real* Eb = (i & 1) ? DLi : DCi;
 #pragma unroll
       for (int u = 0; u < CPW; ++u) {
       const int j = wave + u * NW;
-      covt[i][u] = v4d{0.0, 0.0, 0.0, 0.0};
+      covt[i][u] = v4r{0, 0, 0, 0};
       if (j <= i) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        v4r acc = {0, 0, 0, 0};
         acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
                       [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= -J * J;
+        for (int r = 0; r < 4; ++r) acc[r] = (real)(acc[r] * (-J * J));
         // B[kq][col] = A^T(j, l)[col][kq]: the same element function with the roles of the tile indices as for A
         acc = acc_run(acc, 0, NT, [&](int l, int q) { return Eb[l * TS + o.rc[q]]; },
                       [&](int l, int q) { return at_a(j, l, q); });
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
-          if (row == col) acc[r] += 1.0 / dv[row] + J;
+          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+          if (row == col) acc[r] = (real)(acc[r] + (1.0 / (double)dv[row] + J));
           if (row < N && col < N) {
             // (a diagonal tile is a full 16x16 accumulation: only its lower half is exported here, the upper half is
             //  mirrored from it below, so that cov is exactly symmetric like the general path's extraction)
@@ -884,7 +936,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       SYNC();
     }
     if (g.mu)
-      for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = av[t];
+      for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = (real)av[t];
     // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -892,15 +944,15 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       for (int u = 0; u < CPW; ++u) {
       const int j = wave + u * NW;
       if (j <= i) {
-        v4d t = covt[i][u];
+        v4r t = covt[i][u];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.lk + 4 * r, col = 16 * j + o.lr;
+          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
           if (row >= N || col >= N) {
             double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
             if (col < N && row == N) v = 1.0;
-            if (col < N && row == N + 1) v = av[col];
-            t[r] = v;
+            if (col < N && row == N + 1) v = (double)av[col];
+            t[r] = (real)v;
           }
         }
         st_tile(Lb + lt(i, j) * TS, o, t);
@@ -924,7 +976,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
         for (int e = tid; e < NT * NT * 256; e += NTH) {
           const int tt = e >> 8, i = tt / NT, j = tt - i * NT, rr = (e >> 4) & 15, cc = e & 15;
           const int row = 16 * i + rr, col = 16 * j + cc;
-          if (row < N && col < N) g.chol[((long)b * N + row) * N + col] = col <= row ? Lb[lt(i, j) * TS + swz(rr, cc)] : 0.0;
+          if (row < N && col < N) g.chol[((long)b * N + row) * N + col] = col <= row ? Lb[lt(i, j) * TS + swz(rr, cc)] : (real)0;
         }
       }
       if (g.basis) {
@@ -935,7 +987,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
       }
       if (g.logdet) {
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Lb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log((double)Lb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
         s = wave_sum(s);
         if (lane == 0) misc[16 + wave] = s;
         SYNC();
@@ -957,7 +1009,7 @@ __global__ __launch_bounds__(NTH) void small_fit_kernel(SmallArgs g) {
 
 template <int NT>
 static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
-  const size_t lds = (size_t)Layout<NT>::TOTAL * sizeof(double);
+  const size_t lds = Layout<NT>::BYTES;
   static bool configured = false;
   if (!configured) {
     BAYENS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_fit_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -971,6 +1023,7 @@ static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
   BAYENS_HIP(hipGetLastError());
 }
 
+#ifndef BAYENS_F32
 // ---- diagnostic: the 16x16 diagonal factorisation and the raw dependent-chain latencies it is made of, in isolation
 // (one workgroup of `waves` waves; wave 0 runs the measured sequence `reps` times, the others idle at a barrier or, with
 // variant bit 8, keep the matrix pipes busy).  out[0] = shader cycles per repetition.
@@ -978,9 +1031,7 @@ __global__ void diag_bench_kernel(int variant, int reps, double* out, double see
   __shared__ double T0[TS], T[TS], D[TS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Lane o;
-  o.lr = lane & 15; o.lk = lane >> 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { o.rc[q] = swz(o.lr, 4 * q + o.lk); o.cr[q] = swz(4 * q + o.lk, o.lr); }
+  lane_init(o, lane);
   if (wave == 0)
     for (int e = lane; e < 256; e += 64) {
       const int r = e >> 4, c = e & 15;
@@ -1017,7 +1068,7 @@ __global__ void diag_bench_kernel(int variant, int reps, double* out, double see
     for (int rep = 0; rep < reps; ++rep) {
       if (kind == 0) {                     // the factorisation as the fit uses it (tile restored every time)
         for (int e = lane; e < 256; e += 64) T[e] = T0[e];
-        diag16(ld_tile_sym(T, o), T, D, lane, 0, bad, o);
+        diag16(ld_tile_sym64(T, o), T, D, lane, 0, bad, o);
       } else if (kind == 1) {              // 64 dependent v_fma_f64
 #pragma unroll
         for (int i = 0; i < 64; ++i) x = fma(x, y, 1e-3);
@@ -1060,6 +1111,7 @@ void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* ou
   hipLaunchKernelGGL(diag_bench_kernel, dim3(1), dim3(64 * waves), 0, stream, variant, reps, out_dev, 0.0);
   BAYENS_HIP(hipGetLastError());
 }
+#endif
 
 bool small_fit_supported(int N, int R) { return N >= 1 && N <= SMALL_MAX_N && R >= 1; }
 
@@ -1072,5 +1124,4 @@ void small_fit(hipStream_t stream, const SmallArgs& g, int n_cus) {
 }
 
 }  // namespace smalln
-}  // namespace bayens
-#endif
+}  // namespace BAYENS_NS

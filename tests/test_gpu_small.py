@@ -102,3 +102,20 @@ def test_reduced_export_rejects_large_members(ctx):
     with pytest.raises(L.BayensError) as e:
         ctx.gp_fit_batch_reduced(X, np.zeros((1, 95)), np.ones((1, 95)), 1)
     assert e.value.code == -1
+
+
+def test_fp32_instance_at_batch_scale(ctx):
+    """The fp32 build of the fused kernel (fp32 tiles and MFMA products; diagonal factorisations, squared distances,
+    vectors and reductions in fp64): B = 2048 members of N = 86 against the fp64 oracle at BASELINE's 1e-3."""
+    B, N, R, T = 2048, 86, 8, 2
+    X, y, nu = _batch(B, N, R, seed=9)
+    out = ctx.gp_fit_batch(X, y, nu, T, dtype=np.float32, want_loss=True)
+    assert not out["info"].any() and out["cov"].dtype == np.float32
+    assert np.isfinite(out["cov"]).all() and np.array_equal(out["cov"], np.swapaxes(out["cov"], 1, 2))
+    with threadpool_limits(1):
+        for m in list(range(0, B, 256)) + [B - 1]:
+            mo, co, ho, lo = go.gp_fit(X[m], y[m], nu[m], T, loss_every=25)
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m].astype(np.float64), mo) < 1e-3 and relerr(out["cov"][m].astype(np.float64), co) < 1e-3, m
+            assert relerr(out["chol"][m].astype(np.float64), Lc) < 1e-3 and relerr(out["hyp"][m], ho) < 1e-3, m
+            assert abs(out["logdet"][m] - ld) < 1e-3 * abs(ld) and np.allclose(out["loss"][m], lo, rtol=1e-3), m
