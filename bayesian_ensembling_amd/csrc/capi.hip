@@ -2,6 +2,7 @@
 // entry points and the RCCL all-gather.  No torch types, no exceptions across the boundary.
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -656,6 +657,190 @@ struct FactorSolve {
   Mat rows() const { return w.T1; }
   void solve() { trsm_rlt(*c->prims, B, LEAF, Np, w.T2, w.invL, w.inv_stride(), w.T1); }
 };
+
+// The two-right-hand-side case (the log-likelihood basis L^-1 1, L^-1 mu) straight from the COMPACT factor, in one
+// launch and one pass over its lower triangle: workgroup (J, m) owns the 64 rows J of member m.  It inverts its own
+// diagonal block in LDS and forms M = L_JJ^-1 L_J,J-1, then walks the blocks k < J - 1 of its block row (fetched a
+// block ahead; the factor does not depend on the chain), multiplying each by z_k as soon as workgroup (k, m) has
+// published it, prepares v = L_JJ^-1 (b_J - sum_{k<J-1} L_Jk z_k), and publishes
+//   z_J = v - M z_J-1
+// - the only work between seeing z_J-1 and publishing z_J is one 64 x 64 product done by ONE wave per right-hand side
+// from registers (lane = row, z_J-1 broadcast lane by lane with v_readlane): no LDS, no barrier on the chain.
+// Publication is the data itself: the exchange buffer starts as all-ones words (a NaN no arithmetic produces) and a
+// consumer polls the word it needs with device-scope atomic loads, so there is no separate flag round trip.  Block
+// ids are J-major: a workgroup only ever waits for workgroups with smaller ids, which the dispatcher has started
+// before it, so the chain cannot deadlock however many workgroups are resident; a poll that sees nothing for
+// CHAIN_POLL_LIMIT tries gives up (err = 1) instead of spinning for ever.
+constexpr int CHAIN_B = 64, CHAIN_LS = 65, CHAIN_POLL_LIMIT = 1 << 21;
+constexpr unsigned long long CHAIN_EMPTY = ~0ull;
+
+__device__ __forceinline__ double chain_readlane(double v, int src_lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+// polls one published word; returns false when the producer never showed up
+__device__ __forceinline__ bool chain_poll(const double* src, double& v) {
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long bits = CHAIN_EMPTY;
+  for (int tries = 0; tries < CHAIN_POLL_LIMIT; ++tries) {
+    bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bits != CHAIN_EMPTY) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  v = __longlong_as_double((long long)bits);
+  return bits != CHAIN_EMPTY;
+}
+
+__global__ __launch_bounds__(256) void fwd2_chain_kernel(int B, int N, int nblk, const double* __restrict__ chol,
+                                                         const double* __restrict__ mu, double* zbuf,
+                                                         double* __restrict__ basis, int* err) {
+  __shared__ double Ds[CHAIN_B * CHAIN_LS];      // the diagonal block, its inverse, then M
+  __shared__ double Ls[CHAIN_B * CHAIN_LS];      // the off-diagonal block being multiplied
+  __shared__ double zs[2 * CHAIN_B];
+  __shared__ double red[4 * 2 * CHAIN_B];
+  __shared__ int dead;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int J = blockIdx.x / B, m = blockIdx.x - J * B;
+  const int r0 = J * CHAIN_B;
+  const double* Lm = chol + (size_t)m * N * N;
+  double* zm = zbuf + (size_t)m * nblk * 2 * CHAIN_B;
+  double regs[16];
+  // rows r0 + 16 wave + i, column 64 k + lane of the factor: zero above the diagonal, identity in the padding
+  auto load_block = [&](int k) {
+    const int col = k * CHAIN_B + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + 16 * wave + i;
+      double v = 0.0;
+      if (row < N && col <= row) v = Lm[(size_t)row * N + col];
+      else if (row >= N && col == row) v = 1.0;
+      regs[i] = v;
+    }
+  };
+  auto store_block = [&](double* dst) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[(16 * wave + i) * CHAIN_LS + lane] = regs[i];
+  };
+  // red <- partial sums over this wave's 16 columns of (coefficients a[i]) x (the two vectors in zs); lane = row
+  auto partial = [&](const double* a) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0 = fma(a[i], zs[16 * wave + i], s0);
+      s1 = fma(a[i], zs[CHAIN_B + 16 * wave + i], s1);
+    }
+    red[(wave * 2 + 0) * CHAIN_B + lane] = s0;
+    red[(wave * 2 + 1) * CHAIN_B + lane] = s1;
+  };
+  auto reduced = [&]() {   // threads < 128: vector `wave`, row `lane`
+    return (red[(0 * 2 + wave) * CHAIN_B + lane] + red[(1 * 2 + wave) * CHAIN_B + lane]) +
+           (red[(2 * 2 + wave) * CHAIN_B + lane] + red[(3 * 2 + wave) * CHAIN_B + lane]);
+  };
+
+  if (t == 0) dead = 0;
+  load_block(J);
+  store_block(Ds);
+  if (J > 0) load_block(J - 1);                  // in flight while the diagonal block is inverted
+  __syncthreads();
+  if (wave == 0) {
+    // X = L_JJ^-1 in place, column `lane`: X_i = (e_i - sum_{k<i} L_ik X_k) / L_ii.  Row i of L is read before it is
+    // overwritten (one wave, program order); X_k = 0 above the diagonal, so every lane runs the same loop.
+    for (int i = 0; i < CHAIN_B; ++i) {
+      double s0 = 0.0, s1 = 0.0;
+      int k = 0;
+      for (; k + 1 < i; k += 2) {
+        s0 = fma(Ds[i * CHAIN_LS + k], Ds[k * CHAIN_LS + lane], s0);
+        s1 = fma(Ds[i * CHAIN_LS + k + 1], Ds[(k + 1) * CHAIN_LS + lane], s1);
+      }
+      if (k < i) s0 = fma(Ds[i * CHAIN_LS + k], Ds[k * CHAIN_LS + lane], s0);
+      const double d = Ds[i * CHAIN_LS + i];
+      Ds[i * CHAIN_LS + lane] = ((i == lane ? 1.0 : 0.0) - (s0 + s1)) / d;
+    }
+  }
+  if (J > 0) store_block(Ls);                    // L_J,J-1
+  __syncthreads();
+  double dinv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dinv[i] = Ds[lane * CHAIN_LS + 16 * wave + i];
+  if (J > 0) {
+    if (J > 1) load_block(0);
+    // M = L_JJ^-1 L_J,J-1: row `lane`, this wave's 16 columns (L_JJ^-1 is lower triangular: k <= lane)
+    double mrow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mrow[i] = 0.0;
+    for (int k = 0; k < CHAIN_B; ++k) {
+      const double d = Ds[lane * CHAIN_LS + k];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mrow[i] = fma(d, Ls[k * CHAIN_LS + 16 * wave + i], mrow[i]);
+    }
+    __syncthreads();                             // every wave has read the inverse: M replaces it
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ds[lane * CHAIN_LS + 16 * wave + i] = mrow[i];
+  }
+
+  double acc = 0.0;
+  for (int k = 0; k + 1 < J; ++k) {
+    __syncthreads();                             // Ls, zs and red of the previous block are done with
+    store_block(Ls);
+    if (k + 2 < J) load_block(k + 1);
+    if (t < 128) {
+      double v;
+      if (!chain_poll(zm + (size_t)(k * 2 + wave) * CHAIN_B + lane, v)) dead = 1;
+      zs[wave * CHAIN_B + lane] = v;
+    }
+    __syncthreads();
+    if (dead) {
+      if (t == 0) *err = 1;
+      return;
+    }
+    double a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = Ls[lane * CHAIN_LS + 16 * wave + i];
+    partial(a);
+    __syncthreads();
+    if (t < 128) acc += reduced();
+  }
+  __syncthreads();
+  if (t < 128) {
+    const int row = r0 + lane;
+    const double b = row < N ? (wave == 0 ? 1.0 : mu[(size_t)m * N + row]) : 0.0;
+    zs[wave * CHAIN_B + lane] = b - acc;
+  }
+  __syncthreads();
+  partial(dinv);
+  __syncthreads();
+  if (t >= 128) return;
+  // the chain step: one wave per right-hand side, registers only
+  double z = reduced();
+  if (J > 0) {
+    double mfull[CHAIN_B];
+#pragma unroll
+    for (int c = 0; c < CHAIN_B; ++c) mfull[c] = Ds[lane * CHAIN_LS + c];
+    double zp;
+    const bool ok = chain_poll(zm + (size_t)((J - 1) * 2 + wave) * CHAIN_B + lane, zp);
+    if (!__all(ok)) {
+      if (lane == 0) *err = 1;
+      return;
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int c = 0; c < CHAIN_B; c += 4) {
+      s0 = fma(mfull[c], chain_readlane(zp, c), s0);
+      s1 = fma(mfull[c + 1], chain_readlane(zp, c + 1), s1);
+      s2 = fma(mfull[c + 2], chain_readlane(zp, c + 2), s2);
+      s3 = fma(mfull[c + 3], chain_readlane(zp, c + 3), s3);
+    }
+    z -= (s0 + s1) + (s2 + s3);
+  }
+  const int row = r0 + lane;
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(zm + (size_t)(J * 2 + wave) * CHAIN_B + lane);
+  unsigned long long bits = (unsigned long long)__double_as_longlong(z);
+  if (bits == CHAIN_EMPTY) bits = 0x7ff8000000000000ull;     // (an input NaN with that payload: publish a plain NaN)
+  __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (row < N) basis[((size_t)m * 2 + wave) * N + row] = z;
+}
 }  // namespace
 
 int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const double* mu, const double* cov_chol,
@@ -669,15 +854,23 @@ int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const do
     const double* dld = st.in(logdet, (size_t)B);
     const double* dobs = st.in(obs, (size_t)R_obs * N);
     double* dll = st.out(ll_mean, (size_t)B * N);
-    // the basis (L^-1 1, L^-1 mu) from the factor: two rows through the blocked solve, then the basis path
-    FactorSolve fs(c, B, N, dch);
-    c->prims->solve_rows_set(B, N, fs.Np, 2, 1, nullptr, 0, dmu, fs.rows());
-    fs.solve();
-    double* dots = c->small_scratch((size_t)B * 3 + 2 + (size_t)B * 2 * N);
-    double* basis = dots + (size_t)B * 3 + 2;
-    c->prims->basis_rows_get(B, N, fs.Np, fs.rows(), basis);
+    // the basis (L^-1 1, L^-1 mu) from the compact factor in one chained launch, then the basis path
+    const int nblk = (N + CHAIN_B - 1) / CHAIN_B;
+    const size_t n_z = (size_t)B * nblk * 2 * CHAIN_B;
+    double* dots = c->small_scratch((size_t)B * 3 + 4 + (size_t)B * 2 * N + n_z);
+    double* basis = dots + (size_t)B * 3 + 4;
+    double* zbuf = basis + (size_t)B * 2 * N;
+    int* derr = reinterpret_cast<int*>(dots + (size_t)B * 3 + 2);
+    BAYENS_HIP(hipMemsetAsync(derr, 0, sizeof(int), c->stream));
+    BAYENS_HIP(hipMemsetAsync(zbuf, 0xFF, n_z * sizeof(double), c->stream));
+    hipLaunchKernelGGL(fwd2_chain_kernel, dim3((unsigned)(nblk * B)), dim3(256), 0, c->stream, B, N, nblk, dch, dmu, zbuf, basis,
+                       derr);
+    BAYENS_HIP(hipGetLastError());
     c->prims->loglik_rows_basis(B, N, R_obs, basis, dld, dobs, dll, dots);
+    int herr = 0;
+    BAYENS_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();
+    if (herr) return fail(c, BAYENS_E_INTERNAL, "loglik_rows: the substitution chain stalled");
     return 0;
   });
 }
@@ -829,6 +1022,45 @@ namespace {
 // factors); the M(M-1)/2 polar iterations are dealt over the ranks of the communicator by anchor member i (i mod
 // nranks: the batches of an anchor have M-1-i pairs, so interleaving balances the work), each rank fills its part of
 // the nuclear-norm table and one ncclAllReduce (sum, M*M doubles) completes it everywhere.
+// v_b <- v_b / ||v_b||, norm[b] = ||v_b|| (one workgroup per member)
+__global__ __launch_bounds__(256) void vec_normalise_kernel(int n, double* v, double* norm) {
+  __shared__ double red[256];
+  double* x = v + (size_t)blockIdx.x * n;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) s += x[t] * x[t];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  const double nrm = sqrt(red[0]);
+  const double r = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) x[t] *= r;
+  if (threadIdx.x == 0) norm[blockIdx.x] = nrm;
+}
+
+// lam[b] <- ||A^T A v|| after `steps` normalised power steps from v (A lower triangular, zeros above): an estimate FROM
+// BELOW of the largest eigenvalue of A_b^T A_b.  v [nb][n] is overwritten, y [nb][n] scratch, ones [nb][n] = 1.
+void tri_power(HipPrims& P, hipStream_t stream, int nb, int n, Mat A, double* v, double* y, const double* ones, double* lam,
+               int steps) {
+  for (int it = 0; it < steps; ++it) {
+    P.resid(nb, n, A, v, nullptr, y);                 // y = A v
+    P.lt_dvec(nb, n, A, y, ones, 1.0, 0.0, v);        // v = A^T y
+    hipLaunchKernelGGL(vec_normalise_kernel, dim3(nb), dim3(256), 0, stream, n, v, lam);
+    BAYENS_HIP(hipGetLastError());
+  }
+}
+
+// packed[p] (pairs i < j in row-major order) -> table[i][j]
+__global__ void scatter_pairs_kernel(int M, int n_pairs, const double* packed, double* table) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  int i = 0, first = 0;                     // first = index of pair (i, i + 1)
+  while (first + (M - 1 - i) <= p) { first += M - 1 - i; ++i; }
+  table[(size_t)i * M + (i + 1 + p - first)] = packed[p];
+}
+
 int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const double* chol, const double* sd,
                    double* w, double* D, bool sharded) {
   return guarded(c, [&]() {
@@ -863,18 +1095,92 @@ int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const
     double* rel = st.scratch<double>((size_t)M);
     P.dot_all(M, Np, Lp, Lp, tr);                      // tr S_i = ||L_i||_F^2 (+ padding)
     P.pair_terms(M, N, dmu, nullptr, gap, nullptr);
-    // nuc[M*M] is followed by one more double: the number of anchors whose polar iteration did not converge (summed
+    // The interval of every factor's singular values, once per member (a few fit iterations' worth of work for all M):
+    //   rigorous:  hi_m = sqrt(||L||_1 ||L||_inf) >= sigma_max(L_m),   lo_m = 1 / sqrt(||L^-1||_1 ||L^-1||_inf) <= sigma_min(L_m);
+    //   estimated: smax_m, smin_m from W2_POWER_STEPS power steps on L^T L and L^-T L^-1 (the explicit inverse is there
+    //              anyway), which approach the true values from inside the interval.
+    // A pair's product L_j^T L_i has its singular values in [smin_i smin_j, smax_i smax_j]: the polar iteration starts from
+    // X_0 = M / min(||M||_F, 1.21 smax_i smax_j, hi_i hi_j) and from the lower bound ell0 = smin_i smin_j / (4 x that
+    // scale) instead of a blanket 1e-7 - on posterior covariances that is one of its five steps.  The estimates only
+    // steer the weights; what ends the iteration is the size of its steps (polar_nuclear), and an ell0 that is too
+    // optimistic delays singular values whose share of the nuclear norm is below ell0 itself.
+    constexpr int W2_POWER_STEPS = 12;
+    std::vector<double> hi(M, 0.0), lo(M, 0.0), smax(M, 0.0), smin(M, 0.0);
+    {
+      double* bounds = st.scratch<double>((size_t)M * 6);
+      double* vec = st.scratch<double>((size_t)M * Np * 3);
+      double *v = vec, *y = vec + (size_t)M * Np, *ones = vec + (size_t)M * Np * 2;
+      std::vector<double> h0((size_t)M * Np), h1((size_t)M * Np, 1.0);
+      unsigned long long z = 0x9E3779B97F4A7C15ull;
+      for (auto& x : h0) {                             // fixed pseudo-random start: every component of both signs
+        z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+        x = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 0.75;
+      }
+      BAYENS_HIP(hipMemsetAsync(bounds, 0, (size_t)M * 6 * sizeof(double), c->stream));
+      BAYENS_HIP(hipMemcpyAsync(ones, h1.data(), h1.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      BAYENS_HIP(hipMemcpyAsync(v, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      P.tri_absnorms(M, Np, Lp, bounds);
+      tri_power(P, c->stream, M, Np, Lp, v, y, ones, bounds + (size_t)M * 4, W2_POWER_STEPS);
+      P.tri_inv64(M, Np, Lp, ws.invL, ws.inv_stride(), ws.info);
+      P.identity(M, Np, ws.T2);
+      trsm_rln(P, M, Np, Np, Lp, ws.invL, ws.inv_stride(), ws.T2, true);
+      P.tri_absnorms(M, Np, ws.T2, bounds + (size_t)M * 2);
+      BAYENS_HIP(hipMemcpyAsync(v, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      tri_power(P, c->stream, M, Np, ws.T2, v, y, ones, bounds + (size_t)M * 5, W2_POWER_STEPS);
+      std::vector<double> hb((size_t)M * 6);
+      BAYENS_HIP(hipMemcpyAsync(hb.data(), bounds, hb.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      BAYENS_HIP(hipStreamSynchronize(c->stream));
+      for (int m = 0; m < M; ++m) {
+        hi[m] = std::sqrt(hb[(size_t)m * 2] * hb[(size_t)m * 2 + 1]);
+        lo[m] = 1.0 / std::sqrt(hb[(size_t)(M + m) * 2] * hb[(size_t)(M + m) * 2 + 1]);
+        smax[m] = std::fmin(hi[m], 1.1 * std::sqrt(hb[(size_t)M * 4 + m]));
+        smin[m] = std::fmax(lo[m], 1.0 / std::sqrt(hb[(size_t)M * 5 + m]));
+      }
+    }
+    const bool trace = getenv("BAYENS_W2_TRACE") != nullptr;
+    // nuc[M*M] is followed by one more double: the number of batches whose polar iteration did not converge (summed
     // over the ranks by the same all-reduce, so that every rank takes the same decision)
     BAYENS_HIP(hipMemsetAsync(nuc, 0, ((size_t)M * M + 1) * sizeof(double), c->stream));
+    // The M(M-1)/2 pairs in row-major order (i < j), M slots at a time: every batch of the iteration is full (the last
+    // one excepted) whichever anchors its pairs belong to - only the products L_j^T L_i that fill the slots are issued
+    // per anchor.  Batches are dealt over the ranks.
+    const int n_pairs = M * (M - 1) / 2;
+    std::vector<int> pi((size_t)n_pairs), pj((size_t)n_pairs);
+    std::vector<double> hcap((size_t)n_pairs > 0 ? n_pairs : 1);
+    for (int i = 0, p = 0; i + 1 < M; ++i)
+      for (int j = i + 1; j < M; ++j, ++p) { pi[p] = i; pj[p] = j; hcap[p] = smax[i] * smax[j]; }
+    double* packed = st.scratch<double>((size_t)n_pairs + 1);
+    double* dcap = st.scratch<double>((size_t)n_pairs + 1);
+    BAYENS_HIP(hipMemsetAsync(packed, 0, ((size_t)n_pairs + 1) * sizeof(double), c->stream));
+    BAYENS_HIP(hipMemcpyAsync(dcap, hcap.data(), (size_t)n_pairs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
     double not_converged = 0.0;
-    for (int i = 0; i + 1 < M; ++i) {
-      if (i % nranks != rank) continue;
-      const int nb = M - 1 - i;
+    for (int p0 = 0, chunk = 0; p0 < n_pairs; p0 += M, ++chunk) {
+      if (chunk % nranks != rank) continue;
+      const int nb = std::min(M, n_pairs - p0);
       FitWorkspace wsi = ws;
       wsi.nb = nb;
-      const int its = nuclear_norms(P, wsi, nb, Mat{Lpad + (size_t)i * Np * Np, Np, 0},
-                                    Mat{Lpad + (size_t)(i + 1) * Np * Np, Np, (long)Np * Np}, nuc + (size_t)i * M + i + 1, rel);
+      double ell0 = 1.0;
+      for (int s0 = 0; s0 < nb;) {                     // one product launch per run of slots that share the anchor
+        const int i = pi[p0 + s0];
+        int len = 1;
+        while (s0 + len < nb && pi[p0 + s0 + len] == i) ++len;
+        const int j0 = pj[p0 + s0];
+        P.gemm(len, Np, Np, Np, 1.0, Mat{Lpad + (size_t)j0 * Np * Np, Np, (long)Np * Np}, Mat{Lpad + (size_t)i * Np * Np, Np, 0},
+               0.0, Mat{ws.W0.p + (size_t)s0 * ws.W0.stride, ws.W0.ld, ws.W0.stride}, GEMM_TA | GEMM_KTRIM_TN_LOWER, 0.0);
+        for (int q = 0; q < len; ++q) ell0 = std::fmin(ell0, 0.25 * (smin[i] * smin[j0 + q]) / (smax[i] * smax[j0 + q]));
+        s0 += len;
+      }
+      const bool bracketed = ell0 > 1e-7 && ell0 < 1.0;      // (NaN / non-finite brackets fall back to the blanket bound)
+      if (!bracketed) ell0 = 1e-7;
+      const int its = polar_nuclear(P, wsi, nb, packed + p0, rel, ell0, 1e-7, 16, bracketed ? dcap + p0 : nullptr, 1.0,
+                                    bracketed ? 1e-12 : 0.0);
+      if (trace) fprintf(stderr, "w2_single: pairs %d..%d, ell0 %.3g, %d steps\n", p0, p0 + nb - 1, ell0, its);
       if (its <= 0) not_converged += 1.0;
+    }
+    if (n_pairs > 0) {
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, M, n_pairs, packed, nuc);
+      BAYENS_HIP(hipGetLastError());
     }
     if (sharded) {
       BAYENS_HIP(hipMemcpyAsync(nuc + (size_t)M * M, &not_converged, sizeof(double), hipMemcpyHostToDevice, c->stream));

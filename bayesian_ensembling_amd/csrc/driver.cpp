@@ -273,13 +273,18 @@ void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* cho
 }
 
 int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel, double ell0,
-                  double tol, int max_iters) {
+                  double tol, int max_iters, const double* cap, double cap_scale) {
+  // M = L_j^T L_i  (both lower triangular: k >= max(i0, j0))
+  P.gemm(nb, ws.Np, ws.Np, ws.Np, 1.0, Lj, Li, 0.0, ws.W0, GEMM_TA | GEMM_KTRIM_TN_LOWER, 0.0);
+  return polar_nuclear(P, ws, nb, nuc, scratch_rel, ell0, tol, max_iters, cap, cap_scale, 0.0);
+}
+
+int polar_nuclear(Prims& P, FitWorkspace& ws, int nb, double* nuc, double* scratch_rel, double ell0, double tol,
+                  int max_iters, const double* cap, double cap_scale, double ell_done) {
   const int Np = ws.Np;
   const long is = ws.inv_stride();
   Mat M = ws.W0, X = ws.Lb, Z = ws.Cb, T = ws.T1;
-  // M = L_j^T L_i  (both lower triangular: k >= max(i0, j0))
-  P.gemm(nb, Np, Np, Np, 1.0, Lj, Li, 0.0, M, GEMM_TA | GEMM_KTRIM_TN_LOWER, 0.0);
-  P.frob_normalise(nb, Np, M, X);
+  P.frob_normalise(nb, Np, M, X, cap, cap_scale);
   double ell = ell0;
   std::vector<double> rel(nb);
   int it = 0;
@@ -297,12 +302,21 @@ int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nu
     trsm_rlt(P, nb, Np, Np, Z, ws.invC, is, T);
     trsm_rln(P, nb, Np, Np, Z, ws.invC, is, T, false);
     P.axpby_rel(nb, Np, b / c, X, a - b / c, T, scratch_rel);
+    // With weights this close to Halley's (3, 1, 3) the step is cubically convergent for every singular value near 1,
+    // wherever the true spectrum lies, and the size of the step IS the error it removes: `tol` applies.  While the
+    // weights are still the aggressive ones of a small ell a singular value near 1 may be thrown back, so only an
+    // (almost) vanishing step counts as convergence there.
+    const bool halley = 1.0 - ell < 0.05;
     ell = ell * (a + b * l2) / (1.0 + c * l2);
     if (ell > 1.0) ell = 1.0;
     P.read_back(scratch_rel, rel.data(), nb);
     double worst = 0.0;
     for (double r : rel) worst = r > worst || r != r ? r : worst;
-    if (worst < tol) { ++it; converged = true; break; }
+    if (worst < (halley ? tol : (tol < 1e-13 ? tol : 1e-13))) { ++it; converged = true; break; }
+    // ell is a lower bound of every singular value of the new X when ell0 was one of X_0: once it is within ell_done
+    // of 1 the polar factor is too - provided the step just taken was a small one, i.e. nothing of weight lay below
+    // the caller's ell0 and is still on its way.
+    if (ell_done > 0.0 && 1.0 - ell <= ell_done && worst < 1e-3) { ++it; converged = true; break; }
   }
   P.dot_all(nb, Np, X, M, nuc);    // ||M||_* = tr(U^T M)
   return converged ? it : -it;     // a NaN step or a pair still moving after max_iters: the caller must not use nuc

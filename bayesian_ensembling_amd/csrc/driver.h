@@ -76,8 +76,20 @@ void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* cho
 // every pair moved by less than tol.  Lj: the nb factors L_j (padded, lower).  Uses ws.W0 (M), ws.Lb (X), ws.Cb (Z),
 // ws.T1 (T).  nuc: device [nb], scratch_rel: device [nb].  Returns the number of iterations taken, NEGATED when the
 // iteration did not converge (a pair still moved by >= tol after max_iters, or a step produced NaN).
+// ell0: a lower bound of sigma_min(X_0) (a too large value only costs speed: the stopping test does not use it).
+// cap / cap_scale: optional device array [nb] with cap_scale * cap[b] >= ||L_j^T L_i||_2; X_0 is scaled by the smaller of
+// it and the Frobenius norm.  tol: the iteration converges cubically and a step moves X by its distance from the polar
+// factor, so a relative step d leaves an error of about (sqrt(N) d)^3 / 4 - the default stops at 1e-17 for N = 2000
+// without spending a whole step on confirming it.
 int nuclear_norms(Prims& P, FitWorkspace& ws, int nb, Mat Li, Mat Lj, double* nuc, double* scratch_rel,
-                  double ell0 = 1e-7, double tol = 1e-13, int max_iters = 16);
+                  double ell0 = 1e-7, double tol = 1e-7, int max_iters = 16, const double* cap = nullptr,
+                  double cap_scale = 0.0);
+// The iteration alone, on nb products the caller has already placed in the slots of ws.W0 (so that one batch can mix
+// pairs of several anchors): nuc[b] = ||W0_b||_*.
+// ell_done > 0: also stop once the bound ell carried along from ell0 is within ell_done of 1 (see the definition).
+int polar_nuclear(Prims& P, FitWorkspace& ws, int nb, double* nuc, double* scratch_rel, double ell0 = 1e-7,
+                  double tol = 1e-7, int max_iters = 16, const double* cap = nullptr, double cap_scale = 0.0,
+                  double ell_done = 0.0);
 
 // Algorithmic flop of one member fit (2 flop per FMA, triangular structure exploited).
 double fit_flops(int N, int R, int n_iters);

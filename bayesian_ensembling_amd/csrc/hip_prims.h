@@ -113,7 +113,7 @@ struct HipPrims : Prims {
   void extract_vec(int nb, int N, int Np, const real* src, real* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;
-  void frob_normalise(int nb, int n, Mat M, Mat X) override;
+  void frob_normalise(int nb, int n, Mat M, Mat X, const double* cap = nullptr, double cap_scale = 0.0) override;
   void axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) override;
   void dot_all(int nb, int n, Mat A, Mat B, double* out) override;
   void read_back(const double* dev, double* host, int n) override;
@@ -128,6 +128,8 @@ struct HipPrims : Prims {
   // diagonal blocks, right-hand-side rows (mode 0: x - mu, mode 1: the pair (1, mu)), log-density of solved rows
   void pad_lower(int nb, int N, int Np, const double* src, Mat dst);
   void tri_inv64(int nb, int Np, Mat Lp, real* inv, long inv_stride, int* info);
+  // out[b][0] = max column sum, out[b][1] = max row sum of |A_b| over the lower triangle (out zeroed by the caller)
+  void tri_absnorms(int nb, int n, Mat A, double* out);
   void solve_rows_set(int nb, int N, int Np, int nrows, int mode, const double* x, long x_stride, const double* mu, Mat rows);
   void rows_logprob(int nb, int N, int nrows, Mat rows, const double* logdet, double* out);
   void fill_random(double* dst, size_t count, unsigned seed);           // uniform [-1, 1), diagnostics only

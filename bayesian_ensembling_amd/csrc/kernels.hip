@@ -26,6 +26,11 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;   // valid in lane 0
 }
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;   // valid in lane 0
+}
 
 // K(r2) and dK/dlengthscale for the three stationary kernels (GPflow 2.1.5 forms; Matern-3/2 is the only
 // one the reference instantiates, models.py:186).
@@ -1176,6 +1181,48 @@ __global__ void tile_finish_kernel(int mode, int ntiles, const double* part, dou
   if (threadIdx.x == 0) out[b] = mode == 0 ? sqrt(red[0][0]) : (mode == 1 ? sqrt(red[0][0] / red[1][0]) : red[0][0]);
 }
 
+// norms[b] <- min(norms[b], cap_scale * cap[b]): a tighter bound of the two-norm than the Frobenius norm, when the caller has one
+__global__ void cap_norms_kernel(int nb, double* norms, const double* cap, double cap_scale) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const double c = cap_scale * cap[b];
+  if (c > 0.0 && c < norms[b]) norms[b] = c;
+}
+
+// max column sum / max row sum of |A| over the lower triangle of every member: the brackets
+//   ||A||_2 <= sqrt(||A||_1 ||A||_inf)  of the polar iteration's starting interval.  out[b][0..1], zeroed by the caller
+// (non-negative doubles order like their bit patterns, so the maximum is an integer atomicMax).
+__global__ __launch_bounds__(256) void tri_absnorms_kernel(int n, Mat A, double* out) {
+  __shared__ double red[4];
+  const int b = blockIdx.z, which = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const real* pa = A.p + b * A.stride;
+  double best = 0.0;
+  if (which == 0) {                       // column sums: one thread per column, adjacent threads adjacent columns
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n) {
+      double s = 0.0;
+      for (int r = c; r < n; ++r) s += fabs((double)pa[(long)r * A.ld + c]);
+      best = s;
+    }
+  } else {                                // row sums: one wave per row, 64 rows per workgroup
+    for (int q = 0; q < 64; ++q) {
+      const int r = blockIdx.x * 256 + wave * 64 + q;
+      if (r >= n) break;
+      double s = 0.0;
+      for (int c = lane; c <= r; c += 64) s += fabs((double)pa[(long)r * A.ld + c]);
+      s = wave_sum(s);
+      best = s > best ? s : best;
+    }
+  }
+  best = wave_max(best);
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(out + (long)b * 2 + which), (unsigned long long)__double_as_longlong(m));
+  }
+}
+
 __global__ void scale_by_norm_kernel(int n, Mat M, Mat X, const double* norms) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -1534,11 +1581,16 @@ void HipPrims::hyp_out(int nb, const double* ustate, double* hyp) {
   hipLaunchKernelGGL(hyp_out_kernel, dim3((nb + 63) / 64), dim3(64), 0, stream, nb, ustate, hyp);
   LAUNCH_CHECK();
 }
-void HipPrims::frob_normalise(int nb, int n, Mat M, Mat X) {
+void HipPrims::tri_absnorms(int nb, int n, Mat A, double* out) {
+  hipLaunchKernelGGL(tri_absnorms_kernel, dim3((n + 255) / 256, 2, nb), dim3(256), 0, stream, n, A, out);
+  LAUNCH_CHECK();
+}
+void HipPrims::frob_normalise(int nb, int n, Mat M, Mat X, const double* cap, double cap_scale) {
   ensure_scratch(nb, n, 4);
   double* norms = ssq;    // [nb] (ssq holds >= nb * n doubles)
   hipLaunchKernelGGL(tile_reduce_kernel, tile_grid(n, nb), dim3(256), 0, stream, 0, M, Mat{nullptr, 0, 0}, 0.0, 0.0, gpart);
   hipLaunchKernelGGL(tile_finish_kernel, dim3(nb), dim3(256), 0, stream, 0, (n / 64) * (n / 64), gpart, norms);
+  if (cap) hipLaunchKernelGGL(cap_norms_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, norms, cap, cap_scale);
   hipLaunchKernelGGL(scale_by_norm_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, M, X, norms);
   LAUNCH_CHECK();
 }

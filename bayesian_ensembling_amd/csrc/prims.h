@@ -152,7 +152,7 @@ struct Prims {
 
   // ---- pieces of the full-covariance Wasserstein distance (polar iteration on L_j^T L_i) ----
   // X = M / ||M||_F per member (Frobenius norms are not returned)
-  virtual void frob_normalise(int nb, int n, Mat M, Mat X) = 0;
+  virtual void frob_normalise(int nb, int n, Mat M, Mat X, const double* cap = nullptr, double cap_scale = 0.0) = 0;
   // X <- a X + b T ; rel[b] = ||X_new - X_old||_F / ||X_new||_F   (rel: device array [nb])
   virtual void axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) = 0;
   // out[b] = sum_ij A_ij B_ij over the n x n matrices (out: device array [nb])

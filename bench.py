@@ -218,8 +218,11 @@ class FieldWorkload:
     fused small-member kernel over the B = M * G fits (reduced export: mu, diag(cov), basis, logdet; or the full
     covariance) -> per-gridpoint LogLikelihoodWeight rows -> normalisation over the members -> barycentre per point."""
 
-    def __init__(self, ctx, M, G, N, R, T, export, R_obs=3, seed=0xC5):
+    def __init__(self, ctx, M, G, N, R, T, export, R_obs=3, seed=0xC5, f32=False):
         self.ctx, self.M, self.G, self.N, self.R, self.T, self.export, self.R_obs = ctx, M, G, N, R, T, export, R_obs
+        self.f32 = f32
+        if f32:
+            export = self.export = "full"          # the fp32 entry point exports the covariance (no reduced fp32 entry)
         B = self.B = M * G
         rng = np.random.default_rng(seed)
         tau = np.linspace(0.0, 1.0, N)
@@ -229,14 +232,18 @@ class FieldWorkload:
         obs = 1.5 * loc[0] * tau ** 2 + 0.036 * rng.standard_normal((G, R_obs, N)).cumsum(axis=2)
         data = data.reshape(B, R, N)
         X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
-        self.dX, self.dy, self.dnu = ctx.to_device(X), ctx.to_device(data.mean(axis=1)), ctx.to_device(data.var(axis=1))
+        dt = np.float32 if f32 else np.float64
+        self.dX, self.dy, self.dnu = ctx.to_device(X, dt), ctx.to_device(data.mean(axis=1), dt), ctx.to_device(data.var(axis=1), dt)
         self.dobs = ctx.to_device(obs)
-        self.dmu, self.dvar, self.dld, self.dhyp = ctx.empty((B, N)), ctx.empty((B, N)), ctx.empty((B,)), ctx.empty((B, 2))
-        self.dbasis, self.dll, self.dw = ctx.empty((B, 2, N)), ctx.empty((B, N)), ctx.empty((B, N))
-        self.dcov = ctx.empty((B, N, N)) if export == "full" else None
+        self.dmu, self.dvar, self.dld, self.dhyp = ctx.empty((B, N), dt), ctx.empty((B, N)), ctx.empty((B,)), ctx.empty((B, 2))
+        self.dbasis, self.dll, self.dw = ctx.empty((B, 2, N), dt), ctx.empty((B, N)), ctx.empty((B, N))
+        self.dcov = ctx.empty((B, N, N), dt) if export == "full" else None
         self.dbmu, self.dbvar = ctx.empty((G * N,)), ctx.empty((G * N,))
+        self.dmu64, self.dbasis64 = (ctx.empty((B, N)), ctx.empty((B, 2, N))) if f32 else (self.dmu, self.dbasis)
         self.bufs = [b for b in (self.dX, self.dy, self.dnu, self.dobs, self.dmu, self.dvar, self.dld, self.dhyp, self.dbasis,
                                  self.dll, self.dw, self.dcov, self.dbmu, self.dbvar) if b is not None]
+        if f32:
+            self.bufs += [self.dmu64, self.dbasis64]
 
     def free(self):
         for b in self.bufs:
@@ -246,17 +253,20 @@ class FieldWorkload:
         c = self.ctx
         if self.export == "full":
             info = c.gp_fit_batch_dev(self.B, self.N, self.R, self.dX, self.dy, self.dnu, self.T, self.dmu, self.dcov, None,
-                                      self.dld, self.dhyp, basis=self.dbasis)
-            c.extract_diag_dev(self.B, self.N, self.dcov, self.dvar)
+                                      self.dld, self.dhyp, basis=self.dbasis, f32=self.f32)
+            c.extract_diag_dev(self.B, self.N, self.dcov, self.dvar, f32=self.f32)
+            if self.f32:
+                c.widen_f32_dev(self.B * self.N, self.dmu, self.dmu64)
+                c.widen_f32_dev(self.B * 2 * self.N, self.dbasis, self.dbasis64)
             return info
         return c.gp_fit_batch_reduced_dev(self.B, self.N, self.R, self.dX, self.dy, self.dnu, self.T, self.dmu, self.dvar,
                                           self.dld, self.dhyp, self.dbasis)
 
     def weighted_posterior(self):
         c, P = self.ctx, self.G * self.N
-        c.loglik_rows_basis_grouped(self.dbasis, self.dld, self.dobs, loc=1, out=self.dll)
+        c.loglik_rows_basis_grouped(self.dbasis64, self.dld, self.dobs, loc=1, out=self.dll)
         c.weights_normalise_dev(self.M, P, self.dll, 1e-3, self.dw)
-        return c.barycentre_dev(self.M, P, self.dw, self.dmu, self.dvar, self.dbmu, self.dbvar)
+        return c.barycentre_dev(self.M, P, self.dw, self.dmu64, self.dvar, self.dbmu, self.dbvar)
 
     def step(self):
         self.fit()
@@ -275,22 +285,24 @@ class FieldWorkload:
         c.timer_start(); self.fit(); fit_ms = c.timer_stop()          # the dominant kernel: HIP events on its stream
         c.timer_start(); bad = self.weighted_posterior(); wp_ms = c.timer_stop()
         N, R = self.N, self.R
-        in_b = 8.0 * (N * R + 2 * N)
-        out_b = 8.0 * (N * N + N) if self.export == "full" else 8.0 * (4 * N + 3)
+        es = 4.0 if self.f32 else 8.0
+        in_b = es * (N * R + 2 * N)
+        out_b = es * (N * N + N) if self.export == "full" else 8.0 * (4 * N + 3)
         gbs = self.B * (in_b + out_b) / (fit_ms * 1e-3) / 1e9
         tfl = self.B * fit_flops(N, R, self.T) / (fit_ms * 1e-3) / 1e12
         return {"value": round(self.B * steps / elapsed, 1), "unit": "member-fits/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "fits_per_step": self.B, "export": self.export, "fit_kernel_ms": round(fit_ms, 3),
                 "weighted_posterior_latency_ms": round(wp_ms, 4), "barycentre_not_converged": int(bad),
-                "roofline": {"bound": "hbm", "kernel": "bayens::smalln::small_fit_kernel<6>", "achieved": round(gbs, 2),
+                "roofline": {"bound": "hbm", "kernel": ("bayens_f32" if self.f32 else "bayens") + "::smalln::small_fit_kernel<6>", "achieved": round(gbs, 2),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
                              "algorithmic_bytes_per_fit": in_b + out_b, "launches_per_step": 1,
                              "avg_launch_us": round(fit_ms * 1e3, 1),
                              "note": "SURVEY 8(d) prices config 5 against HBM; with every matrix resident in LDS the kernel is "
                                      "bound by the fp64 matrix / vector pipes and its serial 16x16 factorisations, not by "
                                      "HBM - see roofline_mfma"},
-                "roofline_mfma": {"bound": "mfma", "achieved": round(tfl, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tfl / F64_MFMA_PEAK_TFLOPS, 4),
+                "roofline_mfma": {"bound": "mfma", "achieved": round(tfl, 3),
+                                  "peak": F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tfl / (F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS), 4),
                                   "algorithmic_flop_per_fit": fit_flops(N, R, self.T)}}
 
 
@@ -375,7 +387,7 @@ def run_config5(args, ctx, rank, world, exchange, rdzv):
     """--config c5: grid points shard over the ranks with no data-path collective; each rank runs its own
     32 x grid-points field.  value = all ranks' fits / max-over-ranks time."""
     M, G, N, R, T = args.members, args.grid_points, 86, args.realisations, args.nits
-    fw = FieldWorkload(ctx, M, G, N, R, T, args.export, seed=0xC5 + rank)
+    fw = FieldWorkload(ctx, M, G, N, R, T, args.export, seed=0xC5 + rank, f32=(args.dtype == "f32"))
     for _ in range(args.warmup):
         fw.step()
     ctx.sync()
@@ -400,7 +412,7 @@ def run_config5(args, ctx, rank, world, exchange, rdzv):
         cpu = cpu_baseline_small(N, R, T, 400)
     out = {"metric": METRIC, "value": round(fw.B * world * args.steps / elapsed, 1), "unit": "member-fits/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"BASELINE config 5: {M} members x {G} grid points per GPU of independent GP fits (N={N} annual "
                                   f"steps, R={R}, matern32, n_optim_nits={T}, {args.export} export) + per-gridpoint "
                                   "LogLikelihoodWeight(c=1e-3) + Barycentre",
@@ -516,6 +528,10 @@ def main():
         c5f = fw.measure(3, 1)
         fw.free()
         c5["full_export"] = {k: c5f[k] for k in ("value", "fits_per_step", "fit_kernel_ms", "roofline")}
+        fw = FieldWorkload(ctx, 32, 432, 86, 8, T, "full", f32=True)
+        c5s = fw.measure(3, 1)
+        fw.free()
+        c5["fp32_full_export"] = {k: c5s[k] for k in ("value", "fits_per_step", "fit_kernel_ms", "roofline_mfma")}
         c5["workload"] = ("BASELINE config 5, one GPU's share: 32 members x 1728 grid points (96x144 over 8 GPUs) of "
                           "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
         extra["config5"] = c5
@@ -527,6 +543,25 @@ def main():
                           "dtype": "f32" if is32 else "f64", "kernel": kern,
                           "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
                                                           "frac_on_padded_dims", "avg_launch_us")}}
+            if is32:
+                # BASELINE config 3's weighting step: ModelSimilarityWeight(mode='single') = M(M-1)/2 Gaussian W2 distances
+                # between the full-covariance posteriors (weights.py:240-265); the fp32 factors are widened once, the polar
+                # iterations run in fp64 (their first steps factor I + c X^T X with c ~ 1e9: not an fp32 computation)
+                chol64, dws, dD = ctx.empty((M, N, N)), ctx.empty((M,)), ctx.empty((M, M))
+                ctx.widen_f32_dev(M * N * N, w2.dchol, chol64)
+                w2.local_rows()
+                ctx.w2_single_dev(M, N, w2.dmu64, chol64, dws, dD)            # warm-up (workspace growth)
+                ctx.sync()
+                t0 = time.perf_counter()
+                ctx.w2_single_dev(M, N, w2.dmu64, chol64, dws, dD)
+                ctx.sync()
+                w2_ms = (time.perf_counter() - t0) * 1e3
+                pairs = M * (M - 1) // 2
+                extra[key]["w2_single"] = {"ms": round(w2_ms, 1), "pairs": pairs, "ms_per_pair": round(w2_ms / pairs, 3),
+                                           "note": "ModelSimilarityWeight(mode='single') on the resident posteriors: "
+                                                   "QDWH polar iteration per pair, fp64, all pairs in full batches of M"}
+                for b in (chol64, dws, dD):
+                    b.free()
             w2.free()
 
     out = {

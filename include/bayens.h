@@ -36,7 +36,8 @@ enum {
   BAYENS_E_NOGPU = -3,    /* no HIP device / kernel image not loadable */
   BAYENS_E_COMM = -4,     /* RCCL not initialised or not loadable */
   BAYENS_E_ALLOC = -5,
-  BAYENS_E_NOCONV = -6    /* an iteration (the polar iteration of bayens_w2_single) did not converge: outputs invalid */
+  BAYENS_E_NOCONV = -6,   /* an iteration (the polar iteration of bayens_w2_single) did not converge: outputs invalid */
+  BAYENS_E_INTERNAL = -7  /* a device-side wait gave up (bayens_loglik_rows' substitution chain): outputs invalid */
 };
 
 /* ---- context, memory and timing plumbing -------------------------------------------------- */

@@ -37,6 +37,26 @@ def test_loglik_rows_and_weights(ctx, M, N, R_obs):
         assert np.allclose(w.sum(axis=0), 1.0, rtol=1e-12)
 
 
+@pytest.mark.parametrize("M,N", [(3, 1000), (2, 64), (5, 191), (40, 130)])
+def test_loglik_rows_chain_reads_only_the_lower_triangle(ctx, M, N):
+    """bayens_loglik_rows walks the compact factor in ONE chained launch (one workgroup per 64 rows and member): whatever
+    sits above the diagonal must not matter, partial last blocks and more members than a wave of workgroups included."""
+    from scipy.linalg import solve_triangular
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((M, N, N + 8))
+    cov = A @ A.transpose(0, 2, 1) / N + 0.5 * np.eye(N)
+    chol = np.linalg.cholesky(cov)
+    logdet = 2.0 * np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(axis=1)
+    mu = rng.standard_normal((M, N))
+    obs = rng.standard_normal((4, N))
+    ll_ref = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(mu[m], chol[m], logdet[m], obs)) for m in range(M)])
+    dirty = chol + np.triu(np.full((N, N), np.nan), 1)
+    ll = ctx.loglik_rows(mu, dirty, logdet, obs)
+    assert relerr(ll, ll_ref) < 1e-11
+    z = np.stack([solve_triangular(chol[m], np.stack([np.ones(N), mu[m]], axis=1), lower=True).T for m in range(M)])
+    assert relerr(ctx.loglik_rows_basis(z, logdet, obs), ll_ref) < 1e-11
+
+
 def test_weighted_posterior_in_one_call_equals_the_separate_steps(ctx):
     data, obs, out = _posteriors(ctx, 5, 90, R=4, seed=17)
     w, bm, bv, bad = ctx.weighted_posterior(out["basis"], out["logdet"], obs, out["mu"], out["cov"], c_std=1e-3)
