@@ -335,11 +335,13 @@ struct CpuPrims : Prims {
       out[b] = s;
     }
   }
-  void frob_normalise(int nb, int n, Mat M, Mat X) override {
+  void frob_normalise(int nb, int n, Mat M, Mat X, const double* cap, double cap_scale) override {
     for (int b = 0; b < nb; ++b) {
       double s = 0;
       for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double v = M.p[b * M.stride + (size_t)i * M.ld + j]; s += v * v; }
-      s = 1.0 / std::sqrt(s);
+      s = std::sqrt(s);
+      if (cap && cap_scale * cap[b] > 0.0 && cap_scale * cap[b] < s) s = cap_scale * cap[b];
+      s = 1.0 / s;
       for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) X.p[b * X.stride + (size_t)i * X.ld + j] = M.p[b * M.stride + (size_t)i * M.ld + j] * s;
     }
   }
