@@ -137,7 +137,9 @@ int bayens_extract_diag_f32(bayens_ctx* ctx, int loc, int B, int N, const float*
 int bayens_widen_f32(bayens_ctx* ctx, int loc, size_t n, const float* src, double* dst);
 
 /* LogLikelihoodWeight._compute inner loops, MVN branch (ensembles/weights.py:88-104):
- * ll_mean[b][t] = mean_r log N(obs[r][t] * 1_N ; mu_b, cov_b)   obs [R_obs][N] */
+ * ll_mean[b][t] = mean_r log N(obs[r][t] * 1_N ; mu_b, cov_b)   obs [R_obs][N]
+ * cov_chol [B][N][N]: lower factors, only the lower triangle is read (one chained launch over the compact factor).
+ * BAYENS_E_INTERNAL if the device-side chain gives up waiting (outputs invalid). */
 int bayens_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                        const double* mu, const double* cov_chol, const double* logdet,
                        const double* obs, double* ll_mean);
