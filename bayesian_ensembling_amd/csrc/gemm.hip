@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
         for (int r = 0; r < 4; ++r) acc[jt][r] = B[(long)(wave * 16 + acc_row(lk, r)) * g.ldb + 64 * j + jt * 16 + lr];
 #pragma unroll
       for (int t = 0; t <= s; ++t) {
-        __syncthreads();                       // the previous product is done with Bs
+        BAYENS_LDS_BARRIER();                       // the previous product is done with Bs
         if (t == s) {
 #pragma unroll
           for (int jt = 0; jt < 4; ++jt)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
             for (int r = 0; r < 4; ++r) As[wave * 16 + acc_row(lk, r)][jt * 16 + lr] = acc[jt][r];
         }
         stage64_store<false>(Bs, tid, rb);       // as stored; RLT reads it transposed (see panel_mma_tri)
-        __syncthreads();
+        BAYENS_LDS_BARRIER();
         // next tile's global load flies while this product runs
         if (t < s) tile_load(s, t + 1, rb);
         else if (s + 1 < nsub) tile_load(s + 1, 0, rb);

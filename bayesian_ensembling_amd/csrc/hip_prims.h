@@ -8,6 +8,12 @@
 
 #include "prims.h"
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every global load AND store the
+// wave has in flight (s_waitcnt vmcnt(0): on gfx9 stores return through the same counter), i.e. it puts an HBM round
+// trip on the critical path after every result store.  Legal wherever no thread reads global memory that another
+// thread of the workgroup wrote earlier in the kernel (the compiler still waits for a load before its value is used).
+#define BAYENS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 namespace BAYENS_NS {
 
 struct HipError {

@@ -588,7 +588,7 @@ __device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], d
         }
       }
     }
-    __syncthreads();
+    BAYENS_LDS_BARRIER();
     LEAF_STAMP(1 + 3 * bj);
     // ---- P2: panel rows below: P <- P * inv(L_dd)^T ----
     const int nrb = 3 - bj;                         // 16-row blocks below the diagonal sub-block
@@ -598,7 +598,7 @@ __device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], d
       acc = tile_mma<true>(acc, S, r0, d0, Mi, d0, d0, lane, 1.0);
       tile_store(S, r0, d0, lane, acc);
     }
-    __syncthreads();
+    BAYENS_LDS_BARRIER();
     LEAF_STAMP(2 + 3 * bj);
     // ---- P3: trailing update of the lower block pairs (rb >= cb > bj) ----
     {
@@ -611,7 +611,7 @@ __device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], d
             tile_store(S, 16 * rb, 16 * cb, lane, acc);
           }
     }
-    __syncthreads();
+    BAYENS_LDS_BARRIER();
     LEAF_STAMP(3 + 3 * bj);
   }
 
@@ -628,7 +628,7 @@ __device__ __forceinline__ void leaf_factor(double (*S)[LS], double (*Mi)[LS], d
       acc = tile_mma<false>(acc, Mi, 16 * I, 16 * I, Tt[wave], 0, 0, lane, -1.0);
       tile_store(Mi, 16 * I, 16 * J, lane, acc);
     }
-    __syncthreads();
+    BAYENS_LDS_BARRIER();
   }
   LEAF_STAMP(13);
 }
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(Mat Ablk, real* inv, lo
       Mi[r][c] = 0.0;
     }
   }
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   LEAF_STAMP(0);
   leaf_factor(S, Mi, Tt, b, tid, pivot_base, info, stamps);
   real* iv = inv + b * inv_stride;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) p21[q] = a[(64 + rq + 4 * q) * ld + c];
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   leaf_factor(U, V, Tt, b, tid, pivot_base, info, stamps);
 #pragma unroll
   for (int q = 0; q < 16; ++q) p22[q] = a[(64 + rq + 4 * q) * ld + 64 + c];
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv
     iv[r * 64 + c] = c <= r ? V[r][c] : 0.0;
     U[r][c] = p21[q];
   }
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   {   // L21 = A21 inv(L11)^T: wave w owns rows 16w..16w+15 (reads and writes only those rows of U)
     v4d acc[4];
 #pragma unroll
@@ -716,14 +716,14 @@ __global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv
 #pragma unroll
     for (int J = 0; J < 4; ++J) tile_store(U, 16 * wave, 16 * J, lane, acc[J]);
   }
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
 #pragma unroll
   for (int q = 0; q < 16; ++q) {   // L21 out; A22 (lower) into V, whose inverse image is no longer needed
     const int r = rq + 4 * q;
     a[(64 + r) * ld + c] = U[r][c];
     V[r][c] = c <= r ? (double)p22[q] : 0.0;
   }
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   {   // A22 -= L21 L21^T on the lower 16-block pairs
     int p = 0;
     for (int rb = 0; rb < 4; ++rb)
@@ -734,9 +734,9 @@ __global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv
           tile_store(V, 16 * rb, 16 * cb, lane, acc);
         }
   }
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   for (int q = 0; q < 16; ++q) U[rq + 4 * q][c] = 0.0;
-  __syncthreads();
+  BAYENS_LDS_BARRIER();
   leaf_factor(V, U, Tt, b, tid, pivot_base + 64, info, stamps);
   for (int q = 0; q < 16; ++q) {
     const int r = rq + 4 * q;

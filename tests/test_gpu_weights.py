@@ -105,6 +105,53 @@ def test_w2_single_full_covariance(ctx, M, N):
     assert np.allclose(D, D.T, rtol=0, atol=0)
 
 
+def _nuclear_reference(Li, Lj):
+    return np.linalg.svd(Lj.T @ Li, compute_uv=False).sum()
+
+
+@pytest.mark.parametrize("case", ["scaled_down", "scaled_up", "ill_conditioned", "mixed_scales", "identical", "one_pair",
+                                  "more_pairs_than_slots"])
+def test_w2_single_starting_interval_and_stopping_rule(ctx, case):
+    """The polar iteration starts from per-member estimates of the factors' extreme singular values and stops on the size
+    of its steps: badly scaled, ill-conditioned, coincident and very unequal members must neither fool the estimates nor
+    end the iteration early.  Reference: nuclear norms from an SVD (wasserstein.py:41-45 is tr sqrtm = ||L_j^T L_i||_*)."""
+    rng = np.random.default_rng(sum(case.encode()))
+    N = 96
+    M = {"one_pair": 2, "more_pairs_than_slots": 9}.get(case, 4)
+
+    def factor(scale=1.0, cond=1e2):
+        Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        ev = scale * np.logspace(0, -np.log10(cond), N)
+        return np.linalg.cholesky((Q * ev) @ Q.T + 0.0)
+    if case == "scaled_down":
+        Ls = [factor(1e-8) for _ in range(M)]
+    elif case == "scaled_up":
+        Ls = [factor(1e6) for _ in range(M)]
+    elif case == "ill_conditioned":
+        Ls = [factor(1.0, 1e9) for _ in range(M)]
+    elif case == "mixed_scales":
+        Ls = [factor(10.0 ** (3 * m - 4), 10.0 ** (1 + 2 * m)) for m in range(M)]
+    elif case == "identical":
+        Ls = [factor()] * 2 + [factor(), factor(3.0)]
+    else:
+        Ls = [factor(1.0 + m, 10.0 ** (1 + m % 4)) for m in range(M)]
+    chol = np.stack(Ls)
+    mu = rng.standard_normal((M, N))
+    w, D = ctx.w2_single(mu, chol=chol)
+    tr = np.array([(L * L).sum() for L in Ls])
+    for i in range(M):
+        for j in range(M):
+            if i == j:
+                assert D[i, j] == 0.0
+                continue
+            nuc = _nuclear_reference(Ls[i], Ls[j])
+            ref = np.linalg.norm(mu[i] - mu[j]) + (tr[i] + tr[j] - 2.0 * nuc)
+            # the trace term is a difference of numbers of size tr_i + tr_j: that is the scale of its rounding error
+            assert abs(D[i, j] - ref) <= 1e-11 * (tr[i] + tr[j]) + 1e-12 * abs(ref), (case, i, j, D[i, j], ref)
+    v = D.mean(axis=1)
+    assert relerr(w, v / v.sum()) < 1e-12
+
+
 def test_w2_single_sharded_over_a_one_rank_communicator(ctx):
     """The multi-GPU form of mode='single' (all-gather of the factors, pairs dealt over ranks, all-reduce of the
     nuclear-norm table) on a communicator of one rank: must equal the single-GPU table exactly."""
