@@ -203,6 +203,33 @@ class RcclExchange:
         self.ctx.comm_destroy()
 
 
+def make_exchange(ctx, rdzv, prefer="rccl"):
+    """The rows exchange of a multi-rank run: RCCL when every rank can load it and the communicator comes up, else the
+    host-staged transport over the rendezvous - decided by ALL ranks together, so that no rank waits inside
+    ncclCommInitRank for a peer that has already given up.  Returns (exchange, kind, note)."""
+    if prefer != "rccl":
+        return HostStagedExchange(ctx, rdzv), "file", None
+    try:                                   # phase 1: can this rank load librccl at all?  (no communicator yet)
+        ctx.comm_unique_id()
+        mine = (True, "")
+    except Exception as e:                 # noqa: BLE001 - whatever it is, the peers must hear about it
+        mine = (False, f"rank {rdzv.rank}: {e}")
+    flags = rdzv.allgather_obj(mine)
+    if all(f[0] for f in flags):
+        try:                               # phase 2: bring the communicator up (a failure here is symmetric)
+            ex = RcclExchange(ctx, rdzv)
+            mine = (True, "")
+        except Exception as e:             # noqa: BLE001
+            ex, mine = None, (False, f"rank {rdzv.rank}: {e}")
+        flags = rdzv.allgather_obj(mine)
+        if all(f[0] for f in flags):
+            return ex, "rccl", None
+        if ex is not None:
+            ex.close()
+    note = next(f[1] for f in flags if not f[0])
+    return HostStagedExchange(ctx, rdzv), "file", "RCCL unavailable, host-staged exchange used instead: " + note
+
+
 class HostStagedExchange:
     """RcclExchange's interface (device rows in, device tables out) carried over a host transport: rows are
     downloaded, gathered by `host` (FileRendezvous / HostGather) and uploaded.  A rehearsal transport - several ranks

@@ -475,7 +475,7 @@ def main():
     force_comm = bool(os.environ.get("BAYENS_FORCE_COMM"))    # exercise the RCCL path with a single rank
     if world > 1 or force_comm:
         rdzv = parallel.FileRendezvous(parallel.FileRendezvous.directory_from_env(), rank, world)
-        exchange = parallel.RcclExchange(ctx, rdzv) if args.exchange == "rccl" else parallel.HostStagedExchange(ctx, rdzv)
+        exchange, args.exchange, args.exchange_note = parallel.make_exchange(ctx, rdzv, args.exchange)
 
     if args.config == "c5":
         run_config5(args, ctx, rank, world, exchange, rdzv)
@@ -575,7 +575,8 @@ def main():
                    "member_groups": args.groups,
                    "parallelism": (f"member-sharded x{world}, one RCCL all-gather of packed [M_loc,3,N] rows per step"
                                    if world > 1 else "single GPU"),
-                   "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib},
+                   "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib,
+                   "exchange_note": getattr(args, "exchange_note", None)},
         "roofline": roof, "cpu_baseline": cpu,
     }
     out.update(extra)
