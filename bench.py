@@ -557,6 +557,7 @@ def main():
                 ctx.sync()
                 w2_ms = (time.perf_counter() - t0) * 1e3
                 pairs = M * (M - 1) // 2
+                extra[key]["step_ms_with_w2_single"] = round(el / 3 * 1e3 + w2_ms, 1)    # fit + rows + barycentre + the W2 table
                 extra[key]["w2_single"] = {"ms": round(w2_ms, 1), "pairs": pairs, "ms_per_pair": round(w2_ms / pairs, 3),
                                            "note": "ModelSimilarityWeight(mode='single') on the resident posteriors: "
                                                    "QDWH polar iteration per pair, fp64, all pairs in full batches of M"}

@@ -37,7 +37,7 @@ def test_loglik_rows_and_weights(ctx, M, N, R_obs):
         assert np.allclose(w.sum(axis=0), 1.0, rtol=1e-12)
 
 
-@pytest.mark.parametrize("M,N", [(3, 1000), (2, 64), (5, 191), (40, 130)])
+@pytest.mark.parametrize("M,N", [(3, 1000), (2, 64), (5, 191), (40, 130), (2500, 86), (1, 1)])
 def test_loglik_rows_chain_reads_only_the_lower_triangle(ctx, M, N):
     """bayens_loglik_rows walks the compact factor in ONE chained launch (one workgroup per 64 rows and member): whatever
     sits above the diagonal must not matter, partial last blocks and more members than a wave of workgroups included."""
