@@ -1546,9 +1546,29 @@ int bayens_bench_leaf(bayens_ctx* c, int nb, int reps, double* us_per_launch, un
     // S = A A^T + 64 I  (SPD)
     c->prims->gemm(nb, n, n, n, 1.0, A, A, 0.0, S, GEMM_TB, 64.0);
     c->prims->copy(nb, n, S, A);
+    // BAYENS_LEAF_SIDE=k: the stamped launch runs beside a trailing-update-sized product on another stream
+    // (k = 1: 1536 x 1536 x 256 lower, the Cholesky's side-stream update; k = 2: a copy of the same size instead)
+    const char* side_env = getenv("BAYENS_LEAF_SIDE");
+    const int side = side_env ? atoi(side_env) : 0;
+    double *sa = nullptr, *sc = nullptr;
+    if (side) {
+      const size_t an = (size_t)1536 * 256, cn = (size_t)1536 * 1536;
+      sa = st.scratch<double>(an * 32);
+      sc = st.scratch<double>(cn * 32 * 2);
+      c->prims->fill_random(sa, an * 32, 5);
+      c->prims->fill_random(sc, cn * 32 * 2, 6);
+      BAYENS_HIP(hipStreamSynchronize(c->stream));
+      HipPrims& S2 = *c->gprims[1];
+      Mat PA{sa, 256, (long)an}, PC{sc, 1536, (long)cn}, PD{sc + cn * 32, 1536, (long)cn};
+      for (int r = 0; r < 3; ++r) {
+        if (side == 1) S2.gemm(32, 1536, 1536, 256, -1.0, PA, PA, 1.0, PC, GEMM_TB | GEMM_TRI_OUT, 0.0);
+        else S2.copy(32, 1536, PC, PD);
+      }
+    }
     c->prims->leaf_stamps = dst;
     c->prims->potrf_leaf(nb, A, inv, (long)n * n, 0, dinfo);
     c->prims->leaf_stamps = nullptr;
+    if (side) BAYENS_HIP(hipStreamSynchronize(c->gstreams[1]));
     BAYENS_HIP(hipEventRecord(c->t0, c->stream));
     for (int r = 0; r < reps; ++r) { c->prims->copy(nb, n, S, A); c->prims->potrf_leaf(nb, A, inv, (long)n * n, 0, dinfo); }
     BAYENS_HIP(hipEventRecord(c->t1, c->stream));

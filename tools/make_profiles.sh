@@ -31,4 +31,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt5 -o kt5 -- 
 cd $R
 python3 tools/rocpd_stats.py $(find $OUT/${TAG}_kt5 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_c5.txt > /dev/null
 rm -rf $OUT/${TAG}_kt5
+timeout -k 10 300 python3 bench.py --config c5 --dtype f32 --grid-points 432 --no-cpu-baseline > $OUT/${TAG}_bench_c5_f32.json 2> $OUT/${TAG}_bench_c5_f32.err || exit 7
+timeout -k 10 120 python3 tools/loglik_rows_time.py > $OUT/${TAG}_loglik_rows.txt 2>&1 || exit 8
+BAYENS_W2_TRACE=1 timeout -k 10 300 python3 tools/w2_time.py > $OUT/${TAG}_w2_single.txt 2>&1 || exit 9
+timeout -k 10 120 python3 tools/diag16_bench.py > $OUT/${TAG}_diag16_bench.txt 2>&1 || exit 10
+# one 32 x 2048 Cholesky kernel by kernel (the chain analysis of DESIGN section 9)
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/${TAG}_ktp -o ktp -- python3 $R/tools/potrf_trace.py > $OUT/${TAG}_ktp.log 2>&1 || exit 11
+cd $R
+python3 tools/rocpd_seq.py $(find $OUT/${TAG}_ktp -name "*.db" | head -1) > $OUT/${TAG}_potrf_sequence.txt
+rm -rf $OUT/${TAG}_ktp
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
