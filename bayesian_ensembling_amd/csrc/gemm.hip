@@ -7,13 +7,15 @@
 // Tiling (CDNA4: 64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
 //   workgroup = 256 threads = 4 waves, output tile 128 x 128, each wave a 64 x 64 sub-tile
 //   = 4 x 4 MFMA tiles of 16 x 16 (16 accumulators x 4 f64 = 128 VGPR);
-//   K is consumed in steps of 16: both operand tiles are staged through LDS in a k-major image
-//   [16][128+2] (the +2 double pad keeps the transposing ds_write at 2-way conflicts), double-buffered,
-//   with the global loads of step s+1 in flight while step s runs 64 MFMAs per wave;
-//   66.6 KB LDS and <=256 VGPR per workgroup => two workgroups per CU.
+//   K is consumed in steps of 16, both operand tiles double-buffered in LDS, the global loads of step s+1 in flight
+//   while step s runs 64 MFMAs per wave.  fp64: the tiles go STRAIGHT into LDS (global_load_lds_dwordx4, no staging
+//   registers, no ds_write) in per-1-KB-block swizzled images whose operand reads are conflict-free (see
+//   gemm_f64_mfma's fp64 definition); fp32: staged through registers into a k-major image [16][128+2].
+//   64-66.6 KB LDS and <=256 VGPR per workgroup => two workgroups per CU.
 //   All dimensions are multiples of 64; waves whose 64 x 64 sub-tile lies outside the matrix (or, with
 //   GEMM_TRI_OUT, strictly above the block diagonal) skip their MFMAs and stores (wave-uniform).
 //   Block ids are dealt so that each XCD (own L2) walks a contiguous range of tiles of few members.
+#include <cstdlib>
 #include "hip_prims.h"
 
 namespace BAYENS_NS {
@@ -100,6 +102,8 @@ __device__ __forceinline__ void stage_store(real (*tile)[LDT], int tid, const vs
   }
 }
 
+#ifdef BAYENS_F32
+// The fp32 instance stages its operand tiles through registers (the fp64 instance below loads them straight into LDS).
 // Register budget: two workgroups per CU (<=256 VGPR).  The fp32 instance needs 135 and runs three per CU; holding
 // it to 128 VGPR for four per CU was measured slower (85 against 91 TFLOP/s).
 template <bool TA, bool TB>
@@ -225,6 +229,174 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     }
   }
 }
+
+#else   // fp64
+// ------------------------------------------------------------------------------------------------
+// fp64: the operand tiles are loaded STRAIGHT INTO LDS (global_load_lds_dwordx4: lane l's 16 bytes land
+// at M0 + 16 l, no staging registers, no ds_write), fp64 only.  A wave instruction fills 1 KB of LDS, so padding is
+// not available and the images are laid out per 1 KB block such that the MFMA operand reads (ds_read_b64: the two
+// 32-lane halves are banked separately over 32 eight-byte banks) are conflict-free and every kk / sub-tile offset
+// is an immediate:
+//  * operand stored k-contiguous in memory (A of NN/NT, B of NT/TT) - "row image": block rb8 = 8 rows x 16 k,
+//    element (row, k) at  rb8*128 + 16*((k>>1) ^ (rb8&1)) + 2*(row&7) + (k&1)   (doubles).  Lane j of the block's
+//    load fetches row rb8*8 + (j&7), k-chunk (j>>3) ^ (rb8&1): eight lanes cover each 128-byte line.
+//  * operand stored row-contiguous in memory (A of TN/TT, B of NN/TN) - "k image": block = one k row of 128,
+//    element (k, row) at  k*128 + (row ^ 16*(k&1)).  Lane j fetches the two rows 2*(j ^ 8*(k&1)), +1: one 1 KB line run.
+// MFMA operand of lane (lr = lane&15, lk = lane>>4), sub-tile i, step kk: row/col = w*64 + i*16 + lr, k = 4 kk + lk.
+// One wave instruction: every lane's 16 bytes at `src` go to LDS at `dst_wave_base` + 16 * lane.  Issued as inline
+// assembly: through the builtin the compiler must assume that the write may alias the LDS reads that follow and puts an
+// s_waitcnt vmcnt(0) in front of them - the K loop then waits out the global latency of the NEXT tile before it touches
+// the current one (measured: 59.7 instead of 68.5 TFLOP/s).  The caller waits (dl_wait) before the step's barrier.
+__device__ __forceinline__ void lds_dma16(const double* src, const double* dst_wave_base) {
+  const unsigned lds_off = (unsigned)(size_t)dst_wave_base;      // low half of a generic LDS address = the LDS offset
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ void dl_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool KIMG>
+__device__ __forceinline__ void dl_issue(const double* base, int ld, int row0, int nrows, int k0, int lane, int wave,
+                                         double* tile) {
+  if (!KIMG) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rb8 = 4 * p + wave;                         // blocks of this wave: wave, 4 + wave, 8 + wave, 12 + wave
+      int rr = row0 + rb8 * 8 + (lane & 7);
+      rr = rr < nrows ? rr : nrows - 1;
+      const int c8 = (lane >> 3) ^ (rb8 & 1);
+      lds_dma16(base + (long)rr * ld + k0 + 2 * c8, tile + rb8 * 128);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = 4 * p + wave;
+      int cc = row0 + 2 * (lane ^ (8 * (k & 1)));
+      cc = cc <= nrows - 2 ? cc : nrows - 2;
+      lds_dma16(base + (long)(k0 + k) * ld + cc, tile + k * 128);
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) double As[2][BK * BM];
+  __shared__ __attribute__((aligned(1024))) double Bs[2][BK * BN];
+
+  int bid = blockIdx.x;
+  const int tiles = g.tiles_m * g.tiles_n;
+  int batch, t;
+  if ((g.flags & GEMM_TRI_OUT) && (g.nb & 7) == 0) {
+    const int mpc = g.nb >> 3, loc = bid >> 3;
+    t = loc / mpc;
+    batch = (bid & 7) * mpc + (loc - t * mpc);
+  } else {
+    if ((g.total & 7) == 0) bid = (bid & 7) * (g.total >> 3) + (bid >> 3);
+    batch = bid / tiles;
+    t = bid - batch * tiles;
+  }
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  if ((g.flags & GEMM_TRI_OUT) && (g.flags & GEMM_ZERO_SKIPPED)) {
+    const int r64 = row0 + wm * 64, c64 = col0 + wn * 64;
+    if (c64 > r64 && r64 < g.m && c64 < g.n) {
+      double* Cz = g.C + batch * g.sC + (long)r64 * g.ldc + c64;
+      for (int e = lane; e < 64 * 64; e += 64) Cz[(long)(e >> 6) * g.ldc + (e & 63)] = 0.0;
+    }
+  }
+  if ((g.flags & GEMM_TRI_OUT) && col0 > row0) return;
+  const double* A = g.A + batch * g.sA;
+  const double* B = g.B + batch * g.sB;
+  double* C = g.C + batch * g.sC;
+
+  bool active = (row0 + wm * 64 < g.m) && (col0 + wn * 64 < g.n);
+  if ((g.flags & GEMM_TRI_OUT) && (col0 + wn * 64 > row0 + wm * 64)) active = false;
+
+  int kbeg = 0;
+  if (g.flags & GEMM_KTRIM_TN_LOWER) kbeg = row0 > col0 ? row0 : col0;
+  const int nk = (g.k - kbeg) / BK;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0, 0, 0, 0};
+
+  const int lr = lane & 15, lk = lane >> 4;
+  // lane parts of the operand addresses (doubles); the sub-tile and kk parts are immediates
+  //   row image: w*1024 + i*256 + kk*32 + [ (lr>>3)*128 + 16*((lk>>1) ^ (lr>>3)) + 2*(lr&7) + (lk&1) ]
+  //   k image:   kk*512 + lk*128 + w*64 + lr + 16*((i ^ (lk&1)))        (i even: +16 s, i odd: -16 s, s = lk&1)
+  const int row_part = (lr >> 3) * 128 + 16 * ((lk >> 1) ^ (lr >> 3)) + 2 * (lr & 7) + (lk & 1);
+  const int k_part = lk * 128 + lr, ks = 16 * (lk & 1);
+  const int a_lane = TA ? k_part + wm * 64 : row_part + wm * 1024;
+  const int b_lane = TB ? row_part + wn * 1024 : k_part + wn * 64;
+
+  if (nk > 0) {
+    dl_issue<TA>(A, g.lda, row0, g.m, kbeg, lane, wave, As[0]);
+    dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg, lane, wave, Bs[0]);
+  }
+  dl_wait();
+  __syncthreads();
+
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) {
+      dl_issue<TA>(A, g.lda, row0, g.m, kbeg + (s + 1) * BK, lane, wave, As[buf ^ 1]);
+      dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 1) * BK, lane, wave, Bs[buf ^ 1]);
+    }
+    if (active) {
+      const double* pa = As[buf] + a_lane;
+      const double* pb = Bs[buf] + b_lane;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          a[i] = TA ? pa[kk * 512 + i * 16 + ((i & 1) ? -ks : ks)] : pa[i * 256 + kk * 32];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          b[j] = TB ? pb[j * 256 + kk * 32] : pb[kk * 512 + j * 16 + ((j & 1) ? -ks : ks)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = BAYENS_MFMA16(a[i], b[j], acc[i][j]);
+      }
+    }
+    dl_wait();
+    __syncthreads();
+  }
+
+  if (!active) return;
+  real cv[2][4][4];
+  auto load_strip = [&](int i, real (&dst)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
+  };
+  const bool accumulate = g.beta != 0.0;
+  if (accumulate) load_strip(0, cv[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (accumulate && i + 1 < 4) load_strip(i + 1, cv[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + wn * 64 + j * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wm * 64 + i * 16 + acc_row(lk, r);
+        double v = g.alpha * acc[i][j][r];
+        if (accumulate) v += g.beta * cv[i & 1][j][r];
+        if (row == col) v += g.diag_add;
+        C[(long)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // One-shot kernel for the narrow products of the blocked solves: C[m x 64] = alpha A[m x 64] op(B)[64 x 64] + beta C.
