@@ -332,40 +332,67 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   const int a_lane = TA ? k_part + wm * 64 : row_part + wm * 1024;
   const int b_lane = TB ? row_part + wn * 1024 : k_part + wn * 64;
 
+  // Operand reads run half a step ahead of their MFMAs, ACROSS the step's barrier: the last quarter of a step's MFMAs
+  // (kk = 3, operands already in registers) is issued after the barrier, under the first operand reads of the next tile -
+  // otherwise every step starts with a wave that has nothing to issue until its first ds_read returns.
+  auto rd = [&](int buf, int kk, double (&a)[4], double (&b)[4]) {
+    const double* pa = As[buf] + a_lane;
+    const double* pb = Bs[buf] + b_lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = TA ? pa[kk * 512 + i * 16 + ((i & 1) ? -ks : ks)] : pa[i * 256 + kk * 32];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = TB ? pb[j * 256 + kk * 32] : pb[kk * 512 + j * 16 + ((j & 1) ? -ks : ks)];
+  };
+  auto mm = [&](const double (&a)[4], const double (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = BAYENS_MFMA16(a[i], b[j], acc[i][j]);
+  };
+
   if (nk > 0) {
     dl_issue<TA>(A, g.lda, row0, g.m, kbeg, lane, wave, As[0]);
     dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg, lane, wave, Bs[0]);
   }
   dl_wait();
   __syncthreads();
-
-  for (int s = 0; s < nk; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nk) {
-      dl_issue<TA>(A, g.lda, row0, g.m, kbeg + (s + 1) * BK, lane, wave, As[buf ^ 1]);
-      dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 1) * BK, lane, wave, Bs[buf ^ 1]);
+  if (nk > 1) {
+    dl_issue<TA>(A, g.lda, row0, g.m, kbeg + BK, lane, wave, As[1]);
+    dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + BK, lane, wave, Bs[1]);
+  }
+  if (active) {
+    double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    rd(0, 0, a0, b0);
+    rd(0, 1, a1, b1);
+    for (int s = 0; s < nk; ++s) {
+      const int buf = s & 1;
+      rd(buf, 2, a2, b2);
+      rd(buf, 3, a3, b3);
+      mm(a0, b0);
+      mm(a1, b1);
+      mm(a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      dl_wait();                       // tile s + 1 has landed
+      __syncthreads();                 // ... everywhere, and every wave has read the last of tile s
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nk) {
+        dl_issue<TA>(A, g.lda, row0, g.m, kbeg + (s + 2) * BK, lane, wave, As[buf]);
+        dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 2) * BK, lane, wave, Bs[buf]);
+      }
+      rd(buf ^ 1, 0, a0, b0);          // (after the last step: whatever the other buffer holds - never used)
+      rd(buf ^ 1, 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(a3, b3);
     }
-    if (active) {
-      const double* pa = As[buf] + a_lane;
-      const double* pb = Bs[buf] + b_lane;
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          a[i] = TA ? pa[kk * 512 + i * 16 + ((i & 1) ? -ks : ks)] : pa[i * 256 + kk * 32];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[j] = TB ? pb[j * 256 + kk * 32] : pb[kk * 512 + j * 16 + ((j & 1) ? -ks : ks)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = BAYENS_MFMA16(a[i], b[j], acc[i][j]);
+  } else {
+    for (int s = 0; s < nk; ++s) {     // a wave with no output block still moves its share of the tiles
+      dl_wait();
+      __syncthreads();
+      if (s + 2 < nk) {
+        dl_issue<TA>(A, g.lda, row0, g.m, kbeg + (s + 2) * BK, lane, wave, As[s & 1]);
+        dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 2) * BK, lane, wave, Bs[s & 1]);
       }
     }
-    dl_wait();
-    __syncthreads();
   }
 
   if (!active) return;
