@@ -251,7 +251,9 @@ __device__ __forceinline__ void lds_dma16(const double* src, const double* dst_w
   const unsigned lds_off = (unsigned)(size_t)dst_wave_base;      // low half of a generic LDS address = the LDS offset
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory", "m0");
 }
-__device__ __forceinline__ void dl_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// before a step's barrier: this wave's DMA loads have landed AND its own operand reads of the buffer that the next DMA
+// overwrites have returned (they were issued 48 MFMAs earlier; the wait is free, the guarantee is not optional)
+__device__ __forceinline__ void dl_wait() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 template <bool KIMG>
 __device__ __forceinline__ void dl_issue(const double* base, int ld, int row0, int nrows, int k0, int lane, int wave,
