@@ -109,3 +109,51 @@ def test_w2_single_sharded_rejects_uneven_shards():
             return 0, 2, "librccl"
     with pytest.raises(ValueError, match="n_members=5"):
         parallel.w2_single_sharded(FakeCtx(), 5, np.zeros((3, 4)), np.zeros((3, 4, 4)))
+
+
+class _FakeCommCtx:
+    """Stands in for _lib.Context in make_exchange: `fail_at` = None | 'load' | 'init' picks where this rank's RCCL breaks."""
+
+    def __init__(self, fail_at):
+        self.fail_at, self.inited, self.destroyed = fail_at, False, False
+
+    def comm_unique_id(self):
+        if self.fail_at == "load":
+            raise RuntimeError("librccl.so: cannot open shared object file")
+        return bytes(128)
+
+    def comm_init(self, rank, world, uid):
+        if self.fail_at == "init":
+            raise RuntimeError("ncclCommInitRank: invalid usage")
+        self.inited = True
+
+    def comm_destroy(self):
+        self.destroyed = True
+
+
+def _consensus_worker(rank, world, rdzv_dir, failing_rank, fail_at, out_dir):
+    rdzv = parallel.FileRendezvous(rdzv_dir, rank, world, timeout_s=60)
+    ctx = _FakeCommCtx(fail_at if rank == failing_rank else None)
+    ex, kind, note = parallel.make_exchange(ctx, rdzv, "rccl")
+    with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
+        f.write(f"{kind}|{type(ex).__name__}|{ctx.inited}|{ctx.destroyed}|{note}")
+    rdzv.close()
+
+
+@pytest.mark.parametrize("fail_at,failing_rank", [(None, 0), ("load", 1), ("init", 0), ("init", 2)])
+def test_all_ranks_agree_on_the_exchange(tmp_path, fail_at, failing_rank):
+    """One rank that cannot load RCCL, or whose communicator does not come up, sends EVERY rank to the host-staged
+    exchange (nobody is left inside ncclCommInitRank); a rank whose own communicator did come up tears it down again."""
+    world = 3
+    mp.spawn(_consensus_worker, args=(world, str(tmp_path / "rdzv"), failing_rank, fail_at, str(tmp_path)), nprocs=world,
+             join=True)
+    for r in range(world):
+        kind, cls, inited, destroyed, note = open(tmp_path / f"c{r}.txt").read().split("|", 4)
+        if fail_at is None:
+            assert (kind, cls, inited, destroyed, note) == ("rccl", "RcclExchange", "True", "False", "None")
+        else:
+            assert kind == "file" and cls == "HostStagedExchange" and f"rank {failing_rank}" in note
+            if fail_at == "load":
+                assert inited == "False"                       # nobody entered the communicator
+            elif r != failing_rank:
+                assert inited == "True" and destroyed == "True"
