@@ -321,7 +321,7 @@ def cpu_baseline_small(N, R, T, fits):
             "sample": f"{fits} fits of the same shape (N={N}, R={R}, n_optim_nits={T}), NumPy/LAPACK oracle, {dt:.1f} s"}
 
 
-def api_path(ctx, M, N, R, T, reps=3):
+def api_path(ctx, M, N, R, T, reps=5):
     """The same step through the plug-in classes a user of the reference calls: ModelCollection.fit(GPDTW1D) ->
     LogLikelihoodWeight -> Barycentre (ensembles/data.py:385-395, weights.py:87-131, ensemble_scheme.py:43-81), host
     arrays in, posteriors resident in HBM (resident.py).  Includes the PCIe upload of the realisations, the Python
@@ -346,6 +346,8 @@ def api_path(ctx, M, N, R, T, reps=3):
                 w = es.LogLikelihoodWeight()(mc, ob, standardisation_constant=1e-3)
                 post = es.Barycentre()(mc, w)
                 dt = time.perf_counter() - t0
+            if os.environ.get("BAYENS_PRINT_STAGES"):
+                print(f"api_path progress_bar={bar}: {dt * 1e3:.1f} ms", file=sys.stderr, flush=True)
             best = dt if best is None else min(best, dt)
         times[bar] = best
     assert np.isfinite(post.mu).all()
