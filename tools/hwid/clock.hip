@@ -2,13 +2,14 @@
 //   mode 0: a register-only fp64 MFMA loop (16 independent accumulators per wave, 2 workgroups of 4 waves per CU)
 //   mode 1: the same loop with a 1 KB global -> LDS DMA per wave every 16 MFMAs (the GEMM's operand traffic)
 //   mode 2: the DMA alone
+//   mode 7: a fifth wave per workgroup issues the workgroup's DMA (mode 3's traffic), the four MFMA waves none
 //   mode 3: the MFMA loop with 2 KB of DMA per wave and 16 MFMAs - the ratio of the 128 x 128 x 16 GEMM step
 // Prints the achieved TFLOP/s and the mean shader frequency.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256, 2) void k(int mode, int iters, const double* src, long span, unsigned long long* out, double* sink) {
+__global__ __launch_bounds__(320, 2) void k(int mode, int iters, const double* src, long span, unsigned long long* out, double* sink) {
   __shared__ __attribute__((aligned(1024))) double lds[4096];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v4d acc[16];
@@ -16,6 +17,20 @@ __global__ __launch_bounds__(256, 2) void k(int mode, int iters, const double* s
   double a = 1.0 + lane * 1e-9, b = 1.0 - lane * 1e-9;
   double keep[2] = {0, 0};
   const double* p = src + ((long)blockIdx.x * 4 + wave) * 128 + 2 * lane;
+  if (wave == 4) {                       // (only launched in mode 7) the workgroup's loader: all its DMA, no MFMA
+    if (mode != 7) return;
+    for (int it = 0; it < iters; ++it) {
+      const double* q = p + ((long)it * 131072) % span;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned off = (unsigned)(size_t)(lds + (u & 3) * 128) + (u >> 2) * 4096;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(q + u * 65536), "s"(off) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
     if (mode >= 1 && mode <= 3) {
@@ -48,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k(int mode, int iters, const double* s
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(q + u * 65536), "s"(off) : "memory");
       }
     }
-    if (mode <= 1 || mode >= 3) {
+    if (mode <= 1 || mode >= 3) {   // (mode 7: waves 0-3 run the pure MFMA loop)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
@@ -70,11 +85,11 @@ int main() {
   hipMalloc(&src, (span + (1 << 20)) * sizeof(double)); hipMalloc(&sink, 8); hipMalloc(&out, nwg * 8 * sizeof(unsigned long long));
   hipMemset(src, 0, (span + (1 << 20)) * sizeof(double));
   std::vector<unsigned long long> h(nwg * 8);
-  for (int mode = 0; mode < 7; ++mode) {
+  for (int mode = 0; mode < 8; ++mode) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(256), 0, 0, mode, 2000, src, span, out, sink);   // warm-up
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(mode == 7 ? 320 : 256), 0, 0, mode, 2000, src, span, out, sink);   // warm-up
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(256), 0, 0, mode, iters, src, span, out, sink);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(mode == 7 ? 320 : 256), 0, 0, mode, iters, src, span, out, sink);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(h.data(), out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
