@@ -32,6 +32,8 @@ cd $R
 python3 tools/rocpd_stats.py $(find $OUT/${TAG}_kt5 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_c5.txt > /dev/null
 rm -rf $OUT/${TAG}_kt5
 timeout -k 10 300 python3 bench.py --config c5 --dtype f32 --grid-points 432 --no-cpu-baseline > $OUT/${TAG}_bench_c5_f32.json 2> $OUT/${TAG}_bench_c5_f32.err || exit 7
+timeout -k 10 300 python3 bench.py --config c3 --no-extras > $OUT/${TAG}_bench_c3.json 2> /dev/null || exit 12
+timeout -k 10 300 python3 bench.py --config c4 --no-extras > $OUT/${TAG}_bench_c4.json 2> /dev/null || exit 13
 timeout -k 10 120 python3 tools/loglik_rows_time.py > $OUT/${TAG}_loglik_rows.txt 2>&1 || exit 8
 BAYENS_W2_TRACE=1 timeout -k 10 300 python3 tools/w2_time.py > $OUT/${TAG}_w2_single.txt 2>&1 || exit 9
 timeout -k 10 120 python3 tools/diag16_bench.py > $OUT/${TAG}_diag16_bench.txt 2>&1 || exit 10
