@@ -266,15 +266,17 @@ def init_rccl(ctx, bootstrap):
 
 
 def weighted_posterior_sharded(n_members, local_ll, local_mean, local_var, exchange, normalise, barycentre,
-                               c_std=1.0):
+                               c_std=1.0, weights=None):
     """The exchange step + the replicated tail of the weighted posterior, written once for every transport
     (ensembles/weights.py:118-123 normalisation over ALL members, then ensemble_scheme.py:52-78).
 
     exchange.gather_rows(M, ll, mean, var) -> the three [M, P] tables (host arrays or device buffers, as the
     transport carries them); normalise(ll [M,P], c) -> w [M,P]; barycentre(w, mean, var) -> (mu [P], var [P], n_bad).
+    weights(ll, mean, var) -> w, when given, replaces normalise: weights that are functions of the members' moments
+    (ModelSimilarityWeight mode='temporal', weights.py:302-325) need the same three tables and nothing more.
     EVERY rank must call this (the gather is a collective).  Returns (w, mu, var)."""
     ll, mean, var = exchange.gather_rows(n_members, local_ll, local_mean, local_var)
-    w = normalise(ll, c_std)
+    w = weights(ll, mean, var) if weights is not None else normalise(ll, c_std)
     mu, v, _ = barycentre(w, mean, var)
     return w, mu, v
 

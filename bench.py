@@ -15,7 +15,8 @@ Launch:  python bench.py --gpus N --steps K --warmup W
 No PyTorch in the ranks: the 128-byte RCCL id travels through a file rendezvous, barrier and max-over-ranks are an
 ncclAllReduce.  Rank 0 prints ONE JSON line.
 
-Presets: --config c2 (default: 32 members/GPU, fp64 Matern-3/2), c3 (fp32 Matern-5/2), c4 (16 members/GPU = 128 members
+Presets: --config c2 (default: 32 members/GPU, fp64 Matern-3/2), c3 (fp32 Matern-5/2, weights = ModelSimilarityWeight
+mode='temporal'; its mode='single' table is timed beside it in the default line), c4 (16 members/GPU = 128 members
 over 8 GPUs).
 """
 from __future__ import annotations
@@ -72,11 +73,12 @@ def cpu_baseline(N, R, T, members):
 class Workload:
     """Resident inputs/outputs of one configuration on one rank and the step over them."""
 
-    def __init__(self, ctx, M, N, R, T, kernel, f32, rank, world, exchange, groups=1, R_obs=3):
+    def __init__(self, ctx, M, N, R, T, kernel, f32, rank, world, exchange, groups=1, R_obs=3, weighting="loglik"):
         from bayesian_ensembling_amd import _lib, parallel
         self.ctx, self.M, self.N, self.R, self.T, self.f32, self.R_obs = ctx, M, N, R, T, f32, R_obs
         self.kernel, self.kid, self.world, self.exchange, self.parallel = kernel, _lib.KERNEL_IDS[kernel], world, exchange, parallel
         self.Mtot = M * world
+        self.weighting = weighting        # "loglik": LogLikelihoodWeight; "w2_temporal": ModelSimilarityWeight(mode='temporal')
         X, y, nu, obs = make_inputs(M, N, R, R_obs, seed=0xB4E5 + rank)
         dt = np.float32 if f32 else np.float64
         self.dX, self.dy, self.dnu, self.dobs = ctx.to_device(X, dt), ctx.to_device(y, dt), ctx.to_device(nu, dt), ctx.to_device(obs)
@@ -113,13 +115,17 @@ class Workload:
         """Weights over ALL members + barycentre.  local_only: this rank's members alone, no collective (the untimed
         rank-0 diagnostics - a collective there would wait for ranks that have already left)."""
         c, M, N = self.ctx, self.M, self.N
-        if (self.exchange is None or local_only) and not self.f32:
+        temporal = self.weighting == "w2_temporal"
+        if (self.exchange is None or local_only) and not self.f32 and not temporal:
             # one GPU: the whole weighted posterior (rows -> weights -> barycentre) is one entry point, one host wait
             return c.weighted_posterior_dev(M, N, self.R_obs, self.dbasis, self.dld, self.dobs, self.dmu, self.dcov, self.dw,
                                             self.dbmu, self.dbvar, c_std=1e-3)
         self.local_rows()
         if self.exchange is None or local_only:
-            c.weights_normalise_dev(M, N, self.dll_loc, 1e-3, self.dw)
+            if temporal:
+                c.w2_temporal_dev(M, N, self.dmu64, self.dvar_loc, self.dw)
+            else:
+                c.weights_normalise_dev(M, N, self.dll_loc, 1e-3, self.dw)
             return c.barycentre_dev(M, N, self.dw, self.dmu64, self.dvar_loc, self.dbmu, self.dbvar)
         bad = []
 
@@ -131,8 +137,12 @@ class Workload:
             bad.append(c.barycentre_dev(self.Mtot, N, w, mean, var, self.dbmu, self.dbvar))
             return self.dbmu, self.dbvar, bad[-1]
 
+        def similarity(ll, mean, var):
+            c.w2_temporal_dev(self.Mtot, N, mean, var, self.dw)
+            return self.dw
+
         self.parallel.weighted_posterior_sharded(self.Mtot, self.dll_loc, self.dmu64, self.dvar_loc, self.exchange,
-                                                 normalise, barycentre, c_std=1e-3)
+                                                 normalise, barycentre, c_std=1e-3, weights=similarity if temporal else None)
         return bad[-1]
 
     def step(self):
@@ -484,7 +494,8 @@ def main():
         return
     M, N, R, T = args.members, args.timesteps, args.realisations, args.nits
     f32 = args.dtype == "f32"
-    wl = Workload(ctx, M, N, R, T, args.kernel, f32, rank, world, exchange, args.groups)
+    weighting = "w2_temporal" if args.config == "c3" else "loglik"      # C3 weights with ModelSimilarityWeight
+    wl = Workload(ctx, M, N, R, T, args.kernel, f32, rank, world, exchange, args.groups, weighting=weighting)
     elapsed = wl.timed(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = wl.Mtot * args.steps / elapsed
@@ -539,11 +550,12 @@ def main():
                           "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
         extra["config5"] = c5
         for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):
-            w2 = Workload(ctx, M, N, R, T, kern, is32, 0, 1, None)
+            w2 = Workload(ctx, M, N, R, T, kern, is32, 0, 1, None, weighting="w2_temporal" if is32 else "loglik")
             el = w2.timed(3, 1)
             r2 = w2.roofline()
             extra[key] = {"value": round(M * 3 / el, 3), "unit": "member-fits/s", "ms_per_step": round(el / 3 * 1e3, 3),
                           "dtype": "f32" if is32 else "f64", "kernel": kern,
+                          "weighting": "ModelSimilarityWeight(mode='temporal')" if is32 else "LogLikelihoodWeight",
                           "roofline": {k: r2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
                                                           "frac_on_padded_dims", "avg_launch_us")}}
             if is32:
@@ -573,7 +585,9 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{M}-member x {N}-timestep synthetic ensemble per GPU, R={R} realisations, "
-                               f"{args.kernel} VGP fit (n_optim_nits={T}) + LogLikelihoodWeight(c=1e-3) + Barycentre",
+                               f"{args.kernel} VGP fit (n_optim_nits={T}) + " +
+                               ("ModelSimilarityWeight(mode='temporal')" if weighting == "w2_temporal" else "LogLikelihoodWeight(c=1e-3)") +
+                               " + Barycentre",
                    "preset": args.config, "members_per_gpu": M, "members_total": M * world, "timesteps": N,
                    "realisations": R, "n_optim_nits": T, "kernel": args.kernel, "obs_realisations": wl.R_obs,
                    "member_groups": args.groups,
