@@ -145,16 +145,20 @@ void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info
 static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const real* mu_pad, real* chol,
                               double* logdet, real* basis) {
   const int nb = ws.nb, Np = ws.Np;
-  P.tri_copy(nb, Np, src, ws.T1);
   // bordering rows (1^T, mu^T): in the padding when the member has at least two padded rows (no extra rows to
   // drag through the factorisation), else in a 64-row block appended below the matrix
   const bool in_pad = Np - N >= 2;
   const int extra = (basis && !in_pad) ? LEAF : 0;
-  Mat rows = ws.T1.sub(in_pad ? N : Np, 0);
+  // The factorisation reads and writes the lower triangle only and `src` is not needed afterwards: factor it where it
+  // lies unless the appended rows are needed (only T1 has room for them) - one 2 N^2 pass less.
+  const bool in_place = extra == 0 && src.p != ws.T1.p;
+  Mat F = in_place ? src : ws.T1;
+  if (!in_place) P.tri_copy(nb, Np, src, ws.T1);
+  Mat rows = F.sub(in_pad ? N : Np, 0);
   if (basis) P.basis_rows_set(nb, N, Np, rows, mu_pad, in_pad ? 1 : 0);
-  potrf(P, nb, Np, ws.T1, ws.invL, ws.inv_stride(), ws.info, extra);
-  if (chol) P.extract(nb, N, ws.T1, chol, 2);
-  if (logdet) P.logdet(nb, N, ws.T1, logdet);
+  potrf(P, nb, Np, F, ws.invL, ws.inv_stride(), ws.info, extra);
+  if (chol) P.extract(nb, N, F, chol, 2);
+  if (logdet) P.logdet(nb, N, F, logdet);
   if (basis) P.basis_rows_get(nb, N, Np, rows, basis);
 }
 

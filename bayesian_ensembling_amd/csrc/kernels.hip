@@ -127,6 +127,10 @@ __global__ void init_vec_kernel(int nb, int N, int Np, real* theta1, real* mvec,
 }
 
 __global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
+  // src is lower triangular and dst only feeds the k-trimmed lower x lower product (G = W^T W), which reads the 64-blocks
+  // on or below the diagonal and, inside its 128 x 128 diagonal tiles, the one above it: the rest is neither read nor
+  // written here
+  if ((blockIdx.x >> 1) > (blockIdx.y >> 1)) return;
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Lin
 }
 
 __global__ void diag_init_kernel(int n, const real* nu, double add, Mat dst) {
+  if (blockIdx.x > blockIdx.y) return;     // the accumulation that follows, and everything after it, is lower-only
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
