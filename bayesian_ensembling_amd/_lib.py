@@ -11,7 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbayens.so")
-HEADER = os.path.join(HERE, "..", "include", "bayens.h")
+HEADER = os.path.join(HERE, "..", "include", "bayens.h")            # the drop-in boundary
+DIAG_HEADER = os.path.join(HERE, "..", "include", "bayens_diag.h")  # diagnostics / benchmarks (not part of the boundary)
 
 HOST, DEVICE = 0, 1
 MATERN32, MATERN52, RBF = 0, 1, 2
@@ -35,7 +36,7 @@ _lib = None
 
 def declared_symbols():
     """Every function name include/bayens.h declares (used by the CPU test that checks the exports)."""
-    txt = open(HEADER).read()
+    txt = open(HEADER).read() + open(DIAG_HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(bayens_[a-z0-9_]+)\s*\(", txt)))
 
@@ -95,6 +96,7 @@ def load():
     lib.bayens_inverse_square_weights.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.bayens_multi_model_mean.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
     lib.bayens_dba_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]
+    lib.bayens_comm_available.argtypes = [_vp]
     lib.bayens_comm_unique_id.argtypes = [_vp, _vp]
     lib.bayens_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
     lib.bayens_comm_destroy.argtypes = [_vp]
@@ -115,6 +117,7 @@ def load():
     lib.bayens_small_stamps.argtypes = [_vp, C.c_int, _vp]
     lib.bayens_bench_diag16.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
+    lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
 
@@ -558,6 +561,10 @@ class Context:
         return center, medoid
 
     # -- RCCL ------------------------------------------------------------------------------------------
+    def comm_available(self):
+        """Raises unless librccl can be loaded (load-only probe: no id drawn, no communicator)."""
+        self._check(self.lib.bayens_comm_available(self.h))
+
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
         self._check(self.lib.bayens_comm_unique_id(self.h, buf))
@@ -658,6 +665,15 @@ class Context:
         info = np.zeros(nb, dtype=np.int32)
         self._check(self.lib.bayens_test_potrf(self.h, nb, n, _ptr(A), _ptr(info)))
         return A, info
+
+    def test_member_rows_exchange(self, nranks, ll, mean, var):
+        """pack (per fictitious rank) -> gathered image -> unpack of bayens_allgather_member_rows, without RCCL."""
+        ll, mean, var = _f64(ll), _f64(mean), _f64(var)
+        M, P = ll.shape
+        out = [np.empty((M, P)) for _ in range(3)]
+        self._check(self.lib.bayens_test_member_rows_exchange(self.h, M, P, int(nranks), _ptr(ll), _ptr(mean), _ptr(var),
+                                                              _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+        return out
 
     def test_trsm(self, L, Bm, mode):
         L = _f64(L)

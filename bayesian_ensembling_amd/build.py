@@ -23,7 +23,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libbayens.so cannot be built on this host")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "bayens.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("bayens.h", "bayens_diag.h")]
     if not force and os.path.exists(LIB) and not any(_newer(d, LIB) for d in deps):
         return LIB
     bdir = os.path.join(HERE, "build")

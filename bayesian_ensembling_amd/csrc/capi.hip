@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/bayens.h"
+#include "../../include/bayens_diag.h"
 #include "driver.h"
 #include "fit_f32.h"
 #include "fit_ws.h"
@@ -654,6 +655,15 @@ struct FactorSolve {
     c->prims->pad_lower(B, N, Np, dchol, w.T2);
     c->prims->tri_inv64(B, Np, w.T2, w.invL, w.inv_stride(), w.info);
   }
+  // first member whose factor has a diagonal entry that is not a positive finite number (0 = none); one host wait
+  int bad_member(int* pivot) {
+    std::vector<int> h(B);
+    BAYENS_HIP(hipMemcpyAsync(h.data(), w.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < B; ++b)
+      if (h[b]) { *pivot = h[b]; return b + 1; }
+    return 0;
+  }
   Mat rows() const { return w.T1; }
   void solve() { trsm_rlt(*c->prims, B, LEAF, Np, w.T2, w.invL, w.inv_stride(), w.T1); }
 };
@@ -887,6 +897,13 @@ int bayens_mvn_log_prob(bayens_ctx* c, int loc, int B, int N, int n_x, int share
     const double* dx = st.in(x, (size_t)(shared_x ? 1 : B) * n_x * N);
     double* dout = st.out(log_prob, (size_t)B * n_x);
     FactorSolve fs(c, B, N, dch);
+    {
+      int pivot = 0;
+      if (const int bad = fs.bad_member(&pivot))
+        return fail(c, BAYENS_E_NOTPD, "mvn_log_prob: the factor of member " + std::to_string(bad - 1) +
+                                           " has a diagonal entry that is not positive and finite (row " +
+                                           std::to_string(pivot) + ")");
+    }
     double* tmp = st.scratch<double>((size_t)B * LEAF);
     for (int r0 = 0; r0 < n_x; r0 += LEAF) {           // 64 arguments per pass of the factor
       const int nr = n_x - r0 < LEAF ? n_x - r0 : LEAF;
@@ -1121,6 +1138,7 @@ int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const
       BAYENS_HIP(hipMemcpyAsync(v, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
       P.tri_absnorms(M, Np, Lp, bounds);
       tri_power(P, c->stream, M, Np, Lp, v, y, ones, bounds + (size_t)M * 4, W2_POWER_STEPS);
+      BAYENS_HIP(hipMemsetAsync(ws.info, 0, (size_t)M * sizeof(int), c->stream));
       P.tri_inv64(M, Np, Lp, ws.invL, ws.inv_stride(), ws.info);
       P.identity(M, Np, ws.T2);
       trsm_rln(P, M, Np, Np, Lp, ws.invL, ws.inv_stride(), ws.T2, true);
@@ -1129,7 +1147,14 @@ int w2_single_impl(bayens_ctx* c, int loc, int M, int N, const double* mu, const
       tri_power(P, c->stream, M, Np, ws.T2, v, y, ones, bounds + (size_t)M * 5, W2_POWER_STEPS);
       std::vector<double> hb((size_t)M * 6);
       BAYENS_HIP(hipMemcpyAsync(hb.data(), bounds, hb.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      std::vector<int> hinfo(M);
+      BAYENS_HIP(hipMemcpyAsync(hinfo.data(), ws.info, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       BAYENS_HIP(hipStreamSynchronize(c->stream));
+      for (int m = 0; m < M; ++m)
+        if (hinfo[m])
+          return fail(c, BAYENS_E_NOTPD, "w2_single: the factor of member " + std::to_string(m) +
+                                             " has a diagonal entry that is not positive and finite (row " +
+                                             std::to_string(hinfo[m]) + ")");
       for (int m = 0; m < M; ++m) {
         hi[m] = std::sqrt(hb[(size_t)m * 2] * hb[(size_t)m * 2 + 1]);
         lo[m] = 1.0 / std::sqrt(hb[(size_t)(M + m) * 2] * hb[(size_t)(M + m) * 2 + 1]);
@@ -1322,6 +1347,14 @@ int bayens_dba_batch(bayens_ctx* c, int loc, int B, int R, int N, const double* 
 }
 
 // ---- RCCL ---------------------------------------------------------------------------------------
+int bayens_comm_available(bayens_ctx* c) {
+  return guarded(c, [&]() {
+    std::string err;
+    if (!c->rccl.load(err)) return fail(c, BAYENS_E_COMM, err);
+    return 0;
+  });
+}
+
 int bayens_comm_unique_id(bayens_ctx* c, void* id128) {
   return guarded(c, [&]() {
     if (!id128) return fail(c, BAYENS_E_ARG, "comm_unique_id: null buffer");
@@ -1439,6 +1472,48 @@ int bayens_allgather_member_rows(bayens_ctx* c, int M, int P, int M_loc, const d
                        ll_all, mean_all, var_all);
     BAYENS_HIP(hipGetLastError());
     return 0;
+  });
+}
+
+// include/bayens_diag.h: the exchange's index arithmetic (pack per fictitious rank -> gathered image -> unpack), no RCCL
+int bayens_test_member_rows_exchange(bayens_ctx* c, int M, int P, int nranks, const double* ll, const double* mean,
+                                     const double* var, double* ll_out, double* mean_out, double* var_out) {
+  return guarded(c, [&]() {
+    if (M <= 0 || P <= 0 || nranks <= 0 || !ll || !mean || !var || !ll_out || !mean_out || !var_out)
+      return fail(c, BAYENS_E_ARG, "test_member_rows_exchange: bad argument");
+    const int rows = (M + nranks - 1) / nranks;
+    const size_t per_rank = (size_t)rows * 3 * P, tab = (size_t)M * P;
+    double* d = nullptr;
+    BAYENS_HIP(hipMalloc((void**)&d, (6 * tab + per_rank * nranks) * sizeof(double)));
+    double *din = d, *dout = d + 3 * tab, *gathered = d + 6 * tab;
+    int rc = 0;
+    auto body = [&]() -> int {
+      BAYENS_HIP(hipMemcpyAsync(din, ll, tab * 8, hipMemcpyHostToDevice, c->stream));
+      BAYENS_HIP(hipMemcpyAsync(din + tab, mean, tab * 8, hipMemcpyHostToDevice, c->stream));
+      BAYENS_HIP(hipMemcpyAsync(din + 2 * tab, var, tab * 8, hipMemcpyHostToDevice, c->stream));
+      BAYENS_HIP(hipMemsetAsync(gathered, 0xFF, per_rank * nranks * 8, c->stream));       // all-ones words = NaN
+      BAYENS_HIP(hipMemsetAsync(dout, 0xFF, 3 * tab * 8, c->stream));
+      const dim3 block(256);
+      for (int r = 0; r < nranks; ++r) {
+        int lo = 0, hi = 0;
+        bayens_shard_bounds(M, r, nranks, &lo, &hi);
+        if (hi > lo)
+          hipLaunchKernelGGL(pack_rows_kernel, dim3((P + 255) / 256, hi - lo, 3), block, 0, c->stream, hi - lo, P,
+                             din + (size_t)lo * P, din + tab + (size_t)lo * P, din + 2 * tab + (size_t)lo * P,
+                             gathered + per_rank * r);
+      }
+      hipLaunchKernelGGL(unpack_rows_kernel, dim3((P + 255) / 256, M, 3), block, 0, c->stream, M, nranks, rows, P, gathered,
+                         dout, dout + tab, dout + 2 * tab);
+      BAYENS_HIP(hipGetLastError());
+      BAYENS_HIP(hipMemcpyAsync(ll_out, dout, tab * 8, hipMemcpyDeviceToHost, c->stream));
+      BAYENS_HIP(hipMemcpyAsync(mean_out, dout + tab, tab * 8, hipMemcpyDeviceToHost, c->stream));
+      BAYENS_HIP(hipMemcpyAsync(var_out, dout + 2 * tab, tab * 8, hipMemcpyDeviceToHost, c->stream));
+      BAYENS_HIP(hipStreamSynchronize(c->stream));
+      return 0;
+    };
+    try { rc = body(); } catch (...) { (void)hipFree(d); throw; }
+    (void)hipFree(d);
+    return rc;
   });
 }
 

@@ -878,13 +878,15 @@ __global__ void pad_lower_kernel(int N, int Np, const double* src, Mat dst) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
 }
-// inverse of every 64x64 diagonal block of the padded factor: one workgroup per (block, member).  The block T is
-// re-factored from T T^T by the leaf routine of the blocked Cholesky, which returns the factor AND its inverse.
+// inverse of every 64x64 diagonal block of the padded factor: one workgroup per (block, member).  The triangular block
+// is inverted DIRECTLY by forward substitution (lane c solves T x = e_c in LDS; row i of T is a broadcast read), which is
+// backward stable in cond(T).  (Until round 3 the block was re-factored from T T^T by the Cholesky leaf: that squares
+// the condition number and could fail its pivot test on a valid, ill-conditioned factor.)  A diagonal entry that is not
+// a positive finite number is recorded in info[b] (1-based row of the padded matrix) - callers turn it into
+// BAYENS_E_NOTPD instead of returning garbage.
 __global__ __launch_bounds__(256) void tri_inv64_kernel(Mat Lp, real* inv, long inv_stride, int* info) {
   __shared__ double T[64][LS];
-  __shared__ double S[64][LS];
-  __shared__ double Mi[64][LS];
-  __shared__ double Tt[4][16][LT];
+  __shared__ double X[64][LS];
   const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const real* a = Lp.p + b * Lp.stride + (long)(64 * blk) * Lp.ld + 64 * blk;
   {
@@ -892,26 +894,26 @@ __global__ __launch_bounds__(256) void tri_inv64_kernel(Mat Lp, real* inv, long 
     for (int q = 0; q < 16; ++q) {
       const int r = r0 + 4 * q;
       T[r][c] = c <= r ? (double)a[(long)r * Lp.ld + c] : 0.0;
-      Mi[r][c] = 0.0;
     }
   }
   __syncthreads();
-  for (int rb = 0; rb < 4; ++rb) {          // S = T T^T (wave w: tile column w of every tile row; lower tiles are used)
-    const int cb = wave;
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    if (cb <= rb) {
-      for (int kb = 0; kb <= cb; ++kb) acc = tile_mma<true>(acc, T, 16 * rb, 16 * kb, T, 16 * cb, 16 * kb, lane, 1.0);
+  if (wave == 0) {
+    const int c = lane;
+    const double dc = T[c][c];
+    if (!(dc > 0.0) || !(dc < 1.79e308)) atomicCAS(&info[b], 0, 64 * blk + c + 1);      // NaN / inf / <= 0
+    for (int i = 0; i < 64; ++i) {
+      double acc = i == c ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) acc -= T[i][k] * X[k][c];        // X[k][c] == 0 for k < c
+      X[i][c] = c <= i ? acc / T[i][i] : 0.0;
     }
-    tile_store(S, 16 * rb, 16 * cb, lane, acc);
   }
   __syncthreads();
-  leaf_factor(S, Mi, Tt, b, tid, 64 * blk, info, nullptr);
   real* iv = inv + b * inv_stride + (long)blk * 4096;
   {
     const int c = tid & 63, r0 = tid >> 6;
     for (int q = 0; q < 16; ++q) {
       const int r = r0 + 4 * q;
-      iv[r * 64 + c] = c <= r ? Mi[r][c] : 0.0;
+      iv[r * 64 + c] = (real)X[r][c];
     }
   }
 }

@@ -17,8 +17,12 @@ barycentre are computed redundantly on every rank.  M need not divide by the num
 """
 from __future__ import annotations
 
+import io
+import json
 import os
-import pickle
+import stat
+import sys
+import threading
 import time
 
 import numpy as np
@@ -99,16 +103,76 @@ class HostGather(_HostRows):
         self.dist.barrier(group=self.group)
 
 
+def _encode(obj) -> bytes:
+    """Fixed wire formats (no pickle: a rendezvous file is read by every rank, so it must not be able to carry code):
+    b'B' + raw bytes | b'N' + .npy image (allow_pickle=False) | b'J' + JSON (None, bool, int, float, str, lists)."""
+    if isinstance(obj, (bytes, bytearray)):
+        return b"B" + bytes(obj)
+    if isinstance(obj, np.ndarray):
+        buf = io.BytesIO()
+        np.save(buf, np.ascontiguousarray(obj), allow_pickle=False)
+        return b"N" + buf.getvalue()
+    return b"J" + json.dumps(obj).encode()
+
+
+def _decode(raw: bytes):
+    kind, body = raw[:1], raw[1:]
+    if kind == b"B":
+        return body
+    if kind == b"N":
+        return np.load(io.BytesIO(body), allow_pickle=False)
+    if kind == b"J":
+        return json.loads(body.decode())
+    raise ValueError("rendezvous file with an unknown format tag")
+
+
 class FileRendezvous(_HostRows):
     """All-gather of small host payloads through a directory every rank can see (one node): each round, rank r
-    writes `<dir>/<round>.<r>` atomically (temp file + rename) and polls for the others'.  Carries the 128-byte RCCL
-    id before the communicator exists; with `gather_rows` it is also a complete (slow) exchange for rehearsing several
-    ranks on one GPU.  No third-party dependency."""
+    writes `<dir>/<session>.<round>.<r>` atomically (temp file + rename) and polls for the others'.  Carries the
+    128-byte RCCL id before the communicator exists; with `gather_rows` it is also a complete (slow) exchange for
+    rehearsing several ranks on one GPU.  No third-party dependency.
+
+    Safety of the directory (it may sit under a shared /tmp): it is created with mode 0700, and one that already
+    exists is accepted only if this user owns it and nobody else can write to it.  Payloads travel in fixed formats
+    (raw bytes / .npy without pickle / JSON), never pickle.  Every attempt has its own SESSION token - rank 0 draws it
+    and publishes it in `session.<restart count>` together with its pid; the other ranks take a session file only from
+    a LIVE rank 0 - so the round files of an earlier attempt in the same directory (a worker restart under the same
+    launcher) are never read."""
 
     def __init__(self, directory: str, rank: int, world: int, timeout_s: float = 300.0):
         self.dir, self.rank, self.world, self.timeout_s = directory, int(rank), int(world), timeout_s
         self.round = 0
-        os.makedirs(directory, exist_ok=True)
+        try:
+            os.makedirs(directory, mode=0o700)
+        except FileExistsError:
+            pass
+        st = os.stat(directory)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o022):
+            raise PermissionError(f"rendezvous directory {directory} is not a directory owned by this user that only "
+                                  "this user can write to: refusing to exchange through it")
+        self.session = self._open_session()
+
+    def _open_session(self) -> str:
+        restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        path = os.path.join(self.dir, f"session.{restart}")
+        if self.rank == 0:
+            token = f"{restart}-{os.urandom(8).hex()}"
+            with open(path + ".tmp", "wb") as f:
+                f.write(_encode({"token": token, "pid": os.getpid()}))
+            os.replace(path + ".tmp", path)              # replaces whatever an earlier attempt left behind
+            return token
+        deadline = time.time() + self.timeout_s
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    info = _decode(f.read())
+                os.kill(int(info["pid"]), 0)             # the rank 0 that wrote it is still alive: this attempt's session
+                return str(info["token"])
+            except (OSError, ValueError, KeyError, TypeError):
+                pass                                     # no file yet, a torn read, or a dead attempt's file: wait
+            if time.time() > deadline:
+                raise TimeoutError(f"rank {self.rank}: rank 0 never opened a rendezvous session in {self.dir}")
+            time.sleep(0.002)
 
     @staticmethod
     def directory_from_env():
@@ -118,14 +182,14 @@ class FileRendezvous(_HostRows):
         if d:
             return d
         key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
-        return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bayens_rdzv_{key}")
+        return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bayens_rdzv_{os.geteuid()}_{key}")
 
     def allgather_obj(self, obj):
-        tag = f"{self.round:06d}"
+        tag = f"{self.session}.{self.round:06d}"
         self.round += 1
         mine = os.path.join(self.dir, f"{tag}.{self.rank}")
         with open(mine + ".tmp", "wb") as f:
-            pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
+            f.write(_encode(obj))
         os.replace(mine + ".tmp", mine)
         out, deadline = [], time.time() + self.timeout_s
         for r in range(self.world):
@@ -135,7 +199,7 @@ class FileRendezvous(_HostRows):
                     raise TimeoutError(f"rank {self.rank}: rank {r} never reached rendezvous round {tag} in {self.dir}")
                 time.sleep(0.002)
             with open(path, "rb") as f:
-                out.append(pickle.load(f))
+                out.append(_decode(f.read()))
         return out
 
     def allgather(self, local: np.ndarray) -> np.ndarray:
@@ -155,10 +219,10 @@ class FileRendezvous(_HostRows):
         removes the directory when all markers are there (so no rank can find a file gone under its feet)."""
         self.barrier()
         if self.rank != 0:
-            open(os.path.join(self.dir, f"done.{self.rank}"), "wb").close()
+            open(os.path.join(self.dir, f"{self.session}.done.{self.rank}"), "wb").close()
             return
         deadline = time.time() + self.timeout_s
-        while any(not os.path.exists(os.path.join(self.dir, f"done.{r}")) for r in range(1, self.world)):
+        while any(not os.path.exists(os.path.join(self.dir, f"{self.session}.done.{r}")) for r in range(1, self.world)):
             if time.time() > deadline:
                 return
             time.sleep(0.002)
@@ -173,16 +237,46 @@ class FileRendezvous(_HostRows):
             pass
 
 
+class CommInitWatchdog:
+    """Bounds the time a rank may spend inside ncclCommInitRank.  RCCL's bootstrap is a blocking rendezvous of ALL
+    ranks: if one peer failed before entering it (or died inside it), the others wait forever.  While the guarded block
+    runs, a timer thread is armed; if it fires, the process reports and leaves with exit code 75 (`os._exit`: the main
+    thread is stuck in a C call and cannot be interrupted), and the parent - bench.py's spawn_ranks or the launcher -
+    terminates the remaining ranks.  A run that loses its communicator therefore ENDS, non-zero, instead of hanging."""
+
+    EXIT_CODE = 75
+
+    def __init__(self, rank, timeout_s, what="ncclCommInitRank", _exit=os._exit):
+        self.rank, self.timeout_s, self.what, self._exit = rank, float(timeout_s), what, _exit
+        self._timer = None
+
+    def _fire(self):
+        print(f"rank {self.rank}: {self.what} did not return within {self.timeout_s:.0f} s - a peer never joined the "
+              "communicator; leaving with exit code %d" % self.EXIT_CODE, file=sys.stderr, flush=True)
+        self._exit(self.EXIT_CODE)
+
+    def __enter__(self):
+        self._timer = threading.Timer(self.timeout_s, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
 class RcclExchange:
     """Device rows over RCCL (ncclAllGather / ncclAllReduce inside libbayens, over xGMI).  `bootstrap` is any object
     with rank / world / broadcast_bytes (FileRendezvous, HostGather): rank 0 draws the ncclUniqueId, everyone
-    receives it, then joins the communicator."""
+    receives it, then joins the communicator (bounded by CommInitWatchdog)."""
 
-    def __init__(self, ctx, bootstrap):
+    def __init__(self, ctx, bootstrap, init_timeout_s=180.0):
         self.ctx, self.rank, self.world = ctx, bootstrap.rank, bootstrap.world
         uid = ctx.comm_unique_id() if self.rank == 0 else b""
         uid = bootstrap.broadcast_bytes(uid, 128, src=0)
-        ctx.comm_init(self.rank, self.world, uid)
+        with CommInitWatchdog(self.rank, init_timeout_s):
+            ctx.comm_init(self.rank, self.world, uid)
         self._out = {}
 
     def gather_rows(self, n_members, ll_loc, mean_loc, var_loc):
@@ -203,30 +297,49 @@ class RcclExchange:
         self.ctx.comm_destroy()
 
 
-def make_exchange(ctx, rdzv, prefer="rccl"):
-    """The rows exchange of a multi-rank run: RCCL when every rank can load it and the communicator comes up, else the
-    host-staged transport over the rendezvous - decided by ALL ranks together, so that no rank waits inside
-    ncclCommInitRank for a peer that has already given up.  Returns (exchange, kind, note)."""
+class ExchangeUnavailable(RuntimeError):
+    """RCCL could not be loaded / the communicator did not come up and the host-staged exchange was not allowed."""
+
+
+def make_exchange(ctx, rdzv, prefer="rccl", allow_host_exchange=False, init_timeout_s=180.0):
+    """The rows exchange of a multi-rank run, decided by ALL ranks together.  Returns (exchange, kind, note).
+
+    prefer="rccl" (the product): RCCL, or an error.  Phase 1 is a LOAD-ONLY probe (`ctx.comm_available()`: dlopen + symbol
+    lookup; no ncclUniqueId is drawn, so no bootstrap listener is left behind) whose result the ranks compare through the
+    rendezvous: a rank that cannot load librccl stops everybody BEFORE anyone enters the blocking ncclCommInitRank.
+    Phase 2 brings the communicator up under CommInitWatchdog and the ranks compare notes again.  A failure is fatal -
+    `ExchangeUnavailable` on every rank that can still speak, exit code 75 from a rank stuck inside RCCL - unless
+    `allow_host_exchange` (bench.py --allow-host-exchange) explicitly permits the host-staged transport: that one moves
+    the rows through the rendezvous directory, is a rehearsal transport, and says so in config.exchange = "file".
+    Phase 2 assumes nothing about symmetry: ncclCommInitRank failing on ONE rank leaves its peers blocked inside it,
+    which is exactly what the watchdog (and the parent's terminate-on-first-failure) is for.
+
+    prefer="file": the host-staged transport, asked for by name (several ranks rehearsing on ONE GPU)."""
     if prefer != "rccl":
         return HostStagedExchange(ctx, rdzv), "file", None
-    try:                                   # phase 1: can this rank load librccl at all?  (no communicator yet)
-        ctx.comm_unique_id()
-        mine = (True, "")
+    try:                                   # phase 1: can this rank load librccl at all?  (no communicator, no id)
+        ctx.comm_available()
+        mine = [True, ""]
     except Exception as e:                 # noqa: BLE001 - whatever it is, the peers must hear about it
-        mine = (False, f"rank {rdzv.rank}: {e}")
+        mine = [False, f"rank {rdzv.rank}: {e}"]
     flags = rdzv.allgather_obj(mine)
     if all(f[0] for f in flags):
-        try:                               # phase 2: bring the communicator up (a failure here is symmetric)
-            ex = RcclExchange(ctx, rdzv)
-            mine = (True, "")
+        try:                               # phase 2: bring the communicator up (bounded by the watchdog)
+            ex = RcclExchange(ctx, rdzv, init_timeout_s)
+            mine = [True, ""]
         except Exception as e:             # noqa: BLE001
-            ex, mine = None, (False, f"rank {rdzv.rank}: {e}")
+            ex, mine = None, [False, f"rank {rdzv.rank}: {e}"]
+        # (a peer stuck inside ncclCommInitRank never reaches this round: this rank then times out in the rendezvous
+        #  or is terminated by the parent when the stuck rank's watchdog fires - either way the run ends non-zero)
         flags = rdzv.allgather_obj(mine)
         if all(f[0] for f in flags):
             return ex, "rccl", None
         if ex is not None:
             ex.close()
     note = next(f[1] for f in flags if not f[0])
+    if not allow_host_exchange:
+        raise ExchangeUnavailable("RCCL exchange unavailable (" + note + "); pass --allow-host-exchange / "
+                                  "allow_host_exchange=True to rehearse over the host-staged transport instead")
     return HostStagedExchange(ctx, rdzv), "file", "RCCL unavailable, host-staged exchange used instead: " + note
 
 

@@ -457,6 +457,11 @@ def main():
                     help="f64 = the reference precision (the headline); f32 = BASELINE config 3 (1e-3 parity bar)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "file"],
                     help="N > 1 transport: rccl (the product) or file = host-staged rehearsal for several ranks on one GPU")
+    ap.add_argument("--allow-host-exchange", action="store_true",
+                    help="with --exchange rccl: if RCCL cannot be loaded or the communicator does not come up, fall back to "
+                         "the host-staged exchange instead of exiting non-zero (rehearsals only; config.exchange says 'file')")
+    ap.add_argument("--comm-init-timeout", type=float, default=180.0,
+                    help="seconds a rank may spend inside ncclCommInitRank before it gives up with exit code 75")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (T=500, config 3, RBF)")
     ap.add_argument("--cpu-members", type=int, default=2)
@@ -487,7 +492,17 @@ def main():
     force_comm = bool(os.environ.get("BAYENS_FORCE_COMM"))    # exercise the RCCL path with a single rank
     if world > 1 or force_comm:
         rdzv = parallel.FileRendezvous(parallel.FileRendezvous.directory_from_env(), rank, world)
-        exchange, args.exchange, args.exchange_note = parallel.make_exchange(ctx, rdzv, args.exchange)
+        try:
+            exchange, args.exchange, args.exchange_note = parallel.make_exchange(
+                ctx, rdzv, args.exchange, allow_host_exchange=args.allow_host_exchange, init_timeout_s=args.comm_init_timeout)
+        except parallel.ExchangeUnavailable as e:
+            # strict by default: a multi-rank line measured through /tmp files must never pass for an RCCL measurement
+            print(f"rank {rank}: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        if args.exchange == "rccl":
+            r_, n_, _ = ctx.comm_info()
+            if n_ != world or r_ != rank:
+                raise SystemExit(f"rank {rank}: communicator reports rank {r_} of {n_}, expected {rank} of {world}")
 
     if args.config == "c5":
         run_config5(args, ctx, rank, world, exchange, rdzv)
@@ -500,6 +515,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = wl.Mtot * args.steps / elapsed
     rccl_lib = ctx.comm_info()[2] if exchange is not None and args.exchange == "rccl" else None
+    rccl_ranks = ctx.comm_info()[1] if exchange is not None and args.exchange == "rccl" else 0
     if exchange is not None:        # every rank leaves the communicator here; what follows on rank 0 is local
         exchange.close()
         rdzv.close()
@@ -596,7 +612,7 @@ def main():
                    "member_groups": args.groups,
                    "parallelism": (f"member-sharded x{world}, one RCCL all-gather of packed [M_loc,3,N] rows per step"
                                    if world > 1 else "single GPU"),
-                   "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib,
+                   "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib, "rccl_ranks": rccl_ranks,
                    "exchange_note": getattr(args, "exchange_note", None)},
         "roofline": roof, "cpu_baseline": cpu,
     }

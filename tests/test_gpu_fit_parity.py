@@ -177,6 +177,28 @@ def test_fp32_fit_against_the_fp64_oracle(ctx, M, N, R, T, kernel):
             assert relerr(out["basis"][m, 1].astype(np.float64), sla.solve_triangular(Lc, mo, lower=True)) < 10 * F32_TOL
 
 
+def test_fp32_fuzz_case_whose_loss_sample_passes_near_zero(ctx):
+    """Round 2's randomised sweep (profiles/r02_fuzz_seed11.log, case 12: M=3, N=65, R=8, T=3, Matern-5/2, fp32) reported
+    "max rel err 2.88e-3" without saying of what.  It is the -ELBO SAMPLE of member 2: 0.0096, the sum of terms of size
+    ~75 (sum_t 1/2 log nu_t = -75.3, the quadratic term +40.7, the KL +34.6).  An fp32 error of 3.7e-7 RELATIVE TO THE
+    TERMS is 2.9e-3 relative to a loss that happens to pass near zero; the posterior itself (mu, cov, hypers) of the same
+    fit sits at 1e-5.  The loss is therefore held to 1e-3 of the magnitude of its terms (which is what an fp32 evaluation
+    can promise), everything else to BASELINE's 1e-3 - asserted 30 x tighter."""
+    M, N, R, T, kernel = 3, 65, 8, 3, 1
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=625353)
+    X, y, nu = member_inputs(data)
+    for dtype, tol in ((np.float32, F32_TOL), (np.float64, 1e-9)):
+        out = ctx.gp_fit_batch(X, y, nu, T, kernel=kernel, dtype=dtype, want_loss=True)
+        assert not out["info"].any()
+        for m in range(M):
+            mo, co, ho, lo = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel, loss_every=25)
+            assert relerr(out["mu"][m].astype(np.float64), mo) < tol / 30 and relerr(out["hyp"][m], ho) < tol / 30
+            assert relerr(out["cov"][m].astype(np.float64), co) < tol / 30
+            scale = abs(np.sum(0.5 * go.LOG2PI + 0.5 * np.log(nu[m])))        # the loss's largest term
+            assert scale > 60 and np.all(np.abs(out["loss"][m] - lo) < tol * scale), (m, out["loss"][m], lo)
+    assert abs(lo[0]) < 0.02             # member 2: the sample that made the sweep's relative figure meaningless
+
+
 def test_fp32_full_size_is_finite_and_close_to_fp64(ctx):
     """Config 3 size (32-member batch trimmed to 4 for the test's run time): fp32 against the fp64 device path."""
     data, _ = go.synthetic_ensemble(4, 2000, R=8, seed=2)
@@ -208,19 +230,27 @@ def test_benchmarked_batch_sizes_small_members_all_against_the_oracle(ctx, M):
 @pytest.mark.parametrize("M", [16, 32])
 def test_benchmarked_configuration_full_size(ctx, M):
     """BASELINE config 2 exactly as bench.py runs it (32 x 2000, R = 8, T = 2; 16 = config 4's per-GPU share), on
-    resident buffers: members 0 / M/2-1 / M-1 against the oracle, and EVERY member bit-equal to the same member fitted
-    in a batch of 4 (the triangular GEMM launches deal tiles differently when nb % 8 == 0, gemm.hip)."""
+    resident buffers: members 0 / M/2-1 / M-1 against the oracle, EVERY member bit-equal to the same member fitted
+    in a batch of 4 (the triangular GEMM launches deal tiles differently when nb % 8 == 0, gemm.hip), and the weighted
+    posterior of the step (bayens_weighted_posterior: rows -> weights -> barycentre) against the oracle's
+    weights.py:88-123 / ensemble_scheme.py:52-78 evaluated on the device's own (mu, chol, logdet)."""
     N, R, T = 2000, 8, 2
-    data, _ = go.synthetic_ensemble(M, N, R=R, seed=0xB4E5)
+    data, obs = go.synthetic_ensemble(M, N, R=R, seed=0xB4E5)
     X, y, nu = member_inputs(data)
     dX, dy, dnu = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu)
     dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
     dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
-    bufs = [dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis]
+    R_obs = 3
+    dobs, dw, dbmu, dbvar = ctx.to_device(obs), ctx.empty((M, N)), ctx.empty((N,)), ctx.empty((N,))
+    bufs = [dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis, dobs, dw, dbmu, dbvar]
     try:
         info = ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
         assert not info.any()
+        # the weighted posterior exactly as bench.py's step runs it (one entry point on the resident posteriors)
+        bad = ctx.weighted_posterior_dev(M, N, R_obs, dbasis, dld, dobs, dmu, dcov, dw, dbmu, dbvar, c_std=1e-3)
+        w_dev, bmu_dev, bvar_dev = dw.download(), dbmu.download(), dbvar.download()
         mu, hyp, ld, basis = dmu.download(), dhyp.download(), dld.download(), dbasis.download()
+        ll_ref, var_ref = np.empty((M, N)), np.empty((M, N))
         for b0 in range(0, M, 4):
             ref = ctx.gp_fit_batch(X[b0:b0 + 4], y[b0:b0 + 4], nu[b0:b0 + 4], T)
             assert np.array_equal(mu[b0:b0 + 4], ref["mu"]) and np.array_equal(hyp[b0:b0 + 4], ref["hyp"]), b0
@@ -230,9 +260,20 @@ def test_benchmarked_configuration_full_size(ctx, M):
                 ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, cov.ctypes.data, dcov.offset((b0 + j) * N * N * 8), cov.nbytes))
                 ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, ch.ctypes.data, dchol.offset((b0 + j) * N * N * 8), ch.nbytes))
                 assert np.array_equal(cov, ref["cov"][j]) and np.array_equal(ch, ref["chol"][j]), b0 + j
+                # oracle rows on the device's own (mu, chol, logdet): weights.py:98-104
+                ll_ref[b0 + j] = go.loglik_mean_rows(go.mvn_constvec_loglik(mu[b0 + j], ch, ld[b0 + j], obs))
+                var_ref[b0 + j] = np.diag(cov)
                 if b0 + j in (0, M // 2 - 1, M - 1):
                     mo, co, ho = go.gp_fit(X[b0 + j], y[b0 + j], nu[b0 + j], T)
                     assert relerr(mu[b0 + j], mo) < 1e-9 and relerr(cov, co) < 1e-9 and relerr(hyp[b0 + j], ho) < 1e-9
+        # north_star: "matching reference weights to 1e-5" at 32 x 2000 - the normalisation and the barycentre deal the
+        # members over four waves (kernels.hip), so M = 32 is where that dealing is exercised at size
+        w_ref, _ = go.loglik_weights(ll_ref, 1e-3)
+        rm, rv, rbad = go.barycentre(w_ref, mu, var_ref)
+        assert np.isfinite(w_ref).all() and bad == rbad == 0
+        assert relerr(w_dev, w_ref) < REL_TOL and relerr(bmu_dev, rm) < REL_TOL and relerr(bvar_dev, rv) < REL_TOL
+        assert relerr(w_dev, w_ref) < 1e-9 and relerr(bmu_dev, rm) < 1e-9 and relerr(bvar_dev, rv) < 1e-9     # (measured)
+        assert np.allclose(w_dev.sum(axis=0), 1.0, rtol=1e-12)
     finally:
         for b in bufs:
             b.free()

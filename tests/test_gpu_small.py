@@ -119,3 +119,47 @@ def test_fp32_instance_at_batch_scale(ctx):
             assert relerr(out["mu"][m].astype(np.float64), mo) < 1e-3 and relerr(out["cov"][m].astype(np.float64), co) < 1e-3, m
             assert relerr(out["chol"][m].astype(np.float64), Lc) < 1e-3 and relerr(out["hyp"][m], ho) < 1e-3, m
             assert abs(out["logdet"][m] - ld) < 1e-3 * abs(ld) and np.allclose(out["loss"][m], lo, rtol=1e-3), m
+
+
+def test_config5_weighting_step_over_the_chunk_boundary(ctx):
+    """BASELINE config 5's weighting half, which bench.py times: a field of posteriors [M][G] (b = m * G + g) ->
+    bayens_loglik_rows_basis_grouped (one observation set per grid point: `b % n_groups`) -> normalisation over the
+    members -> barycentre, at B = 32 * 1100 = 35 200 > 32 768, so that the second chunk of the row kernel's grid runs
+    (kernels.hip: `b0` loop) - against the oracle PER GRID POINT on a sample of points that includes the last posterior
+    of chunk 1 (b = 32 767: member 29, point 867) and the first of chunk 2 (point 868).
+    Reference: ensembles/weights.py:88-123 (rows, exp, normalisation over 'model'), ensemble_scheme.py:52-78 (space
+    flattened into the point axis), wasserstein.py:61-100."""
+    M, G, N, R, R_obs, T = 32, 1100, 30, 4, 3, 2
+    B, P = M * G, G * N
+    rng = np.random.default_rng(0xC5)
+    tau = np.linspace(0.0, 1.0, N)
+    amp = 0.8 + 0.4 * rng.random((M, 1, 1, 1))
+    loc = 1.0 + 0.2 * rng.standard_normal((1, G, 1, 1))
+    data = (1.5 * amp * loc * tau ** 2 + 0.036 * rng.standard_normal((M, G, R, N)).cumsum(axis=3)).reshape(B, R, N)
+    obs = 1.5 * loc[0] * tau ** 2 + 0.036 * rng.standard_normal((G, R_obs, N)).cumsum(axis=2)      # [G][R_obs][N]
+    X, y, nu = member_inputs(data)
+    red = ctx.gp_fit_batch_reduced(X, y, nu, T)
+    assert not red["info"].any()
+    ll = ctx.loglik_rows_basis_grouped(red["basis"], red["logdet"], obs)
+    assert ll.shape == (B, N) and np.isfinite(ll).all()
+    c_std = 1e-2
+    w = ctx.weights_normalise(ll.reshape(M, P), c_std)
+    bmu, bvar, bad = ctx.barycentre(w, red["mu"].reshape(M, P), red["var"].reshape(M, P))
+    assert bad == 0 and np.allclose(w.sum(axis=0), 1.0, rtol=1e-12)
+    assert (32767 // G, 32767 % G) == (29, 867)
+    with threadpool_limits(1):
+        for g in (0, 1, 500, 867, 868, 869, G - 1):
+            mus, vars_, lls = [], [], []
+            for m in range(M):
+                b = m * G + g
+                mo, co, _ = go.gp_fit(X[b], y[b], nu[b], T)
+                Lc, ld = go.mvn_factor(co)
+                lls.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, Lc, ld, obs[g])))
+                mus.append(mo); vars_.append(np.diag(co))
+                assert relerr(red["mu"][b], mo) < 1e-10 and relerr(red["var"][b], vars_[-1]) < 1e-10, (g, m)
+            lls, mus, vars_ = np.stack(lls), np.stack(mus), np.stack(vars_)
+            assert relerr(ll.reshape(M, G, N)[:, g], lls) < 1e-10, g
+            w_ref, _ = go.loglik_weights(lls, c_std)
+            assert relerr(w.reshape(M, G, N)[:, g], w_ref) < 1e-9, g
+            rm, rv, _ = go.barycentre(w_ref, mus, vars_)
+            assert relerr(bmu.reshape(G, N)[g], rm) < 1e-9 and relerr(bvar.reshape(G, N)[g], rv) < 1e-9, g

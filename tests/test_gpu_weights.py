@@ -422,3 +422,112 @@ def test_perfect_model_test_metrics_against_the_oracle(ctx, tmp_path):
     assert abs(got[4] + np.mean(go.normal_loglik(mm, mv, obs_fut))) < 1e-9
     assert abs(got[5] - np.mean(np.sqrt(np.mean((mm[None] - obs_fut) ** 2, axis=0)))) < 1e-12
     assert abs(got[6] - go.gaussian_w2(mm, np.diag(mv ** 2), om, np.diag(np.diag(oc)))) < 1e-8
+
+
+# ---- round 3: the members' sums at the benchmarked ensemble sizes, the exchange's index arithmetic, size -----------
+@pytest.mark.parametrize("M,P", [(32, 2000), (33, 2000), (128, 517), (32, 148608)])
+def test_member_sums_at_benchmarked_ensemble_sizes(ctx, M, P):
+    """normalise / barycentre / w2_temporal deal the members over four waves per 64 points (kernels.hip); the unit tests
+    above stop at M = 10.  Here: M = 32 (configs 2, 3), 33 (not a multiple of the four waves), 128 (config 4's table after
+    the all-gather) and P = 1728 x 86 (config 5's per-GPU point axis) - against the oracle's weights.py:107,118-123,
+    302-325 and ensemble_scheme.py:52-78."""
+    rng = np.random.default_rng(M * 7 + P)
+    ll = -300.0 - 2000.0 * rng.random((M, P))
+    w, raw = ctx.weights_normalise(ll, 1e-3, return_raw=True)
+    w_ref, raw_ref = go.loglik_weights(ll, 1e-3)
+    assert relerr(w, w_ref) < 1e-13 and relerr(raw, raw_ref) < 1e-13 and np.allclose(w.sum(axis=0), 1.0, rtol=1e-13)
+    mean, var = rng.standard_normal((M, P)), rng.uniform(0.01, 9.0, (M, P))
+    mu, v, bad = ctx.barycentre(w, mean, var)
+    rm, rv, rbad = go.barycentre(w_ref, mean, var)
+    assert bad == rbad == 0 and relerr(mu, rm) < 1e-13 and relerr(v, rv) < 1e-12
+    if P <= 2000:
+        assert relerr(ctx.w2_temporal(mean, var), go.w2_weights_temporal(mean, var)) < 1e-13
+
+
+@pytest.mark.parametrize("M,nranks", [(5, 2), (7, 3), (128, 8), (3, 4), (9, 1)])
+def test_member_rows_exchange_pack_and_unpack(ctx, M, nranks):
+    """The device side of bayens_allgather_member_rows around the collective: pack_rows_kernel per rank into the gathered
+    image [nranks][ceil(M/nranks)][3][P] and unpack_rows_kernel back into three [M][P] tables, uneven shards (and ranks
+    with no member at all) included - against the host twin parallel.pack_rows / unpack_rows that the gloo tests drive."""
+    from bayesian_ensembling_amd import parallel
+    P = 301
+    rng = np.random.default_rng(M * 10 + nranks)
+    ll, mean, var = rng.standard_normal((3, M, P))
+    got = ctx.test_member_rows_exchange(nranks, ll, mean, var)
+    rows = parallel.padded_rows(M, nranks)
+    image = np.concatenate([parallel.pack_rows(ll[lo:hi], mean[lo:hi], var[lo:hi], rows)
+                            for lo, hi in (parallel.shard_bounds(M, r, nranks) for r in range(nranks))], axis=0)
+    ref = parallel.unpack_rows(image, M, nranks)
+    for g, r, src in zip(got, ref, (ll, mean, var)):
+        assert np.array_equal(g, r) and np.array_equal(g, src)
+
+
+def test_allgather_member_rows_on_a_one_rank_communicator(ctx):
+    """The exchange entry point itself (pack -> ncclAllGather -> unpack on the context's stream) over RCCL with one rank:
+    the three tables must come back bit-identical; a wrong M_loc is refused."""
+    M, P = 6, 777
+    rng = np.random.default_rng(6)
+    tabs = rng.standard_normal((3, M, P))
+    d_in = [ctx.to_device(t) for t in tabs]
+    d_out = [ctx.empty((M, P)) for _ in range(3)]
+    ctx.comm_init(0, 1, ctx.comm_unique_id())
+    try:
+        assert ctx.comm_info()[:2] == (0, 1)
+        ctx.allgather_member_rows(M, P, M, *d_in, *d_out)
+        ctx.sync()
+        for t, d in zip(tabs, d_out):
+            assert np.array_equal(d.download(), t)
+        from bayesian_ensembling_amd._lib import BayensError
+        with pytest.raises(BayensError):
+            ctx.allgather_member_rows(M, P, M - 1, *d_in, *d_out)
+        assert ctx.comm_max(3.25) == 3.25
+    finally:
+        ctx.comm_destroy()
+        for d in d_in + d_out:
+            d.free()
+
+
+def test_w2_single_pair_at_the_benchmarked_order(ctx):
+    """mode='single' at N = 2000 (bench.py's config-3 weighting step runs 496 such pairs): two fitted members, the polar
+    iteration with this size's starting interval and stopping rule against the oracle's SVD formula
+    (wasserstein.py:10-13, 21-47)."""
+    data, _, out = _posteriors(ctx, 2, 2000, R=8, seed=0xB4E5)
+    w, D = ctx.w2_single(out["mu"], chol=out["chol"])
+    ref = go.gaussian_w2(out["mu"][0], out["cov"][0], out["mu"][1], out["cov"][1])
+    assert abs(D[0, 1] - ref) < 1e-8 * abs(ref) and D[0, 1] == D[1, 0] and D[0, 0] == 0.0 == D[1, 1]
+    assert relerr(w, np.array([0.5, 0.5])) < 1e-14
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e6, 1e8])
+def test_log_prob_with_an_ill_conditioned_factor(ctx, cond):
+    """bayens_mvn_log_prob inverts the 64 x 64 diagonal blocks of the CALLER's factor (capi.hip: FactorSolve): by direct
+    forward substitution (error ~ cond(L) eps), not by re-factoring L L^T (cond^2) - against the oracle's mvn_logprob."""
+    rng = np.random.default_rng(int(np.log10(cond)))
+    B, N, n_x = 2, 150, 5
+    chol = np.empty((B, N, N))
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        sv = np.logspace(0, -np.log10(cond), N)
+        Lq = np.linalg.qr(((Q * sv) @ np.linalg.qr(rng.standard_normal((N, N)))[0]).T)[1].T    # lower, singular values sv
+        chol[b] = Lq * np.sign(np.diag(Lq))[None, :]
+    logdet = np.log(np.abs(np.diagonal(chol, axis1=1, axis2=2))).sum(axis=1)
+    mu = rng.standard_normal((B, N))
+    z = rng.standard_normal((B, n_x, N))
+    x = mu[:, None, :] + np.einsum("bij,bxj->bxi", chol, z)            # so that the quadratic form is O(N), not 1/sv^2
+    got = ctx.mvn_log_prob(mu, chol, logdet, x)
+    ref = np.stack([go.mvn_logprob(mu[b], chol[b], logdet[b], x[b]) for b in range(B)])
+    assert np.allclose(np.linalg.cond(chol[0]), cond, rtol=1e-3)
+    assert relerr(got, ref) < 1e-15 * cond * N + 1e-12, relerr(got, ref)
+
+
+def test_log_prob_refuses_a_factor_with_a_non_positive_diagonal(ctx):
+    from bayesian_ensembling_amd._lib import BayensError
+    N = 70
+    chol = np.stack([np.eye(N), np.eye(N)])
+    chol[1, 66, 66] = 0.0
+    with pytest.raises(BayensError) as e:
+        ctx.mvn_log_prob(np.zeros((2, N)), chol, np.zeros(2), np.zeros((1, N)))
+    assert e.value.code == -2 and "member 1" in str(e.value) and "row 67" in str(e.value)
+    chol[1, 66, 66] = np.nan
+    with pytest.raises(BayensError):
+        ctx.mvn_log_prob(np.zeros((2, N)), chol, np.zeros(2), np.zeros((1, N)))

@@ -112,48 +112,125 @@ def test_w2_single_sharded_rejects_uneven_shards():
 
 
 class _FakeCommCtx:
-    """Stands in for _lib.Context in make_exchange: `fail_at` = None | 'load' | 'init' picks where this rank's RCCL breaks."""
+    """Stands in for _lib.Context in make_exchange: `fail_at` = None | 'load' | 'init' picks where this rank's RCCL breaks;
+    `block_init`: comm_init never returns (a rank inside ncclCommInitRank whose peer never joined)."""
 
-    def __init__(self, fail_at):
-        self.fail_at, self.inited, self.destroyed = fail_at, False, False
+    def __init__(self, fail_at, block_init=False):
+        self.fail_at, self.block_init, self.inited, self.destroyed, self.ids_drawn = fail_at, block_init, False, False, 0
 
-    def comm_unique_id(self):
+    def comm_available(self):
         if self.fail_at == "load":
             raise RuntimeError("librccl.so: cannot open shared object file")
+
+    def comm_unique_id(self):
+        self.ids_drawn += 1
         return bytes(128)
 
     def comm_init(self, rank, world, uid):
         if self.fail_at == "init":
             raise RuntimeError("ncclCommInitRank: invalid usage")
+        if self.block_init:
+            import time
+            time.sleep(3600)
         self.inited = True
 
     def comm_destroy(self):
         self.destroyed = True
 
 
-def _consensus_worker(rank, world, rdzv_dir, failing_rank, fail_at, out_dir):
+def _consensus_worker(rank, world, rdzv_dir, failing_rank, fail_at, out_dir, allow):
     rdzv = parallel.FileRendezvous(rdzv_dir, rank, world, timeout_s=60)
     ctx = _FakeCommCtx(fail_at if rank == failing_rank else None)
-    ex, kind, note = parallel.make_exchange(ctx, rdzv, "rccl")
+    try:
+        ex, kind, note = parallel.make_exchange(ctx, rdzv, "rccl", allow_host_exchange=allow)
+        res = f"{kind}|{type(ex).__name__}|{ctx.inited}|{ctx.destroyed}|{ctx.ids_drawn}|{note}"
+    except parallel.ExchangeUnavailable as e:
+        res = f"refused|None|{ctx.inited}|{ctx.destroyed}|{ctx.ids_drawn}|{e}"
     with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
-        f.write(f"{kind}|{type(ex).__name__}|{ctx.inited}|{ctx.destroyed}|{note}")
+        f.write(res)
     rdzv.close()
 
 
+@pytest.mark.parametrize("allow", [False, True])
 @pytest.mark.parametrize("fail_at,failing_rank", [(None, 0), ("load", 1), ("init", 0), ("init", 2)])
-def test_all_ranks_agree_on_the_exchange(tmp_path, fail_at, failing_rank):
-    """One rank that cannot load RCCL, or whose communicator does not come up, sends EVERY rank to the host-staged
-    exchange (nobody is left inside ncclCommInitRank); a rank whose own communicator did come up tears it down again."""
+def test_all_ranks_agree_on_the_exchange(tmp_path, fail_at, failing_rank, allow):
+    """One rank that cannot load RCCL, or whose communicator does not come up (here: SYMMETRICALLY - every rank's
+    comm_init returns), makes EVERY rank refuse (`ExchangeUnavailable`: the strict default) or, only with
+    allow_host_exchange, take the host-staged exchange; a rank whose own communicator did come up tears it down again.
+    The load probe draws no ncclUniqueId: exactly one id is drawn, by rank 0, and only when every rank can load RCCL."""
     world = 3
-    mp.spawn(_consensus_worker, args=(world, str(tmp_path / "rdzv"), failing_rank, fail_at, str(tmp_path)), nprocs=world,
-             join=True)
+    mp.spawn(_consensus_worker, args=(world, str(tmp_path / "rdzv"), failing_rank, fail_at, str(tmp_path), allow),
+             nprocs=world, join=True)
     for r in range(world):
-        kind, cls, inited, destroyed, note = open(tmp_path / f"c{r}.txt").read().split("|", 4)
+        kind, cls, inited, destroyed, ids, note = open(tmp_path / f"c{r}.txt").read().split("|", 5)
+        assert int(ids) == (1 if (r == 0 and fail_at != "load") else 0)
         if fail_at is None:
             assert (kind, cls, inited, destroyed, note) == ("rccl", "RcclExchange", "True", "False", "None")
         else:
-            assert kind == "file" and cls == "HostStagedExchange" and f"rank {failing_rank}" in note
+            if allow:
+                assert kind == "file" and cls == "HostStagedExchange" and f"rank {failing_rank}" in note
+            else:
+                assert kind == "refused" and f"rank {failing_rank}" in note and "--allow-host-exchange" in note
             if fail_at == "load":
                 assert inited == "False"                       # nobody entered the communicator
             elif r != failing_rank:
                 assert inited == "True" and destroyed == "True"
+
+
+def _asymmetric_worker(rank, world, rdzv_dir, failing_rank):
+    rdzv = parallel.FileRendezvous(rdzv_dir, rank, world, timeout_s=8)
+    ctx = _FakeCommCtx("init" if rank == failing_rank else None, block_init=True)
+    parallel.make_exchange(ctx, rdzv, "rccl", init_timeout_s=2.0)
+    os._exit(0)                                   # not reached by any rank
+
+
+def test_an_asymmetric_communicator_failure_ends_every_rank_non_zero(tmp_path):
+    """ncclCommInitRank failing on ONE rank leaves its peers blocked inside RCCL (the fake comm_init sleeps for an hour):
+    the blocked ranks' CommInitWatchdog ends them with exit code 75 after init_timeout_s, the failed rank gives up at
+    the rendezvous - nobody hangs, nobody returns 0, and the parent (bench.py spawn_ranks / the launcher) sees a failure."""
+    import multiprocessing
+    import time
+    world, failing = 3, 1
+    mpctx = multiprocessing.get_context("spawn")
+    procs = [mpctx.Process(target=_asymmetric_worker, args=(r, world, str(tmp_path / "rdzv"), failing)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=60)
+    assert all(not p.is_alive() for p in procs), "a rank is still blocked inside the (fake) ncclCommInitRank"
+    codes = [p.exitcode for p in procs]
+    assert codes[0] == codes[2] == parallel.CommInitWatchdog.EXIT_CODE and codes[failing] not in (0, None)
+    assert time.time() - t0 < 40
+
+
+def test_rendezvous_refuses_a_directory_others_can_write_to(tmp_path):
+    d = tmp_path / "shared"
+    d.mkdir(mode=0o777)
+    os.chmod(d, 0o777)
+    with pytest.raises(PermissionError):
+        parallel.FileRendezvous(str(d), 0, 1)
+    os.chmod(d, 0o700)
+    parallel.FileRendezvous(str(d), 0, 1).close()
+
+
+def test_rendezvous_ignores_the_files_of_an_earlier_attempt(tmp_path):
+    """A restarted attempt in the same directory (same launcher pid / port / run id) must not read the previous attempt's
+    round files: every attempt has its own session token, and a session file left by a dead rank 0 is not taken."""
+    d = tmp_path / "rdzv"
+    first = parallel.FileRendezvous(str(d), 0, 1)
+    assert first.allgather_obj([True, "old"]) == [[True, "old"]]
+    stale = sorted(os.listdir(d))
+    second = parallel.FileRendezvous(str(d), 0, 1)               # rank 0 of the next attempt: new token
+    assert second.session != first.session
+    assert second.allgather_obj(b"\x01\x02") == [b"\x01\x02"] and second.round == 1
+    assert all(name in os.listdir(d) for name in stale if not name.startswith("session."))
+    # a non-zero rank only accepts a session whose rank 0 is alive
+    with open(d / "session.0", "wb") as f:
+        f.write(parallel._encode({"token": "dead", "pid": 2 ** 22 + 12345}))
+    with pytest.raises(TimeoutError):
+        parallel.FileRendezvous(str(d), 1, 2, timeout_s=0.3)
+    arr = np.arange(6.0).reshape(2, 3)
+    assert np.array_equal(parallel._decode(parallel._encode(arr)), arr) and parallel._decode(parallel._encode(None)) is None
+    with pytest.raises(ValueError):
+        parallel._decode(b"\x80\x04junk")                        # a pickle stream is not a format this reader accepts
