@@ -88,6 +88,7 @@ def load():
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_weights_normalise.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]
     lib.bayens_w2_temporal.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
+    lib.bayens_w2_spatial.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
     lib.bayens_w2_single.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_barycentre.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_double,
                                       _vp, _vp, _ip]
@@ -452,6 +453,14 @@ class Context:
         M, P = mean.shape
         w = np.empty((M, P))
         self._check(self.lib.bayens_w2_temporal(self.h, HOST, M, P, _ptr(mean), _ptr(var), _ptr(w)))
+        return w
+
+    def w2_spatial(self, mean, scale):
+        """ModelSimilarityWeight(mode='spatial'), dx.Normal branch: mean, scale [M][T][G] -> w [M][G]."""
+        mean, scale = _f64(mean), _f64(scale)
+        M, T, G = mean.shape
+        w = np.empty((M, G))
+        self._check(self.lib.bayens_w2_spatial(self.h, HOST, M, T, G, _ptr(mean), _ptr(scale), _ptr(w)))
         return w
 
     def w2_temporal_dev(self, M, P, mean, var, w):

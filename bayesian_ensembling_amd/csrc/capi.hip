@@ -1034,6 +1034,19 @@ int bayens_w2_temporal(bayens_ctx* c, int loc, int M, int P, const double* mean,
   });
 }
 
+int bayens_w2_spatial(bayens_ctx* c, int loc, int M, int T, int G, const double* mean, const double* scale, double* w) {
+  return guarded(c, [&]() {
+    if (M <= 0 || T <= 0 || G <= 0 || !mean || !scale || !w) return fail(c, BAYENS_E_ARG, "w2_spatial: bad argument");
+    Stage st(c, loc);
+    const double* dm = st.in(mean, (size_t)M * T * G);
+    const double* dv = st.in(scale, (size_t)M * T * G);
+    double* dw = st.out(w, (size_t)M * G);
+    c->prims->w2_spatial(M, T, G, dm, dv, dw);
+    st.finish();
+    return 0;
+  });
+}
+
 namespace {
 // All-pairs Gaussian W2 table and weights.  sharded: every rank holds ALL M members (the caller all-gathered the
 // factors); the M(M-1)/2 polar iterations are dealt over the ranks of the communicator by anchor member i (i mod

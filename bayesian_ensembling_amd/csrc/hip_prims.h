@@ -150,6 +150,7 @@ struct HipPrims : Prims {
                           const double* obs, double* ll_mean);
   void weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw);
   void w2_temporal(int M, int P, const double* mean, const double* var, double* w);
+  void w2_spatial(int M, int T, int G, const double* mean, const double* V, double* w);
   void barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,
                   double init_var, double* mu_out, double* var_out, int* n_bad);
   void weighted_model_mean(int M, int R_max, const int* R, int P, const double* data, const double* w,

@@ -1070,6 +1070,40 @@ __global__ void w2_temporal_kernel(int M, int P, const double* mean, const doubl
   for (int i = 0; i < M; ++i) w[(long)i * P + t] /= tot;
 }
 
+// weights.py:267-300 (mode='spatial', dx.Normal branch) with wasserstein.py:21-47, full_cov=False: per grid point p the
+// reference builds dx.Normal(mean_i[:, p], scale = variance_i[:, p]) over the T time steps, so
+//   D[i,j,p] = || mean_i[:,p] - mean_j[:,p] ||_2  +  sum_t (V_i[t,p] - V_j[t,p])^2        (V = distribution.variance)
+// and w[i,p] = nanmean_j D[i,j,p], normalised over i.  Tables are [M][T][G] (time-major per model, grid points
+// contiguous: a wave reads 512 contiguous bytes of one time step).  Thread (p, i) forms row i's mean distance.
+__global__ void w2_spatial_rows_kernel(int M, int T, int G, const double* mean, const double* V, double* w) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (p >= G) return;
+  const double* mi = mean + (long)i * T * G + p;
+  const double* vi = V + (long)i * T * G + p;
+  double acc = 0.0;
+  int n = 0;
+  for (int j = 0; j < M; ++j) {
+    const double* mj = mean + (long)j * T * G + p;
+    const double* vj = V + (long)j * T * G + p;
+    double dm = 0.0, dv = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double a = mi[(long)t * G] - mj[(long)t * G], b = vi[(long)t * G] - vj[(long)t * G];
+      dm += a * a;
+      dv += b * b;
+    }
+    const double d = sqrt(dm) + dv;
+    if (d == d) { acc += d; ++n; }          // np.nanmean over j
+  }
+  w[(long)i * G + p] = n ? acc / n : NAN;
+}
+__global__ void column_normalise_kernel(int M, int P, double* w) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double tot = 0.0;
+  for (int i = 0; i < M; ++i) tot += w[(long)i * P + p];
+  for (int i = 0; i < M; ++i) w[(long)i * P + p] /= tot;
+}
+
 // ensemble_scheme.py:52-78 + wasserstein.py:61-100 (signed convergence test, <= 201 sweeps)
 // ensemble_scheme.py:43-81 + wasserstein.py:61-100: per point, mu* = sum_m w mu and the fixed point
 // v <- sum_m w sqrt(v) sigma_m with the reference's signed stopping test.  Same layout as normalise_kernel: 64 points
@@ -1672,6 +1706,11 @@ void HipPrims::weights_normalise(int M, int P, const double* ll_mean, double c_s
 }
 void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, double* w) {
   hipLaunchKernelGGL(w2_temporal_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, mean, var, w);
+  LAUNCH_CHECK();
+}
+void HipPrims::w2_spatial(int M, int T, int G, const double* mean, const double* V, double* w) {
+  hipLaunchKernelGGL(w2_spatial_rows_kernel, dim3((G + 255) / 256, M), dim3(256), 0, stream, M, T, G, mean, V, w);
+  hipLaunchKernelGGL(column_normalise_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, M, G, w);
   LAUNCH_CHECK();
 }
 void HipPrims::barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,

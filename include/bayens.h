@@ -183,6 +183,13 @@ int bayens_weights_normalise(bayens_ctx* ctx, int loc, int M, int P, const doubl
 int bayens_w2_temporal(bayens_ctx* ctx, int loc, int M, int P, const double* mean,
                        const double* var, double* w);
 
+/* ModelSimilarityWeight mode='spatial', dx.Normal posteriors (ensembles/weights.py:267-300,331 with
+ * ensembles/wasserstein.py:21-47, full_cov=False): per grid point p, over the T time steps,
+ * D[i,j,p] = ||mean_i[:,p] - mean_j[:,p]||_2 + sum_t (scale_i[t,p] - scale_j[t,p])^2, scale = Distribution.variance (the
+ * reference passes it as dx.Normal's scale); w[i,p] = nanmean_j D / sum_i.  mean, scale [M][T][G] (G = lat * lon grid
+ * points, contiguous); w [M][G]. */
+int bayens_w2_spatial(bayens_ctx* ctx, int loc, int M, int T, int G, const double* mean, const double* scale, double* w);
+
 /* ModelSimilarityWeight mode='single' (ensembles/weights.py:240-265,331 + ensembles/wasserstein.py:10-47):
  * D[i][j] = ||mu_i - mu_j||_2 + tr(S_i + S_j - 2 (S_i^1/2 S_j S_i^1/2)^1/2), w_i = mean_j D[i][j] / sum.
  * Full-covariance posteriors: chol [M][N][N] are the lower factors (S = L L^T); the trace of the matrix square

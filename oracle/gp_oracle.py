@@ -317,6 +317,24 @@ def w2_weights_temporal(mean, var):
     return v / v.sum(axis=0, keepdims=True)
 
 
+def w2_weights_spatial(mean, V):
+    """mode='spatial', dx.Normal posteriors                             [weights.py:267-300,331; wasserstein.py:21-47].
+
+    mean, V (M, T, n_lat, n_lon) = Distribution.mean / Distribution.variance of every member.  Per (i, j, lat, lon) the
+    reference builds dx.Normal(mean_i[:, lat, lon], scale=V_i[:, lat, lon]) and calls gaussian_w2_distance_distrax with
+    full_cov=False: sigma = diag(Normal.variance()) = diag(V^2), sqrtm(diag) = diag(V), so
+    D = ||mean_i - mean_j||_2 + trace(V_i^2 + V_j^2 - 2 V_i V_j) = ||dmean||_2 + sum_t (V_i - V_j)^2.
+    w = nanmean_j D, normalised over the models -> (M, n_lat, n_lon)."""
+    mean, V = np.asarray(mean, dtype=np.float64), np.asarray(V, dtype=np.float64)
+    M = mean.shape[0]
+    D = np.full((M, M) + mean.shape[2:], np.nan)
+    for i in range(M):
+        for j in range(M):
+            D[i, j] = np.sqrt(np.sum((mean[i] - mean[j]) ** 2, axis=0)) + np.sum((V[i] - V[j]) ** 2, axis=0)
+    v = np.nanmean(D, axis=1)
+    return v / v.sum(axis=0, keepdims=True)
+
+
 # --------------------------------------------------------------------------------------
 # Row 10: Barycentre  (ensemble_scheme.py:43-81, wasserstein.py:61-100)
 # --------------------------------------------------------------------------------------
