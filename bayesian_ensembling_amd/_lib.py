@@ -75,6 +75,7 @@ def load():
     lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
     lib.bayens_gp_fit_batch_reduced.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                                 C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_field_prologue.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis_grouped.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
@@ -337,10 +338,18 @@ class Context:
     def gp_fit_batch_reduced_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, var, logdet=None, hyp=None, basis=None,
                                  kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
         info = np.zeros(B, dtype=np.int32)
-        self._check(self.lib.bayens_gp_fit_batch_reduced(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),
-                                                         int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var),
-                                                         _ptr(logdet), _ptr(hyp), _ptr(info), _ptr(basis)))
+        rc = self.lib.bayens_gp_fit_batch_reduced(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),
+                                                  int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var),
+                                                  _ptr(logdet), _ptr(hyp), _ptr(info), _ptr(basis))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
         return info
+
+    def field_prologue_dev(self, M, R, N, G, raw, X, y_mean, y_var):
+        """models.py:175-182 at every grid point, on resident buffers: raw [M][R][N][G] -> X [M*G][N][R], y, nu [M*G][N]."""
+        self._check(self.lib.bayens_field_prologue(self.h, DEVICE, M, R, N, G, _ptr(raw), _ptr(X), _ptr(y_mean), _ptr(y_var)))
 
     def mvn_factor_batch(self, cov, mu=None):
         """chol, logdet (and, with mu, the log-likelihood basis) of caller-supplied covariances."""

@@ -491,6 +491,22 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
   });
 }
 
+int bayens_field_prologue(bayens_ctx* c, int loc, int M, int R, int N, int G, const double* raw, double* X, double* y_mean,
+                          double* y_var) {
+  return guarded(c, [&]() {
+    if (M <= 0 || R <= 0 || N <= 0 || G <= 0 || M > 65535 || N > 65535 || !raw || !X || !y_mean || !y_var)
+      return fail(c, BAYENS_E_ARG, "field_prologue: bad argument");
+    Stage st(c, loc);
+    const double* draw = st.in(raw, (size_t)M * R * N * G);
+    double* dX = st.out(X, (size_t)M * G * N * R);
+    double* dy = st.out(y_mean, (size_t)M * G * N);
+    double* dnu = st.out(y_var, (size_t)M * G * N);
+    c->prims->field_prologue(M, R, N, G, draw, dX, dy, dnu);
+    st.finish();
+    return 0;
+  });
+}
+
 int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
                                 const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
                                 double* mu, double* var, double* logdet, double* hyp, int* info, double* ll_basis) {

@@ -1070,6 +1070,32 @@ __global__ void w2_temporal_kernel(int M, int P, const double* mean, const doubl
   for (int i = 0; i < M; ++i) w[(long)i * P + t] /= tot;
 }
 
+// models.py:175-182 at every grid point of a (realisation, time, *space) field: X = realisation_set^T, y_var = np.var over
+// the realisations (ddof = 0, two passes like NumPy), y_mean = the mean over realisations (the documented stand-in for
+// the DTW barycentre).  raw [M][R][N][G] as the caller's array lies in memory (grid points contiguous: coalesced reads);
+// outputs in the fit's layout, fit index b = m * G + g: X [B][N][R], y_mean / y_var [B][N].
+__global__ void field_prologue_kernel(int R, int N, int G, const double* raw, double* X, double* y_mean, double* y_var) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, m = blockIdx.z;
+  if (g >= G) return;
+  const double* src = raw + ((long)m * R * N + n) * G + g;
+  const long b = (long)m * G + g;
+  double* xr = X + (b * N + n) * R;
+  double sum = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const double v = src[(long)r * N * G];
+    xr[r] = v;
+    sum += v;
+  }
+  const double mean = sum / R;
+  double sq = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const double d = src[(long)r * N * G] - mean;
+    sq += d * d;
+  }
+  y_mean[b * N + n] = mean;
+  y_var[b * N + n] = sq / R;
+}
+
 // weights.py:267-300 (mode='spatial', dx.Normal branch) with wasserstein.py:21-47, full_cov=False: per grid point p the
 // reference builds dx.Normal(mean_i[:, p], scale = variance_i[:, p]) over the T time steps, so
 //   D[i,j,p] = || mean_i[:,p] - mean_j[:,p] ||_2  +  sum_t (V_i[t,p] - V_j[t,p])^2        (V = distribution.variance)
@@ -1706,6 +1732,10 @@ void HipPrims::weights_normalise(int M, int P, const double* ll_mean, double c_s
 }
 void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, double* w) {
   hipLaunchKernelGGL(w2_temporal_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, M, P, mean, var, w);
+  LAUNCH_CHECK();
+}
+void HipPrims::field_prologue(int M, int R, int N, int G, const double* raw, double* X, double* y_mean, double* y_var) {
+  hipLaunchKernelGGL(field_prologue_kernel, dim3((G + 255) / 256, N, M), dim3(256), 0, stream, R, N, G, raw, X, y_mean, y_var);
   LAUNCH_CHECK();
 }
 void HipPrims::w2_spatial(int M, int T, int G, const double* mean, const double* V, double* w) {

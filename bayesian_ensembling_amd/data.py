@@ -29,7 +29,9 @@ class Distribution:
         self.__post_init__()
 
     def __post_init__(self):
-        if self._resident is not None:
+        if self._resident is not None and self.dist_type is dx.GridMultivariateNormalFullCovariance:
+            self._dist = self.dist_type(*self._resident)             # (ResidentField, member index)
+        elif self._resident is not None:
             assert self.dist_type is dx.MultivariateNormalFullCovariance
             self._dist = self.dist_type._from_resident(*self._resident)
         elif self.dist_type is dx.MultivariateNormalFullCovariance and self._factor is not None:
@@ -50,10 +52,53 @@ class Distribution:
             self._covariance = self._dist.covariance()
         return self._covariance
 
+    # the reference's Distribution is a plain dataclass (ensembles/data.py:18-24): fields are assignable and it has a
+    # generated __repr__ / __eq__; assigning a field here re-derives the distribution like a fresh construction would
+    @mu.setter
+    def mu(self, value):
+        self._materialise()
+        self._mu = value
+        self.__post_init__()
+
+    @covariance.setter
+    def covariance(self, value):
+        self._materialise()
+        self._covariance = value
+        self.__post_init__()
+
+    def _materialise(self):
+        """Resident / pre-factored posterior -> plain host fields (before one of them is replaced)."""
+        if self._resident is not None and self.dist_type is dx.MultivariateNormalFullCovariance:
+            self._mu, self._covariance = np.array(self.mu), np.array(self.covariance)
+        elif self._resident is not None:
+            raise AttributeError("a per-gridpoint field posterior is read-only")
+        self._resident, self._factor = None, None
+
+    def __repr__(self):
+        def short(a):
+            return None if a is None else f"array(shape={np.shape(a)})"
+        where = "resident in HBM" if self._resident is not None else "host"
+        return (f"Distribution(mu={short(self._mu) if self._resident is None else '<HBM>'}, "
+                f"covariance={short(self._covariance) if self._resident is None else '<HBM>'}, "
+                f"dim_array={getattr(self.dim_array, 'shape', None)}, dist_type={getattr(self.dist_type, '__name__', None)}) [{where}]")
+
+    def __eq__(self, other):
+        if not isinstance(other, Distribution):
+            return NotImplemented
+        return (self.dist_type is other.dist_type and np.array_equal(np.asarray(self.mu), np.asarray(other.mu))
+                and np.array_equal(np.asarray(self.covariance), np.asarray(other.covariance)))
+
+    __hash__ = None
+
     def __getstate__(self):
         """Pickling (ModelCollection.save, data.py:397-399) takes the posterior to the host."""
         state = dict(self.__dict__)
-        if self._resident is not None:
+        if self._resident is not None and self.dist_type is dx.GridMultivariateNormalFullCovariance:
+            # a field keeps marginals only: it pickles as the dx.Normal-style pair the reference's consumers read
+            state.update(_mu=np.array(self._dist.mean()), _covariance=np.array(self._dist.stddev()), _resident=None,
+                         dist_type=dx.MultivariateNormalDiag)
+            del state["_dist"]
+        elif self._resident is not None:
             d = self._dist
             state.update(_mu=np.array(self.mu), _covariance=np.array(self.covariance), _resident=None,
                          _factor=(np.array(d._scale_tri), float(d._logdet), np.array(d._basis)))

@@ -189,3 +189,47 @@ class MultivariateNormalFullCovariance:
     def sample(self, seed=0):
         rng = np.random.default_rng(int(seed))
         return self.loc + self._scale_tri @ rng.standard_normal(self.loc.shape)
+
+
+class GridMultivariateNormalFullCovariance:
+    """A field of INDEPENDENT full-covariance normals over time, one per grid point: the posterior of
+    `GPDTW1D(per_gridpoint=True)` for (realisation, time, latitude, longitude) data (BASELINE config 5).  This type has
+    no counterpart in the reference (its GPDTW1D refuses more than (realisation, time), ensembles/models.py:171-174);
+    it carries what the reference's consumers read of a posterior - mean() and variance() over the flattened
+    (time, lat, lon) points (ensembles/ensemble_scheme.py:63-65 flattens space the same way) - while the weights treat
+    every grid point as the reference's 1-D path would (weights.py:93-104 per point).  Lives in HBM (resident.ResidentField);
+    the time x time covariances are not kept."""
+
+    def __init__(self, field, m):
+        self._field = (field, m)
+        self._mean_h = self._var_h = None
+
+    def _rows(self, buf):
+        f, m = self._field
+        # [G][N] on the device -> (time, lat, lon) order of the data, flattened
+        return np.ascontiguousarray(f.member_rows(buf, m).T).reshape(-1)
+
+    def mean(self):
+        if self._mean_h is None:
+            self._mean_h = self._rows(self._field[0].mu)
+        return self._mean_h
+
+    def variance(self):
+        if self._var_h is None:
+            self._var_h = self._rows(self._field[0].var)
+        return self._var_h
+
+    def stddev(self):
+        return np.sqrt(self.variance())
+
+    def covariance(self):
+        raise NotImplementedError("a per-gridpoint field keeps the marginal variances only (the time x time covariance of "
+                                  "every grid point is not stored); fit a single grid point with GPDTW1D() to obtain it")
+
+    def log_prob(self, x):
+        raise NotImplementedError("log_prob of a per-gridpoint field is evaluated by LogLikelihoodWeight from the resident "
+                                  "basis (bayens_loglik_rows_basis_grouped)")
+
+    def sample(self, seed=0):
+        rng = np.random.default_rng(int(seed))
+        return self.mean() + self.stddev() * rng.standard_normal(self.mean().shape)      # marginal draws

@@ -10,7 +10,7 @@ from . import _lib
 from . import distributions as dx
 from .data import Distribution, ModelCollection
 from .labelled import DataArray, ones_like
-from .resident import resident_tables
+from .resident import field_of, resident_tables
 
 
 class AbstractEnsembleScheme:
@@ -47,7 +47,22 @@ class Barycentre(AbstractEnsembleScheme):
         if w.shape[1] != n_points:
             raise ValueError(f"weights have {w.shape[1]} points per model, the posteriors {n_points}")
         ds = [pm.distribution._dist for pm in process_models.models]
-        if all(getattr(d, "_resident", None) is not None for d in ds):
+        field = field_of(ds)
+        if field is not None:
+            # per-gridpoint posteriors: the marginals of all M x G fits are resident as [M][G*N]; the weights arrive in
+            # the data's (time, *space) order and are turned into that layout, the result back (ensemble_scheme.py:51-52
+            # flattens space into the point axis in the same way)
+            ctx, G, N = field.ctx, field.G, field.N
+            wf = np.ascontiguousarray(w.reshape(M, N, G).transpose(0, 2, 1)).reshape(M, G * N)
+            dw, dmu, dv = ctx.to_device(wf), ctx.empty((G * N,)), ctx.empty((G * N,))
+            try:
+                bad = ctx.barycentre_dev(M, G * N, dw, field.mu, field.var, dmu, dv)
+                mu = np.ascontiguousarray(dmu.download().reshape(G, N).T).reshape(-1)
+                v = np.ascontiguousarray(dv.download().reshape(G, N).T).reshape(-1)
+            finally:
+                for d in (dw, dmu, dv):
+                    d.free()
+        elif all(getattr(d, "_resident", None) is not None for d in ds):
             # resident posteriors: the [M, P] marginals are read in HBM; the weights go up, mu* / sigma*^2 come down
             ctx = _lib.default_context()
             _, _, mean, var, _, owned = resident_tables(ctx, ds)

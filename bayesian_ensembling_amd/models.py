@@ -16,7 +16,7 @@ from . import _lib
 from . import distributions as dx
 from .data import Distribution
 from .labelled import ones_like
-from .resident import ResidentBatch
+from .resident import ResidentBatch, ResidentField
 
 
 def _blank_array(process_model):
@@ -27,7 +27,7 @@ def _blank_array(process_model):
 
 class GPDTW1D:
     def __init__(self, name: str = "GPRegressor", target="mean", kernel: str = "matern32",
-                 dtype: str = "float64") -> None:
+                 dtype: str = "float64", per_gridpoint: bool = False) -> None:
         """target: 'mean' (mean over realisations - the documented stand-in for the reference's tslearn DTW
         barycentre, which cannot be reproduced offline), 'dba' (DTW barycentre averaging with the semantics of the
         reference's own ensembles/dtwa.py performDBA, 10 iterations, on the GPU) or a callable (R,N) ndarray -> (N,).
@@ -37,6 +37,10 @@ class GPDTW1D:
         self.name = name
         self.target = target
         self.kernel = kernel
+        # per_gridpoint (opt-in, BASELINE config 5): (realisation, time, latitude, longitude) data is treated as one
+        # independent (realisation, time) model per grid point - the reference's own 1-D fit at every point - instead of
+        # raising NotImplementedError like the reference (models.py:171-174).  See fit_field.
+        self.per_gridpoint = bool(per_gridpoint)
         if np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise ValueError("dtype must be 'float64' or 'float32'")
         self.dtype = np.dtype(dtype)
@@ -58,10 +62,70 @@ class GPDTW1D:
         X = np.ascontiguousarray(realisation_set.T)
         return X, y_mean, y_var
 
+    # -- per-gridpoint fields (BASELINE config 5) -------------------------------------------------------
+    FIELD_CHUNK = 65536          # fits per launch of the fused small-member kernel
+
+    def fit_field(self, process_models, n_optim_nits: int = 500):
+        """Every (member, grid point) of a collection of (realisation, time, *space) models as an independent GP over
+        time - models.py:175-220 applied to `model_data[:, :, lat, lon]` - in batched launches of the fused small-member
+        kernel (reduced export), resident in HBM as ONE ResidentField [M][G].  Members must share (R, T, space)."""
+        ctx = _lib.default_context()
+        shapes = {tuple(pm.model_data.shape) for pm in process_models}
+        if len(shapes) != 1:
+            raise ValueError("per_gridpoint: every member must have the same (realisation, time, *space) shape")
+        if self.dtype != np.float64:
+            raise NotImplementedError("per_gridpoint fits run in float64 (the reduced export has no fp32 entry)")
+        if self.target != "mean" and not callable(self.target):
+            raise NotImplementedError("per_gridpoint: target must be 'mean' or a callable")
+        R, N = next(iter(shapes))[:2]
+        G = int(np.prod(next(iter(shapes))[2:]))
+        M = len(process_models)
+        if N > 94:
+            raise NotImplementedError(f"per_gridpoint: {N} time steps; the fused small-member kernel holds N <= 94 (the "
+                                      "reference's annual horizons are 86 steps)")
+        field = ResidentField(ctx, M, G, N)
+        kid = _lib.KERNEL_IDS[self.kernel]
+        B = M * G
+        dX, dy, dnu = ctx.empty((B, N, R)), ctx.empty((B, N)), ctx.empty((B, N))
+        draw = ctx.empty((M, R, N, G))
+        try:
+            # the realisations go up as they lie in memory ((realisation, time, *space), grid points contiguous); the
+            # prologue of models.py:175-182 runs on the device for every grid point at once (bayens_field_prologue)
+            row = R * N * G * 8
+            for m, pm in enumerate(process_models):
+                data = np.ascontiguousarray(pm.model_data.values, dtype=np.float64)
+                ctx._check(ctx.lib.bayens_memcpy_h2d(ctx.h, draw.offset(m * row), data.ctypes.data, data.nbytes))
+            ctx.field_prologue_dev(M, R, N, G, draw, dX, dy, dnu)
+            if callable(self.target):       # a user-supplied barycentre replaces the mean target, grid point by grid point
+                y = np.empty((B, N))
+                for m, pm in enumerate(process_models):
+                    data = np.asarray(pm.model_data.values, dtype=np.float64).reshape(R, N, G)
+                    for g in range(G):
+                        y[m * G + g] = np.asarray(self.target(data[:, :, g]), dtype=np.float64).reshape(-1)
+                dy.upload(y)
+            for b0 in range(0, B, self.FIELD_CHUNK):
+                nb = min(B, b0 + self.FIELD_CHUNK) - b0
+                ctx.gp_fit_batch_reduced_dev(nb, N, R, dX.offset(b0 * N * R * 8), dy.offset(b0 * N * 8), dnu.offset(b0 * N * 8),
+                                             n_optim_nits, field.mu.offset(b0 * N * 8), field.var.offset(b0 * N * 8),
+                                             field.logdet.offset(b0 * 8), field.hyp.offset(b0 * 16),
+                                             field.basis.offset(b0 * 2 * N * 8), kernel=kid)
+        finally:
+            for d in (dX, dy, dnu, draw):
+                d.free()
+        dists = []
+        for m, pm in enumerate(process_models):
+            d = Distribution(dim_array=_blank_array(pm), dist_type=dx.GridMultivariateNormalFullCovariance,
+                             _resident=(field, m))
+            d.losses = None
+            dists.append(d)
+        return dists
+
     def fit_collection(self, process_models, n_optim_nits: int = 500, compile_objective: bool = False,
                        progress_bar: bool = True):
         """All members at once: one bayens_gp_fit_batch call per distinct realisation count."""
         del compile_objective   # accepted for signature compatibility (a tf.function knob)
+        if self.per_gridpoint and all(pm.model_data.ndim > 2 for pm in process_models):
+            return self.fit_field(process_models, n_optim_nits)
         # progress_bar: the reference shows the loss sampled every 25 iterations in a tqdm bar (models.py:211-215);
         # here the same samples are kept on each Distribution as `.losses` (and skipped when progress_bar=False)
         ctx = _lib.default_context()

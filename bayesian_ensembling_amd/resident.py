@@ -75,3 +75,45 @@ def resident_tables(ctx, dists, want_chol=False):
         if chol is not None:
             chol.copy_rows_from(m, b.chol, j)
     return basis, logdet, mean, var, chol, [basis, logdet, mean, var] + ([chol] if chol is not None else [])
+
+
+class ResidentField:
+    """Device outputs of a per-gridpoint fit of a whole collection (BASELINE config 5): M members x G grid points of
+    independent (realisation, time) posteriors, fitted by `GPDTW1D(per_gridpoint=True)` in batched launches of the fused
+    small-member kernel with the REDUCED export - what the weighting path needs of a posterior and nothing else:
+    mean / marginal variance [B][N], log-likelihood basis [B][2][N], log-determinant and hyper-parameters per fit,
+    b = m * G + g (member-major, so that [M][G*N] is the [model][point] table the weight and scheme kernels take).
+    The N x N covariances of the 442 368 fits of config 5 (26 GB) are never formed in HBM, let alone downloaded."""
+
+    def __init__(self, ctx, M, G, N):
+        self.ctx, self.M, self.G, self.N, self.B = ctx, M, G, N, M * G
+        B = self.B
+        self.mu, self.var = ctx.empty((B, N)), ctx.empty((B, N))
+        self.logdet, self.hyp, self.basis = ctx.empty((B,)), ctx.empty((B, 2)), ctx.empty((B, 2, N))
+        self._bufs = [self.mu, self.var, self.logdet, self.hyp, self.basis]
+
+    def member_rows(self, buf, m):
+        """Member m's [G][...] block of a per-fit table as a host array."""
+        return buf.download_rows(m * self.G, self.G)
+
+    def free(self):
+        for b in self._bufs:
+            b.free()
+        self._bufs = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def field_of(dists):
+    """The ResidentField shared by these posteriors when they are its members 0..M-1 in order, else None."""
+    views = [getattr(d, "_field", None) for d in dists]
+    if any(v is None for v in views):
+        return None
+    f0 = views[0][0]
+    if all(f is f0 for f, _ in views) and [m for _, m in views] == list(range(f0.M)):
+        return f0
+    return None

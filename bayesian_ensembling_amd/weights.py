@@ -13,7 +13,7 @@ from . import _lib
 from . import distributions as dx
 from .data import ModelCollection, ProcessModel
 from .labelled import DataArray, concat
-from .resident import resident_tables
+from .resident import field_of, resident_tables
 
 __all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight", "InverseSquareWeight", "UniformWeight",
            "KSDWeight", "CRPSWeight"]
@@ -54,6 +54,10 @@ class LogLikelihoodWeight(AbstractWeight):
         the device; any other callable is applied on the host to the device-computed mean log-likelihood."""
         ctx = _lib.default_context()
         models = list(process_models.models)
+        field = field_of([m.distribution._dist for m in models])
+        if field is not None:
+            return self._compute_field(field, process_models, observations, models, return_lls, standardisation_scheme,
+                                       standardisation_constant)
         obs = np.ascontiguousarray(np.asarray(observations.model_data.values, dtype=np.float64)
                                    .reshape(observations.n_realisations, -1))
         M = len(models)
@@ -98,6 +102,32 @@ class LogLikelihoodWeight(AbstractWeight):
                 w = raw / raw.sum(axis=0, keepdims=True)
 
         return self._finish(process_models, observations, models, w, raw, return_lls)
+
+    def _compute_field(self, field, process_models, observations, models, return_lls, scheme, c_std):
+        """Per-gridpoint posteriors (GPDTW1D(per_gridpoint=True), BASELINE config 5): weights.py:88-123 at EVERY grid
+        point - rows log N(x_{r,t,g} 1; mu_{m,g}, cov_{m,g}) from the resident basis of fit (m, g), mean over the
+        observation realisations, exp(c .), normalisation over the models - in three launches over the whole field
+        (bayens_loglik_rows_basis_grouped -> bayens_weights_normalise).  Only the observations go up and the
+        [M, time, *space] weight table comes down."""
+        if not (scheme is None or scheme == "exp" or scheme is np.exp):
+            raise NotImplementedError("per-gridpoint fields: only the default exp standardisation runs on the device")
+        ctx = field.ctx
+        M, G, N = field.M, field.G, field.N
+        R_obs = observations.n_realisations
+        obs = np.asarray(observations.model_data.values, dtype=np.float64).reshape(R_obs, N, G)
+        dobs = ctx.to_device(np.ascontiguousarray(obs.transpose(2, 0, 1)))                       # [G][R_obs][N]
+        dll, dw, draw = ctx.empty((M * G, N)), ctx.empty((M, G * N)), ctx.empty((M, G * N))
+        try:
+            ctx.loglik_rows_basis_grouped(field.basis, field.logdet, _lib.DeviceView(dobs.ptr, (G, R_obs, N)), loc=_lib.DEVICE,
+                                          out=dll)
+            ctx.weights_normalise_dev(M, G * N, dll, c_std, dw, draw)
+            w, raw = dw.download(), draw.download()
+        finally:
+            for d in (dobs, dll, dw, draw):
+                d.free()
+        # device order [M][G][N] -> the data's (model, time, *space)
+        back = lambda a: np.ascontiguousarray(a.reshape(M, G, N).transpose(0, 2, 1)).reshape(M, -1)
+        return self._finish(process_models, observations, models, back(w), back(raw), return_lls)
 
     @staticmethod
     def _finish(process_models, observations, models, w, raw, return_lls):
@@ -177,10 +207,26 @@ class ModelSimilarityWeight(AbstractWeight):
                              {"model": np.asarray(process_models.model_names), "time": np.asarray([0])},
                              "Model similarity weights")
         if mode == "spatial":
-            raise NotImplementedError(
-                "ModelSimilarityWeight(mode='spatial') needs spatial posteriors (GPDTW3D), which are out of scope; "
-                "the reference's own full-covariance branch of this mode references a non-existent dx.MultiVariate "
-                "(weights.py:284).")
+            # weights.py:267-300.  Only the dx.Normal branch exists in the reference: its other branch builds
+            # `dx.MultiVariate`, which distrax does not have (weights.py:284 - AttributeError at the first grid point).
+            import warnings
+            warnings.warn("Spatial method is experimental. Use with caution.")
+            models = list(process_models.models)
+            if not all(m.distribution.dist_type is dx.Normal for m in models):
+                raise NotImplementedError(
+                    "ModelSimilarityWeight(mode='spatial') is defined for dx.Normal posteriors (MeanFieldApproximation); "
+                    "the reference's branch for other posteriors calls a non-existent dx.MultiVariate (weights.py:284)")
+            md = models[0].model_data
+            if md.ndim != 4:
+                raise ValueError("mode='spatial' needs (realisation, time, latitude, longitude) models")
+            T, n_lat, n_lon = md.shape[1:]
+            mean = np.stack([np.asarray(m.distribution.mean.values, dtype=np.float64).reshape(T, -1) for m in models])
+            V = np.stack([np.asarray(m.distribution.variance.values, dtype=np.float64).reshape(T, -1) for m in models])
+            w = _lib.default_context().w2_spatial(mean, V).reshape(len(models), n_lat, n_lon)
+            lat_name, lon_name = md.dims[2], md.dims[3]
+            return DataArray(w, ("model", lat_name, lon_name),
+                             {"model": np.asarray(process_models.model_names), lat_name: md.coords[lat_name],
+                              lon_name: md.coords[lon_name]}, "Model similarity weights")
         raise ValueError('Mode must be "single", "spatial", or "temporal"')
 
 

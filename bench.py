@@ -368,6 +368,49 @@ def api_path(ctx, M, N, R, T, reps=5):
                              "-ELBO sample per 25 iterations)" % reps}
 
 
+def api_path_c5(ctx, M, n_lat, n_lon, N, R, T, reps=3):
+    """BASELINE config 5 through the plug-in classes: ModelCollection.fit(GPDTW1D(per_gridpoint=True)) ->
+    LogLikelihoodWeight -> Barycentre on (realisation, time, latitude, longitude) models, host arrays in (the realisations
+    cross PCIe as they lie in memory; the prologue runs on the device), per-gridpoint posteriors resident in HBM, the
+    [M, time, lat, lon] weight table and the barycentre field downloaded."""
+    import warnings
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    rng = np.random.default_rng(0xC5)
+    G = n_lat * n_lon
+    tau = np.linspace(0.0, 1.0, N)[None, :, None, None]
+    loc = 1.0 + 0.2 * rng.standard_normal((1, 1, n_lat, n_lon))
+    coords = {"time": np.arange(N), "latitude": np.linspace(-89, 89, n_lat), "longitude": np.linspace(0, 357.5, n_lon)}
+    dims = ("realisation", "time", "latitude", "longitude")
+
+    def pm(amp, n_real, name):
+        vals = 1.5 * amp * loc * tau ** 2 + 0.036 * rng.standard_normal((n_real, N, n_lat, n_lon)).cumsum(axis=1)
+        return es.ProcessModel(DataArray(vals, dims, dict(coords, realisation=np.arange(n_real))), name)
+    mc = es.ModelCollection([pm(0.8 + 0.4 * rng.random(), R, f"member{m}") for m in range(M)])
+    ob = pm(1.0, 3, "obs")
+    best, parts = None, None
+    for _ in range(reps + 1):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=T, progress_bar=False)
+            ctx.sync()
+            t1 = time.perf_counter()
+            w = es.LogLikelihoodWeight()(mc, ob, standardisation_constant=1e-3)
+            t2 = time.perf_counter()
+            post = es.Barycentre()(mc, w)
+            t3 = time.perf_counter()
+        if best is None or t3 - t0 < best:
+            best, parts = t3 - t0, (t1 - t0, t2 - t1, t3 - t2)
+    assert np.isfinite(post.mu).all() and w.shape == (M, N, n_lat, n_lon)
+    return {"api_path_c5_fits_per_s": round(M * G / best, 1), "api_path_c5_ms_per_step": round(best * 1e3, 2),
+            "api_path_c5_ms_fit_weights_barycentre": [round(p * 1e3, 2) for p in parts],
+            "api_path_c5_note": f"{M} members x {n_lat}x{n_lon} grid points, N={N}, R={R}: ModelCollection.fit(GPDTW1D("
+                                "per_gridpoint=True)) + LogLikelihoodWeight + Barycentre through the Python classes, host "
+                                f"realisations in ({M * R * N * G * 8 / 1e6:.0f} MB over PCIe), weight table and barycentre "
+                                "field out; best of %d" % reps}
+
+
 def spawn_ranks(args):
     """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
     rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
@@ -568,6 +611,8 @@ def main():
         c5["workload"] = ("BASELINE config 5, one GPU's share: 32 members x 1728 grid points (96x144 over 8 GPUs) of "
                           "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
         extra["config5"] = c5
+        extra.update(api_path_c5(ctx, 32, 36, 48, 86, 8, T))
+        extra["api_path_c5_vs_resident_step"] = round(extra["api_path_c5_ms_per_step"] / c5["ms_per_step"], 3)
         for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):
             w2 = Workload(ctx, M, N, R, T, kern, is32, 0, 1, None, weighting="w2_temporal" if is32 else "loglik")
             el = w2.timed(3, 1)

@@ -104,6 +104,14 @@ int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         double* mu, double* cov, double* cov_chol, double* logdet,
                         double* hyp, double* loss_trace, int* info, double* ll_basis);
 
+/* The prologue of GPDTW1D.fit (ensembles/models.py:175-182: y_var = np.var(realisation_set, axis=0), X = realisation_set^T;
+ * y_mean = the mean over realisations, the documented stand-in for the tslearn DTW barycentre of models.py:176-178) at
+ * every grid point of M fields raw [M][R][N][G] (realisation, time, flattened space - the array as the caller holds it):
+ * X [M*G][N][R], y_mean / y_var [M*G][N], fit index b = m * G + g - the inputs of bayens_gp_fit_batch_reduced for a
+ * per-gridpoint fit (BASELINE config 5). */
+int bayens_field_prologue(bayens_ctx* ctx, int loc, int M, int R, int N, int G, const double* raw, double* X,
+                          double* y_mean, double* y_var);
+
 /* Small members (N <= 94, e.g. the reference's annual series N = 86, experiments/full_experiment_script.py:57,70, and
  * BASELINE.json config 5's per-gridpoint fits) are fitted by bayens_gp_fit_batch in ONE fused kernel, one workgroup per
  * member with every matrix resident in LDS (csrc/small.hip; BAYENS_NO_SMALL=1 forces the general path).  This entry is

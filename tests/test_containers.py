@@ -70,3 +70,17 @@ def test_dataarray_named_broadcast_and_reductions():
     assert c.dims == ("model", "time") and list(c.coords["model"]) == ["p", "q"]
     e = s.expand_dims(time2=np.arange(4), axis=0)
     assert e.shape == (4, 3)
+
+
+def test_distribution_fields_are_assignable_like_the_references_dataclass():
+    """ensembles/data.py:18-24 is a plain @dataclass: `dist.mu = ...` works, and it has a generated __repr__ / __eq__."""
+    from bayesian_ensembling_amd import distributions as dx
+    from bayesian_ensembling_amd.data import Distribution
+    blank = DataArray(np.full(4, np.nan), ("time",), {"time": np.arange(4)})
+    d = Distribution(mu=np.arange(4.0), covariance=np.full(4, 2.0), dim_array=blank, dist_type=dx.MultivariateNormalDiag)
+    e = Distribution(mu=np.arange(4.0), covariance=np.full(4, 2.0), dim_array=blank, dist_type=dx.MultivariateNormalDiag)
+    assert d == e and "MultivariateNormalDiag" in repr(d)
+    d.mu = np.ones(4)
+    assert np.array_equal(d.mean.values, np.ones(4)) and d != e
+    d.covariance = np.full(4, 3.0)
+    assert np.array_equal(d._dist.variance(), np.full(4, 9.0))            # scale quirk re-derived on assignment

@@ -1,0 +1,104 @@
+"""BASELINE config 5 through the plug-in classes: `GPDTW1D(per_gridpoint=True)` on (realisation, time, latitude, longitude)
+models -> LogLikelihoodWeight -> Barycentre, the reference's 1-D path (ensembles/models.py:175-220, weights.py:88-123,
+ensemble_scheme.py:52-78) applied at every grid point, checked against the oracle point by point; and
+ModelSimilarityWeight(mode='spatial') on MeanFieldApproximation posteriors (weights.py:267-300)."""
+import numpy as np
+import pytest
+from threadpoolctl import threadpool_limits
+
+import bayesian_ensembling_amd as es
+from bayesian_ensembling_amd import distributions as dx
+from bayesian_ensembling_amd.labelled import DataArray
+from conftest import relerr
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _field_collection(M, R, T, n_lat, n_lon, R_obs=3, seed=0):
+    rng = np.random.default_rng(seed)
+    tau = np.linspace(0.0, 1.0, T)[None, :, None, None]
+    loc = 1.0 + 0.2 * rng.standard_normal((1, 1, n_lat, n_lon))
+    coords = {"time": np.arange(T), "latitude": np.linspace(-60, 60, n_lat), "longitude": np.linspace(0, 315, n_lon)}
+    dims = ("realisation", "time", "latitude", "longitude")
+
+    def da(amp, n_real):
+        vals = 1.5 * amp * loc * tau ** 2 + 0.036 * rng.standard_normal((n_real, T, n_lat, n_lon)).cumsum(axis=1)
+        return DataArray(vals, dims, dict(coords, realisation=np.arange(n_real)))
+    mc = es.ModelCollection([es.ProcessModel(da(0.8 + 0.4 * rng.random(), R), f"model{m}") for m in range(M)])
+    return mc, es.ProcessModel(da(1.0, R_obs), "obs")
+
+
+def test_config5_through_the_plugin_classes(ctx):
+    M, R, T, n_lat, n_lon, nits = 4, 4, 30, 6, 8, 2
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon)
+    with pytest.raises(NotImplementedError):                      # the reference's behaviour stays the default
+        mc.fit(model=es.GPDTW1D(), n_optim_nits=nits)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=nits, progress_bar=False)
+    assert all(m.distribution.dist_type is dx.GridMultivariateNormalFullCovariance for m in mc.models)
+    w = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2)
+    assert isinstance(w, DataArray) and w.shape == (M, T, n_lat, n_lon) and w.dims[0] == "model"
+    assert np.all(w.sum("model").values == pytest.approx(1.0, 1e-9))
+    post = es.Barycentre()(mc, w)
+    assert post.dist_type is dx.MultivariateNormalDiag and post.mean.shape == (T, n_lat, n_lon)
+    wv = np.asarray(w.values)
+    bm, bv = np.asarray(post.mu).reshape(T, n_lat, n_lon), np.asarray(post.covariance).reshape(T, n_lat, n_lon)
+    ov = np.asarray(obs.model_data.values)
+    with threadpool_limits(1):
+        for (i, j) in [(0, 0), (2, 5), (5, 7), (3, 3)]:
+            mus, vs, lls = [], [], []
+            for m in range(M):
+                X, y, nu = go.prologue(np.asarray(mc[m].model_data.values)[:, :, i, j])
+                mo, co, _ = go.gp_fit(X, y, nu, nits)
+                Lc, ld = go.mvn_factor(co)
+                lls.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, Lc, ld, ov[:, :, i, j])))
+                mus.append(mo); vs.append(np.diag(co))
+                assert relerr(mc[m].distribution.mean.values[:, i, j], mo) < 1e-10
+                assert relerr(mc[m].distribution.variance.values[:, i, j], vs[-1]) < 1e-10
+            w_ref, _ = go.loglik_weights(np.stack(lls), 1e-2)
+            assert relerr(wv[:, :, i, j], w_ref) < 1e-9
+            rm, rv, _ = go.barycentre(w_ref, np.stack(mus), np.stack(vs))
+            assert relerr(bm[:, i, j], rm) < 1e-9 and relerr(bv[:, i, j], rv) < 1e-9
+    # the other consumers of a posterior's marginals work on the field too (mode='temporal' flattens (time, space))
+    ws = es.CRPSWeight()(mc, obs)
+    assert ws.shape == (M, T, n_lat, n_lon) and np.all(ws.sum("model").values == pytest.approx(1.0, 1e-9))
+    import pickle
+    clone = pickle.loads(pickle.dumps(mc.models[1].distribution))          # ModelCollection.save: marginals survive
+    assert np.array_equal(clone.mean.values, mc.models[1].distribution.mean.values)
+    assert np.allclose(clone.variance.values, mc.models[1].distribution.variance.values, rtol=1e-14)
+
+
+def test_field_fit_in_several_launches_equals_one(ctx):
+    """FIELD_CHUNK splits a field over several launches of the fused kernel: same posteriors, bit for bit."""
+    mc, _ = _field_collection(3, 3, 20, 5, 7, seed=3)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=1)
+    one = [np.array(m.distribution.mean.values) for m in mc.models]
+    model = es.GPDTW1D(per_gridpoint=True)
+    model.FIELD_CHUNK = 16
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mc.fit(model=model, n_optim_nits=1)
+    for a, m in zip(one, mc.models):
+        assert np.array_equal(a, m.distribution.mean.values)
+
+
+def test_model_similarity_weight_spatial_mode(ctx):
+    """weights.py:267-300, the dx.Normal branch: MeanFieldApproximation posteriors of (realisation, time, lat, lon) models;
+    D[i,j,lat,lon] = ||dmean||_2 over time + sum_t (V_i - V_j)^2 with V = Distribution.variance (the reference hands the
+    variance to dx.Normal as its scale), nanmean over j, normalised over the models -> (model, latitude, longitude)."""
+    M, R, T, n_lat, n_lon = 5, 4, 12, 4, 6
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=5)
+    mc.fit(model=es.MeanFieldApproximation())
+    with pytest.warns(UserWarning, match="experimental"):
+        w = es.ModelSimilarityWeight()(mc, obs, mode="spatial")
+    assert w.dims == ("model", "latitude", "longitude") and w.shape == (M, n_lat, n_lon)
+    assert np.all(w.sum("model").values == pytest.approx(1.0, 1e-12))
+    mean = np.stack([m.distribution.mean.values for m in mc.models])
+    V = np.stack([m.distribution.variance.values for m in mc.models])
+    assert relerr(V[0], np.asarray(mc[0].model_data.values).var(axis=0) ** 2) < 1e-12      # variance() = scale^2 quirk
+    assert relerr(w.values, go.w2_weights_spatial(mean, V)) < 1e-12
+    mc1, _ = _field_collection(2, 3, 10, 2, 2, seed=6)
+    mc1.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=1)
+    with pytest.warns(UserWarning), pytest.raises(NotImplementedError):
+        es.ModelSimilarityWeight()(mc1, mode="spatial")
