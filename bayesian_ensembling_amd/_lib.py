@@ -75,6 +75,7 @@ def load():
     lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
     lib.bayens_gp_fit_batch_reduced.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                                 C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_transpose_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_field_prologue.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_factor_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_loglik_rows_basis.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
@@ -346,6 +347,10 @@ class Context:
             err.info = info
             raise err
         return info
+
+    def transpose_rows_dev(self, nb, A, B, src, dst):
+        """[nb][A][B] -> [nb][B][A] on resident buffers (out of place)."""
+        self._check(self.lib.bayens_transpose_rows(self.h, DEVICE, nb, A, B, _ptr(src), _ptr(dst)))
 
     def field_prologue_dev(self, M, R, N, G, raw, X, y_mean, y_var):
         """models.py:175-182 at every grid point, on resident buffers: raw [M][R][N][G] -> X [M*G][N][R], y, nu [M*G][N]."""

@@ -491,6 +491,19 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
   });
 }
 
+int bayens_transpose_rows(bayens_ctx* c, int loc, int nb, int A, int B, const double* src, double* dst) {
+  return guarded(c, [&]() {
+    if (nb <= 0 || A <= 0 || B <= 0 || nb > 65535 || !src || !dst || src == dst)
+      return fail(c, BAYENS_E_ARG, "transpose_rows: bad argument");
+    Stage st(c, loc);
+    const double* ds = st.in(src, (size_t)nb * A * B);
+    double* dd = st.out(dst, (size_t)nb * A * B);
+    c->prims->transpose_rows(nb, A, B, ds, dd);
+    st.finish();
+    return 0;
+  });
+}
+
 int bayens_field_prologue(bayens_ctx* c, int loc, int M, int R, int N, int G, const double* raw, double* X, double* y_mean,
                           double* y_var) {
   return guarded(c, [&]() {
@@ -895,8 +908,26 @@ int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const do
     c->prims->loglik_rows_basis(B, N, R_obs, basis, dld, dobs, dll, dots);
     int herr = 0;
     BAYENS_HIP(hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    static const bool force_stall = getenv("BAYENS_FORCE_CHAIN_STALL") != nullptr;     // (test hook for the fallback)
+    if (herr || force_stall) {
+      // The chain's liveness rests on producer workgroups being dispatched before their consumers and is bounded by a
+      // poll count, not by progress: on a GPU shared with other streams / processes a consumer can run out of polls
+      // for perfectly valid input.  That is a scheduling accident, not an error of the caller: recompute the basis
+      // through the blocked solve, which has no cross-workgroup waits (pad the factor, invert its diagonal blocks,
+      // carry the rows (1, mu) through trsm_rlt) - a few launches and a second pass over the factor instead of one.
+      FactorSolve fs(c, B, N, dch);
+      int pivot = 0;
+      if (const int bad = fs.bad_member(&pivot))
+        return fail(c, BAYENS_E_NOTPD, "loglik_rows: the factor of member " + std::to_string(bad - 1) +
+                                           " has a diagonal entry that is not positive and finite (row " +
+                                           std::to_string(pivot) + ")");
+      c->prims->solve_rows_set(B, N, fs.Np, 2, 1, nullptr, 0, dmu, fs.rows());
+      fs.solve();
+      c->prims->basis_rows_get(B, N, fs.Np, fs.rows(), basis);
+      c->prims->loglik_rows_basis(B, N, R_obs, basis, dld, dobs, dll, dots);
+    }
     st.finish();
-    if (herr) return fail(c, BAYENS_E_INTERNAL, "loglik_rows: the substitution chain stalled");
     return 0;
   });
 }

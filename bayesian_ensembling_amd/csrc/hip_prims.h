@@ -151,6 +151,7 @@ struct HipPrims : Prims {
   void weights_normalise(int M, int P, const double* ll_mean, double c_std, double* w, double* w_raw);
   void w2_temporal(int M, int P, const double* mean, const double* var, double* w);
   void w2_spatial(int M, int T, int G, const double* mean, const double* V, double* w);
+  void transpose_rows(int nb, int A, int B, const double* src, double* dst);
   void field_prologue(int M, int R, int N, int G, const double* raw, double* X, double* y_mean, double* y_var);
   void barycentre(int M, int P, const double* w, const double* mean, const double* var, double tol,
                   double init_var, double* mu_out, double* var_out, int* n_bad);

@@ -1096,6 +1096,20 @@ __global__ void field_prologue_kernel(int R, int N, int G, const double* raw, do
   y_var[b * N + n] = sq / R;
 }
 
+// [nb][A][B] -> [nb][B][A] through a padded 32 x 32 LDS tile (both sides coalesced): the per-gridpoint field keeps its
+// tables fit-major ([member][grid point][time], what the fused fit kernel writes), the plug-in classes speak the data's
+// (time, lat, lon) order
+__global__ void transpose_rows_kernel(int A, int B, const double* src, double* dst) {
+  __shared__ double tile[32][33];
+  const long base = (long)blockIdx.z * A * B;
+  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    if (a0 + r < A && b0 + tx < B) tile[r][tx] = src[base + (long)(a0 + r) * B + b0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (b0 + r < B && a0 + tx < A) dst[base + (long)(b0 + r) * A + a0 + tx] = tile[tx][r];
+}
+
 // weights.py:267-300 (mode='spatial', dx.Normal branch) with wasserstein.py:21-47, full_cov=False: per grid point p the
 // reference builds dx.Normal(mean_i[:, p], scale = variance_i[:, p]) over the T time steps, so
 //   D[i,j,p] = || mean_i[:,p] - mean_j[:,p] ||_2  +  sum_t (V_i[t,p] - V_j[t,p])^2        (V = distribution.variance)
@@ -1736,6 +1750,10 @@ void HipPrims::w2_temporal(int M, int P, const double* mean, const double* var, 
 }
 void HipPrims::field_prologue(int M, int R, int N, int G, const double* raw, double* X, double* y_mean, double* y_var) {
   hipLaunchKernelGGL(field_prologue_kernel, dim3((G + 255) / 256, N, M), dim3(256), 0, stream, R, N, G, raw, X, y_mean, y_var);
+  LAUNCH_CHECK();
+}
+void HipPrims::transpose_rows(int nb, int A, int B, const double* src, double* dst) {
+  hipLaunchKernelGGL(transpose_rows_kernel, dim3((B + 31) / 32, (A + 31) / 32, nb), dim3(256), 0, stream, A, B, src, dst);
   LAUNCH_CHECK();
 }
 void HipPrims::w2_spatial(int M, int T, int G, const double* mean, const double* V, double* w) {

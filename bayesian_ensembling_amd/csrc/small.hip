@@ -1010,11 +1010,15 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 template <int NT>
 static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
   const size_t lds = Layout<NT>::BYTES;
-  static bool configured = false;
-  if (!configured) {
+  // the attribute belongs to the (function, device) pair: one flag per device, so that a second context on another GPU
+  // of the node configures its own copy of the kernel
+  static bool configured[64] = {};
+  int dev = 0;
+  BAYENS_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
     BAYENS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_fit_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-    configured = true;
+    if (dev >= 0 && dev < 64) configured[dev] = true;
   }
   const int per_cu = (int)(163840 / lds) > 0 ? (int)(163840 / lds) : 1;
   int grid = n_cus * per_cu;

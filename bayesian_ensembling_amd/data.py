@@ -105,6 +105,24 @@ class Distribution:
             del state["_dist"]
         return state
 
+    def __deepcopy__(self, memo):
+        """A resident posterior is immutable device data: a deep copy (PerfectModelTest.run copies the whole collection
+        once per held-out member, ensembles/utils.py:196-199) shares the HBM buffers instead of forcing the 64 MB per
+        member download that pickling needs; host-side fields are copied as usual."""
+        import copy
+        if self._resident is None:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+            return new
+        new = Distribution(dim_array=copy.deepcopy(self.dim_array, memo), dist_type=self.dist_type, _resident=self._resident)
+        for k in ("hyperparameters", "losses"):
+            if hasattr(self, k):
+                setattr(new, k, copy.deepcopy(getattr(self, k), memo))
+        memo[id(self)] = new
+        return new
+
     def __setstate__(self, state):
         rebuild = "_dist" not in state
         self.__dict__.update(state)

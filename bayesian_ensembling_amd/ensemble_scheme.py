@@ -53,14 +53,16 @@ class Barycentre(AbstractEnsembleScheme):
             # the data's (time, *space) order and are turned into that layout, the result back (ensemble_scheme.py:51-52
             # flattens space into the point axis in the same way)
             ctx, G, N = field.ctx, field.G, field.N
-            wf = np.ascontiguousarray(w.reshape(M, N, G).transpose(0, 2, 1)).reshape(M, G * N)
-            dw, dmu, dv = ctx.to_device(wf), ctx.empty((G * N,)), ctx.empty((G * N,))
+            dwt, dw, dmu, dv, dout = ctx.to_device(w), ctx.empty((M, G * N)), ctx.empty((G * N,)), ctx.empty((G * N,)), ctx.empty((2, N * G))
             try:
+                ctx.transpose_rows_dev(M, N, G, dwt, dw)                               # (time, space) -> [grid point][time]
                 bad = ctx.barycentre_dev(M, G * N, dw, field.mu, field.var, dmu, dv)
-                mu = np.ascontiguousarray(dmu.download().reshape(G, N).T).reshape(-1)
-                v = np.ascontiguousarray(dv.download().reshape(G, N).T).reshape(-1)
+                ctx.transpose_rows_dev(1, G, N, dmu, dout)
+                ctx.transpose_rows_dev(1, G, N, dv, dout.offset(N * G * 8))
+                both = dout.download()
+                mu, v = both[0], both[1]
             finally:
-                for d in (dw, dmu, dv):
+                for d in (dwt, dw, dmu, dv, dout):
                     d.free()
         elif all(getattr(d, "_resident", None) is not None for d in ds):
             # resident posteriors: the [M, P] marginals are read in HBM; the weights go up, mu* / sigma*^2 come down

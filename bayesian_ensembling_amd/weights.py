@@ -114,20 +114,28 @@ class LogLikelihoodWeight(AbstractWeight):
         ctx = field.ctx
         M, G, N = field.M, field.G, field.N
         R_obs = observations.n_realisations
-        obs = np.asarray(observations.model_data.values, dtype=np.float64).reshape(R_obs, N, G)
-        dobs = ctx.to_device(np.ascontiguousarray(obs.transpose(2, 0, 1)))                       # [G][R_obs][N]
-        dll, dw, draw = ctx.empty((M * G, N)), ctx.empty((M, G * N)), ctx.empty((M, G * N))
+        # observations go up as they lie in memory [R_obs][N][G] and are re-laid on the device to [G][R_obs][N] (one
+        # observation set per grid point): [R_obs * N][G] -> [G][R_obs * N] is that, since rows of one point stay together
+        dobs_raw = ctx.to_device(np.asarray(observations.model_data.values, dtype=np.float64).reshape(R_obs * N, G))
+        dobs, dll, dw = ctx.empty((G, R_obs, N)), ctx.empty((M * G, N)), ctx.empty((M, G * N))
+        draw = ctx.empty((M, G * N)) if return_lls else None
+        dout = ctx.empty((M, N * G))
         try:
-            ctx.loglik_rows_basis_grouped(field.basis, field.logdet, _lib.DeviceView(dobs.ptr, (G, R_obs, N)), loc=_lib.DEVICE,
-                                          out=dll)
+            ctx.transpose_rows_dev(1, R_obs * N, G, dobs_raw, dobs)
+            ctx.loglik_rows_basis_grouped(field.basis, field.logdet, dobs, loc=_lib.DEVICE, out=dll)
             ctx.weights_normalise_dev(M, G * N, dll, c_std, dw, draw)
-            w, raw = dw.download(), draw.download()
+            # device order [M][G][N] -> the data's (model, time, *space)
+            ctx.transpose_rows_dev(M, G, N, dw, dout)
+            w = dout.download()
+            raw = None
+            if return_lls:
+                ctx.transpose_rows_dev(M, G, N, draw, dout)
+                raw = dout.download()
         finally:
-            for d in (dobs, dll, dw, draw):
-                d.free()
-        # device order [M][G][N] -> the data's (model, time, *space)
-        back = lambda a: np.ascontiguousarray(a.reshape(M, G, N).transpose(0, 2, 1)).reshape(M, -1)
-        return self._finish(process_models, observations, models, back(w), back(raw), return_lls)
+            for d in (dobs_raw, dobs, dll, dw, draw, dout):
+                if d is not None:
+                    d.free()
+        return self._finish(process_models, observations, models, w, raw, return_lls)
 
     @staticmethod
     def _finish(process_models, observations, models, w, raw, return_lls):

@@ -104,6 +104,11 @@ int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         double* mu, double* cov, double* cov_chol, double* logdet,
                         double* hyp, double* loss_trace, int* info, double* ll_basis);
 
+/* [nb][A][B] -> [nb][B][A] (out of place).  The per-gridpoint field keeps its tables fit-major ([member][grid point][time]);
+ * the reference's consumers flatten (time, lat, lon) in the data's order (ensembles/ensemble_scheme.py:51-52,
+ * weights.py:93-100 `.ravel()`): this is the device-side change of layout between the two. */
+int bayens_transpose_rows(bayens_ctx* ctx, int loc, int nb, int A, int B, const double* src, double* dst);
+
 /* The prologue of GPDTW1D.fit (ensembles/models.py:175-182: y_var = np.var(realisation_set, axis=0), X = realisation_set^T;
  * y_mean = the mean over realisations, the documented stand-in for the tslearn DTW barycentre of models.py:176-178) at
  * every grid point of M fields raw [M][R][N][G] (realisation, time, flattened space - the array as the caller holds it):

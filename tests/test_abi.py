@@ -56,3 +56,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "gp_oracle" not in txt and "hostcheck" not in txt.replace("oracle/hostcheck", ""), f
+
+
+def test_nothing_but_the_gemms_own_dma_setup_touches_m0():
+    """tools/check_m0.py: compiles csrc/gemm.hip to gfx950 assembly (no GPU needed) and checks the inline-assembly contract
+    of lds_dma16 - the compiler ignores the `m0` clobber, so the absence of compiler-generated M0 traffic is verified."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_m0", os.path.join(root, "tools", "check_m0.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
+    bad, _ = mod.check("s_mov_b32 m0, s4\ns_nop 0\nglobal_load_lds_dwordx4 v[0:1], off\nv_readlane_b32 s5, v1, m0\n")
+    assert bad and "outside lds_dma16" in bad[0]

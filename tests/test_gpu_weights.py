@@ -531,3 +531,30 @@ def test_log_prob_refuses_a_factor_with_a_non_positive_diagonal(ctx):
     chol[1, 66, 66] = np.nan
     with pytest.raises(BayensError):
         ctx.mvn_log_prob(np.zeros((2, N)), chol, np.zeros(2), np.zeros((1, N)))
+
+
+def test_loglik_rows_falls_back_to_the_blocked_solve_when_the_chain_stalls(ctx, tmp_path):
+    """bayens_loglik_rows' one-launch substitution chain waits across workgroups with a bounded number of polls; on a
+    busy GPU a consumer may give up for valid input.  The entry then recomputes the basis through the blocked solve
+    (no cross-workgroup waits) instead of failing.  BAYENS_FORCE_CHAIN_STALL=1 takes that branch deterministically (in
+    a child process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(77)
+    M, N = 3, 200
+    A = rng.standard_normal((M, N, N + 8))
+    chol = np.linalg.cholesky(A @ A.transpose(0, 2, 1) / N + 0.5 * np.eye(N))
+    logdet = np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(axis=1)
+    mu, obs = rng.standard_normal((M, N)), rng.standard_normal((4, N))
+    chained = ctx.loglik_rows(mu, chol, logdet, obs)
+    np.savez(tmp_path / "in.npz", mu=mu, chol=chol, logdet=logdet, obs=obs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from bayesian_ensembling_amd import _lib; "
+            "d = np.load(%r); c = _lib.Context(0); "
+            "np.save(%r, c.loglik_rows(d['mu'], d['chol'], d['logdet'], d['obs']))"
+            % (root, str(tmp_path / "in.npz"), str(tmp_path / "out.npy")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BAYENS_FORCE_CHAIN_STALL="1"), timeout=300)
+    fallback = np.load(tmp_path / "out.npy")
+    ref = np.stack([go.loglik_mean_rows(go.mvn_constvec_loglik(mu[m], chol[m], logdet[m], obs)) for m in range(M)])
+    assert relerr(fallback, ref) < 1e-11 and relerr(chained, ref) < 1e-11
