@@ -713,6 +713,16 @@ def device_count():
 
 
 _default_ctx = None
+_upload_ctxs = {}
+
+
+def upload_context(ctx):
+    """A second context (its own HIP stream) on the device of `ctx`, for host-to-device copies that overlap kernels
+    running on `ctx` (contexts are independent and may be driven from different threads; device memory is shared)."""
+    c = _upload_ctxs.get(ctx.device)
+    if c is None:
+        c = _upload_ctxs[ctx.device] = Context(ctx.device)
+    return c
 
 
 def default_context():

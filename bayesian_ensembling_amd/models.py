@@ -64,6 +64,7 @@ class GPDTW1D:
 
     # -- per-gridpoint fields (BASELINE config 5) -------------------------------------------------------
     FIELD_CHUNK = 65536          # fits per launch of the fused small-member kernel
+    FIELD_STAGES = 8             # upload / fit pipeline stages of a collection
 
     def fit_field(self, process_models, n_optim_nits: int = 500):
         """Every (member, grid point) of a collection of (realisation, time, *space) models as an independent GP over
@@ -88,28 +89,57 @@ class GPDTW1D:
         B = M * G
         dX, dy, dnu = ctx.empty((B, N, R)), ctx.empty((B, N)), ctx.empty((B, N))
         draw = ctx.empty((M, R, N, G))
+        worker = None
         try:
-            # the realisations go up as they lie in memory ((realisation, time, *space), grid points contiguous); the
-            # prologue of models.py:175-182 runs on the device for every grid point at once (bayens_field_prologue)
+            # The realisations go up as they lie in memory ((realisation, time, *space), grid points contiguous); the
+            # prologue of models.py:175-182 runs on the device for every grid point at once (bayens_field_prologue).
+            # The collection is cut into stages of a few members: while one stage is being fitted, the next one's
+            # realisations cross PCIe on a second stream (its own context, driven by a helper thread - ctypes releases
+            # the GIL inside the blocking calls), so the upload (304 MB at config 5) hides behind the fits.
             row = R * N * G * 8
-            for m, pm in enumerate(process_models):
-                data = np.ascontiguousarray(pm.model_data.values, dtype=np.float64)
-                ctx._check(ctx.lib.bayens_memcpy_h2d(ctx.h, draw.offset(m * row), data.ctypes.data, data.nbytes))
-            ctx.field_prologue_dev(M, R, N, G, draw, dX, dy, dnu)
-            if callable(self.target):       # a user-supplied barycentre replaces the mean target, grid point by grid point
-                y = np.empty((B, N))
-                for m, pm in enumerate(process_models):
-                    data = np.asarray(pm.model_data.values, dtype=np.float64).reshape(R, N, G)
-                    for g in range(G):
-                        y[m * G + g] = np.asarray(self.target(data[:, :, g]), dtype=np.float64).reshape(-1)
-                dy.upload(y)
-            for b0 in range(0, B, self.FIELD_CHUNK):
-                nb = min(B, b0 + self.FIELD_CHUNK) - b0
-                ctx.gp_fit_batch_reduced_dev(nb, N, R, dX.offset(b0 * N * R * 8), dy.offset(b0 * N * 8), dnu.offset(b0 * N * 8),
-                                             n_optim_nits, field.mu.offset(b0 * N * 8), field.var.offset(b0 * N * 8),
-                                             field.logdet.offset(b0 * 8), field.hyp.offset(b0 * 16),
-                                             field.basis.offset(b0 * 2 * N * 8), kernel=kid)
+            per_stage = max(1, -(-M // self.FIELD_STAGES))
+            stages = [(m0, min(M, m0 + per_stage)) for m0 in range(0, M, per_stage)]
+            up = _lib.upload_context(ctx)
+            failure = []
+
+            def upload(m0, m1):
+                try:
+                    for m in range(m0, m1):
+                        data = np.ascontiguousarray(process_models[m].model_data.values, dtype=np.float64)
+                        up._check(up.lib.bayens_memcpy_h2d(up.h, draw.offset(m * row), data.ctypes.data, data.nbytes))
+                except Exception as e:       # noqa: BLE001 - re-raised on the main thread
+                    failure.append(e)
+
+            import threading
+            worker = threading.Thread(target=upload, args=stages[0])
+            worker.start()
+            for k, (m0, m1) in enumerate(stages):
+                worker.join()
+                if failure:
+                    raise failure[0]
+                if k + 1 < len(stages):
+                    worker = threading.Thread(target=upload, args=stages[k + 1])
+                    worker.start()
+                f0 = m0 * G
+                ctx.field_prologue_dev(m1 - m0, R, N, G, draw.offset(m0 * row), dX.offset(f0 * N * R * 8),
+                                       dy.offset(f0 * N * 8), dnu.offset(f0 * N * 8))
+                if callable(self.target):   # a user-supplied barycentre replaces the mean target, grid point by grid point
+                    y = np.empty(((m1 - m0) * G, N))
+                    for m in range(m0, m1):
+                        data = np.asarray(process_models[m].model_data.values, dtype=np.float64).reshape(R, N, G)
+                        for g in range(G):
+                            y[(m - m0) * G + g] = np.asarray(self.target(data[:, :, g]), dtype=np.float64).reshape(-1)
+                    ctx._check(ctx.lib.bayens_memcpy_h2d(ctx.h, dy.offset(f0 * N * 8), y.ctypes.data, y.nbytes))
+                for b0 in range(f0, m1 * G, self.FIELD_CHUNK):
+                    nb = min(m1 * G, b0 + self.FIELD_CHUNK) - b0
+                    ctx.gp_fit_batch_reduced_dev(nb, N, R, dX.offset(b0 * N * R * 8), dy.offset(b0 * N * 8),
+                                                 dnu.offset(b0 * N * 8), n_optim_nits, field.mu.offset(b0 * N * 8),
+                                                 field.var.offset(b0 * N * 8), field.logdet.offset(b0 * 8),
+                                                 field.hyp.offset(b0 * 16), field.basis.offset(b0 * 2 * N * 8), kernel=kid)
+            worker.join()
         finally:
+            if worker is not None:
+                worker.join()             # (never free a buffer an upload is still writing to)
             for d in (dX, dy, dnu, draw):
                 d.free()
         dists = []
