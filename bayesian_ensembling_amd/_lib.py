@@ -120,6 +120,7 @@ def load():
     lib.bayens_small_stamps.argtypes = [_vp, C.c_int, _vp]
     lib.bayens_bench_diag16.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
+    lib.bayens_set_medium_min_batch.argtypes = [_vp, C.c_int]
     lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
@@ -253,6 +254,10 @@ class Context:
     def set_groups(self, n):
         """Member groups (HIP streams) a fit batch is split over; 1 serialises every kernel."""
         self._check(self.lib.bayens_set_groups(self.h, int(n)))
+
+    def set_medium_min_batch(self, n):
+        """Batch size from which members with 94 < N <= 254 take the fused mid-size kernel (default 128; 1 = always)."""
+        self._check(self.lib.bayens_set_medium_min_batch(self.h, int(n)))
 
     def profile_enable(self, on=True):
         self._check(self.lib.bayens_profile_enable(self.h, 1 if on else 0))

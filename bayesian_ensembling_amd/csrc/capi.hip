@@ -16,6 +16,7 @@
 #include "fit_f32.h"
 #include "fit_ws.h"
 #include "hip_prims.h"
+#include "medium.h"
 #include "small.h"
 
 using namespace bayens;
@@ -96,6 +97,18 @@ struct bayens_ctx {
     return sscratch;
   }
   int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
+  int medium_min_batch = 128;      // batches of at least this many mid-size members take the fused kernel (medium.hip)
+  double* mscratch = nullptr;      // tile scratch of the fused mid-size kernel (medium.hip), grown on demand
+  size_t mscratch_cap = 0;
+  double* medium_scratch(size_t count) {
+    if (count > mscratch_cap) {
+      if (mscratch) (void)hipFree(mscratch);
+      mscratch = nullptr;
+      if (hipMalloc((void**)&mscratch, count * sizeof(double)) != hipSuccess) throw HipError{BAYENS_E_ALLOC, "hipMalloc"};
+      mscratch_cap = count;
+    }
+    return mscratch;
+  }
   unsigned long long* small_stamps = nullptr;   // diagnostic phase stamps of the fused kernel (bayens_small_stamps)
   RcclApi rccl;
   ncclComm_t comm = nullptr;
@@ -270,6 +283,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   free_ws(c);
   if (c->f32) bayens_f32_destroy(c->f32);
   if (c->sscratch) (void)hipFree(c->sscratch);
+  if (c->mscratch) (void)hipFree(c->mscratch);
   if (c->xbuf) (void)hipFree(c->xbuf);
   if (c->small_stamps) (void)hipFree(c->small_stamps);
   for (auto* p : c->gprims) delete p;
@@ -439,6 +453,12 @@ int bayens_set_groups(bayens_ctx* c, int n_groups) {
   return 0;
 }
 
+int bayens_set_medium_min_batch(bayens_ctx* c, int min_batch) {
+  if (!c || min_batch < 1) return BAYENS_E_ARG;
+  c->medium_min_batch = min_batch;
+  return 0;
+}
+
 int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
                         const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
                         double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
@@ -450,8 +470,15 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
     static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
     const bool small = !no_small && smalln::small_fit_supported(N, R);
+    // mid-size members (94 < N <= 254, the reference's N = 165 series): ONE kernel too, matrices in an L2-resident scratch
+    // (medium.hip; BAYENS_NO_MEDIUM=1 forces the general path)
+    // Measured at N = 165 (profiles/r03_medium_kernel.txt): 441 us per optimiser iteration whatever the batch (one CU per
+    // member) against 356 (20 members) ... 724 (256 members) through the general path, which shares every launch between
+    // the members: the fused kernel takes over from medium_min_batch members on (default 128; bayens_set_medium_min_batch).
+    static const bool no_medium = getenv("BAYENS_NO_MEDIUM") != nullptr;
+    const bool medium = !small && !no_medium && B >= c->medium_min_batch && mediumn::medium_fit_supported(N, R);
     const int Np = pad_to_leaf(N);
-    if (!small) ensure_ws(c, B, Np);
+    if (!small && !medium) ensure_ws(c, B, Np);
     Stage st(c, loc);
     const double* dX = st.in(X, (size_t)B * N * R);
     const double* dy = st.in(y_mean, (size_t)B * N);
@@ -469,6 +496,22 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
       a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
       a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
       smalln::small_fit(c->stream, a, c->n_cus);
+      std::vector<int> hinfo(B, 0);
+      BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      st.finish();
+      int bad = 0;
+      for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+      if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
+      return 0;
+    }
+    if (medium) {
+      int* dinfo = st.scratch<int>((size_t)B);
+      mediumn::MediumArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo,
+                            c->medium_scratch((size_t)mediumn::medium_grid(B, N, c->n_cus) * mediumn::medium_scratch_doubles(N))};
+      a.stamps = c->small_stamps;
+      a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+      a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
+      mediumn::medium_fit(c->stream, a, c->n_cus);
       std::vector<int> hinfo(B, 0);
       BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       st.finish();

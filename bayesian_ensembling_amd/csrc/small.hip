@@ -503,6 +503,8 @@ __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_l
   return acc;
 }
 
+// (medium.hip includes this file for the tile helpers above and stops here)
+#ifndef BAYENS_SMALL_HELPERS_ONLY
 template <int NT>
 struct Layout {
   static constexpr int NTT = NT * (NT + 1) / 2;
@@ -1126,6 +1128,8 @@ void small_fit(hipStream_t stream, const SmallArgs& g, int n_cus) {
   else if (g.N + 2 <= 64) launch<4>(stream, g, n_cus);
   else launch<6>(stream, g, n_cus);
 }
+
+#endif  // BAYENS_SMALL_HELPERS_ONLY
 
 }  // namespace smalln
 }  // namespace BAYENS_NS

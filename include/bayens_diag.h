@@ -50,6 +50,12 @@ int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */
 int bayens_test_trsm(bayens_ctx* ctx, int nb, int m, int n, const double* L, double* Bm, int mode);
 
+/* Members with 94 < N <= 254 time points (the reference's N = 165 annual series) have two routes through
+ * bayens_gp_fit_batch: the general path (batched launches shared by all members) and the fused mid-size kernel
+ * (csrc/medium.hip: one workgroup per member, matrices in an L2-resident scratch), which wins once the batch is large.
+ * This sets the batch size from which the fused kernel is used (default 128; 1 = always, for the parity tests). */
+int bayens_set_medium_min_batch(bayens_ctx* ctx, int min_batch);
+
 /* Diagnostic: the pack -> [ncclAllGather image] -> unpack index arithmetic of bayens_allgather_member_rows without a
  * communicator: the host tables ll / mean / var [M][P] are split over `nranks` fictitious ranks exactly as
  * bayens_shard_bounds deals them, every rank's block goes through pack_rows_kernel into its slot of the gathered image

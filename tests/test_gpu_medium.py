@@ -1,0 +1,96 @@
+"""The fused mid-size fit kernel (csrc/medium.hip): members with 94 < N <= 254 time points - the reference's real workload,
+historical annual series N = 165 fitted with n_optim_nits = 2000-2500 (experiments/full_experiment_script.py:57,87-113) -
+one workgroup per member, matrices in an L2-resident scratch.  bayens_gp_fit_batch takes it for large batches (where it
+beats the general path); here it is forced for every batch size and held to the oracle, to the reference's own pickled
+N = 165 posteriors, and to the general path."""
+import os
+
+import numpy as np
+import pytest
+from threadpoolctl import threadpool_limits
+
+from conftest import GOLDEN, golden_files, member_inputs, relerr
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def mctx(ctx):
+    ctx.set_medium_min_batch(1)
+    yield ctx
+    ctx.set_medium_min_batch(128)
+
+
+@pytest.mark.parametrize("M,N,R,T,kernel", [
+    (2, 95, 4, 2, 0), (3, 130, 4, 2, 0), (2, 165, 9, 3, 0), (1, 174, 5, 2, 0), (1, 175, 5, 1, 0), (2, 200, 8, 2, 0),
+    (1, 254, 6, 2, 0), (2, 130, 4, 2, 1), (1, 100, 8, 2, 2), (1, 128, 4, 51, 0), (1, 200, 8, 0, 0), (1, 158, 50, 1, 0)])
+def test_medium_kernel_matches_the_oracle(mctx, M, N, R, T, kernel):
+    """Both ends of the range, the edges of the tile grid (174 | 175: 11 | 12 tiles of 16 with the two bordering rows), the
+    extension kernels, loss samples over more than 25 iterations, n_iters = 0, many realisations."""
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=N + R)
+    X, y, nu = member_inputs(data)
+    out = mctx.gp_fit_batch(X, y, nu, T, kernel=kernel, want_loss=True)
+    assert not out["info"].any()
+    tight = 1e-10 if kernel == 0 else 1e-6
+    with threadpool_limits(2):
+        for m in range(M):
+            res = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel, loss_every=25) if T > 0 else go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel)
+            mo, co, ho = res[:3]
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m], mo) < tight and relerr(out["cov"][m], co) < tight
+            assert relerr(out["chol"][m], Lc) < tight and relerr(out["hyp"][m], ho) < tight
+            assert abs(out["logdet"][m] - ld) < 1e-9 * max(1.0, abs(ld))
+            assert np.array_equal(out["cov"][m], out["cov"][m].T) and not np.triu(out["chol"][m], 1).any()
+            if T > 0:
+                assert np.allclose(out["loss"][m], res[3], rtol=1e-9)
+            import scipy.linalg as sla
+            assert relerr(out["basis"][m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 10 * tight
+            assert relerr(out["basis"][m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 10 * tight
+
+
+@pytest.mark.parametrize("fname", [f for f in golden_files() if "hist" in f])
+def test_medium_kernel_reproduces_the_references_pickled_n165_posterior(mctx, fname):
+    """experiments/pre_fit_models/histssp*.pkl (N = 165, GPDTW1D with n_optim_nits = 2500) through the fused mid-size kernel."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    X, _, nu = go.prologue(g["data"])
+    assert 94 < X.shape[0] <= 254
+    out = mctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], int(g["n_iters"]))
+    assert relerr(out["cov"][0], g["cov_gold"]) < 1e-6
+    assert np.max(np.abs(out["mu"][0] - g["mu_gold"])) < 1e-5
+    assert relerr(out["hyp"][0], g["hyp"]) < 1e-5
+
+
+def test_medium_and_general_paths_agree_and_large_batches_take_the_fused_kernel(ctx):
+    """A batch of 130 members of N = 120 (more members than the default threshold of 128, and than half the CUs): the
+    default dispatch (fused kernel) against the general path (threshold raised), member by member; every member of the
+    batch against the oracle at the edges of the grid of workgroups."""
+    M, N, R, T = 130, 120, 4, 2
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=7)
+    X, y, nu = member_inputs(data)
+    fused = ctx.gp_fit_batch(X, y, nu, T)
+    ctx.set_medium_min_batch(10 ** 6)
+    try:
+        general = ctx.gp_fit_batch(X, y, nu, T)
+    finally:
+        ctx.set_medium_min_batch(128)
+    for k in ("mu", "cov", "chol", "hyp", "basis"):
+        assert relerr(fused[k], general[k]) < 1e-10, k
+    assert not np.array_equal(fused["cov"], general["cov"])          # two different programs (else the dispatch did not switch)
+    with threadpool_limits(2):
+        for m in (0, 1, 64, 128, 129):
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T)
+            assert relerr(fused["mu"][m], mo) < 1e-10 and relerr(fused["cov"][m], co) < 1e-10 and relerr(fused["hyp"][m], ho) < 1e-10
+
+
+def test_more_members_than_workgroups(mctx):
+    """300 members of N = 96 on 256 CUs: workgroups take a second member and re-initialise their scratch."""
+    M, N, R, T = 300, 96, 3, 1
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=11)
+    X, y, nu = member_inputs(data)
+    out = mctx.gp_fit_batch(X, y, nu, T, want_chol=False)
+    assert not out["info"].any()
+    with threadpool_limits(2):
+        for m in (0, 255, 256, 299):
+            mo, co, _ = go.gp_fit(X[m], y[m], nu[m], T)
+            assert relerr(out["mu"][m], mo) < 1e-10 and relerr(out["cov"][m], co) < 1e-10
