@@ -1,19 +1,26 @@
 // medium.hip - the whole GP fit of a MID-SIZE member (94 < N <= 254 time points) in ONE kernel, one workgroup per
 // member: the reference's real workload (historical annual series N = 165 fitted with n_optim_nits = 2000-2500,
 // experiments/full_experiment_script.py:57,87-113; pre_fitting_cmip6models.py:76-77), which through the general path is
-// ~30 dependent launches per optimiser iteration over matrices padded to 192 - launch / latency bound at ~0.5 ms per
-// iteration whatever the batch.
+// ~30 dependent launches per optimiser iteration over matrices padded to 192 - latency bound at ~0.36 ms per iteration
+// for 20 members and growing with the batch.
 //
-// Same arithmetic and the same phases as the fused small-member kernel (small.hip, whose tile helpers this file
-// includes: 16x16 tiles, tile-packed lower triangles, explicit triangular inverses riding along with the blocked
-// factorisations, MFMA-based 16x16 diagonal factorisation) - reference ensembles/models.py:185-220 + data.py:38-39,
-// SURVEY.md Appendix A.  What differs is where the matrices live: at NT = 11 tiles per side a tile-packed triangle is
-// 132 KB, so the matrices cannot share the CU's 160 KB of LDS.  They live in a per-workgroup scratch in HBM that stays
-// L2-resident (eight triangles, ~1 MB per member at N = 165), every tile operand is fetched from there, LDS keeps the
-// vectors and the staging of the prediction's covariance rows, and the workgroup barrier also drains the vector-memory
-// counter so that one wave's tile stores are visible to the others (all waves of a workgroup share the CU's L1).
-// With no LDS limit there is no need to hold Lam / G / S in registers: they are scratch triangles too, which also
-// makes the tile count a RUN-TIME value (one instantiation for every N).
+// Same arithmetic as the fused small-member kernel (small.hip, whose tile helpers this file includes: 16x16 tiles,
+// tile-packed lower triangles, explicit triangular inverses riding along with the blocked factorisations, MFMA-based
+// 16x16 diagonal factorisation) - reference ensembles/models.py:185-220 + data.py:38-39, SURVEY.md Appendix A.  What
+// differs is where the matrices live.  At NT = 11 tiles per side a tile-packed triangle is 132 KB: the matrices cannot
+// share the CU's 160 KB of LDS.  They live in a per-workgroup scratch in HBM that stays L2-resident (six triangles,
+// ~0.8 MB per member at N = 165), and LDS is the staging area between that scratch and the matrix cores:
+//   * a tile in the scratch is stored in ACCUMULATOR-NATIVE order - lane (lr, lk)'s four accumulator elements
+//     (rows lk + 4r of column lr) are 32 contiguous bytes - so every load / store of a tile is one fully coalesced 2 KB
+//     wave access (the first version of this kernel read MFMA operands straight from the scratch, 8 scattered bytes per
+//     lane and instruction: the CU's L1 saw 64 line accesses per tile and was the bottleneck, 1.06 M cycles per iteration);
+//   * MFMA operands always come from LDS tiles in small.hip's conflict-free swizzled layout: every product phase is a
+//     loop over the contraction index k whose step stages the tiles that carry k (a column / row / "cross" of a
+//     triangle, <= 2 NT tiles) into LDS with coalesced loads, after which every wave updates the accumulators of the
+//     output tiles it owns (<= 9 per wave and pass, in registers) - each scratch tile is read once per phase;
+//   * the blocked factorisations keep the current block column, the current block row of the inverse and of the factor
+//     in LDS, so a trailing / inverse / Gram update is one coalesced read-modify-write of its output tile.
+// With no LDS limit on the matrices the tile count is a RUN-TIME value (one instantiation for every N).
 #include <cmath>
 #include <cstdlib>
 
@@ -32,90 +39,180 @@ using namespace smalln;
 
 // workgroup barrier that also publishes global stores: vector-memory loads AND stores return through vmcnt on gfx9
 #define GSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define LWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[k] = __builtin_readcyclecounter(); } while (0)
+
+constexpr int TPW = 9;                 // accumulator tiles a wave holds per pass of a product phase (72 VGPRs)
+constexpr int PASS_TILES = TPW * NW;   // output tiles per pass
 
 __device__ __forceinline__ void unpack_step(int& i, int& j, int step) {      // advance (i, j) by `step` packed positions
   j += step;
   while (j > i) { j -= i + 1; ++i; }
 }
+// accumulator-native tile in the scratch: element (row, col) at nidx(row, col); lane l owns doubles [4l, 4l + 4)
+__device__ __forceinline__ int nidx(int row, int col) { return ((col + 16 * (row & 3)) << 2) + (row >> 2); }
+__device__ __forceinline__ v4d ldn(const double* t, int lane) { return reinterpret_cast<const v4d*>(t)[lane]; }
+__device__ __forceinline__ void stn(double* t, int lane, v4d a) { reinterpret_cast<v4d*>(t)[lane] = a; }
+// LDS tile <- accumulator registers, transposed (element (row, col) of the registers lands at (col, row))
+__device__ __forceinline__ void st_tile_t(double* t, const Lane& o, v4d a) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[o.rc[r]] = a[r];
+}
+// acc += sa * A B with A an LDS tile and B given in accumulator-native registers (= the MFMA's B operand as it stands)
+__device__ __forceinline__ v4d mma_nb(v4d acc, const double* A, v4d b, const Lane& o) {
+  double a[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = A[o.rc[q]];
+  v4d acc2 = {0, 0, 0, 0};
+  acc = MFMA(a[0], b[0], acc);
+  acc2 = MFMA(a[2], b[2], acc2);
+  acc = MFMA(a[1], b[1], acc);
+  acc2 = MFMA(a[3], b[3], acc2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+  return acc;
+}
+// acc += op(A) op(B), both LDS tiles, orientation chosen at run time (ta: use A^T, tb: use B^T)
+__device__ __forceinline__ v4d mma_rt(v4d acc, const double* A, bool ta, const double* B, bool tb, const Lane& o) {
+  double a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = A[ta ? o.cr[q] : o.rc[q]]; b[q] = B[tb ? o.rc[q] : o.cr[q]]; }
+  v4d acc2 = {0, 0, 0, 0};
+  acc = MFMA(a[0], b[0], acc);
+  acc2 = MFMA(a[2], b[2], acc2);
+  acc = MFMA(a[1], b[1], acc);
+  acc2 = MFMA(a[3], b[3], acc2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+  return acc;
+}
+// (T x)[lr] (ta = false) or (T^T x)[lr] (ta = true) of one LDS tile, x = 16 LDS doubles; valid in every lane after the shuffles
+__device__ __forceinline__ double tile_mv(const double* T, bool ta, const double* x, const Lane& o) {
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s = fma(T[ta ? o.cr[q] : o.rc[q]], x[o.kq[q]], s);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
 
-// (L x)[16 i + lr], (L^T x)[16 j + lr], (S x)[16 i + lr] on tile-packed triangles; valid in lanes lk == 0
-__device__ __forceinline__ double mvr_lower(const double* Lb, const double* x, int i, const Lane& o) {
-  double s = 0.0;
-#pragma unroll 1
-  for (int k = 0; k <= i; ++k) {
-    const double* t = Lb + lt(i, k) * TS;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[o.rc[q]], x[16 * k + o.kq[q]], s);
-  }
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
-__device__ __forceinline__ double mvr_lower_t(const double* Lb, const double* x, int j, int NT, const Lane& o) {
-  double s = 0.0;
-#pragma unroll 1
-  for (int k = j; k < NT; ++k) {
-    const double* t = Lb + lt(k, j) * TS;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[o.cr[q]], x[16 * k + o.kq[q]], s);
-  }
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
-__device__ __forceinline__ double mvr_sym(const double* Sb, const double* x, int i, int NT, const Lane& o) {
-  double s = 0.0;
-#pragma unroll 1
-  for (int k = 0; k < NT; ++k) {
-    const double* t = Sb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma(t[k <= i ? o.rc[q] : o.cr[q]], x[16 * k + o.kq[q]], s);
-  }
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
+// hides a wave-uniform value from loop-invariant code motion: without it the compiler hoists the LDS addresses of every
+// (accumulator tile, operand, orientation) combination out of the k loops - ~150 VGPRs of addresses, i.e. hundreds of spills
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
 
-// Blocked Cholesky of the tile-packed triangle A in place (run-time tile count), D[k] = inverse of diagonal tile k;
-// WITH_INV: the inverse of the factor is formed alongside in Xb (block forward substitution).  Same two phases per
-// block column as smalln::potrf_lds - [panel, every wave] [wave 0: next diagonal tile | waves 1..7: trailing update,
-// inverse updates, extra(k)] - with the barriers publishing global stores.
-template <bool WITH_INV, class Extra>
-__device__ __forceinline__ int potrf_tiles(int NT, double* A, double* D, double* Xb, const Lane& o, int wave, int lane, int bad,
-                                           Extra extra) {
-  if (wave == 0) diag16(ld_tile_sym64(A, o), A, D, lane, 0, bad, o);
+struct Ctx {            // what every phase needs
+  int NT, NTT, wave, lane, tid;
+  double* SA;           // LDS staging: slots [0, NT) and [NT, 2 NT), slot 2 NT = inverse of the current diagonal tile, 2 NT + 1 = work tile
+  Lane o;
+  __device__ __forceinline__ double* slot(int s) const { return SA + (size_t)opaque(s) * TS; }
+};
+
+// ---- blocked Cholesky of the scratch triangle A in place; WITH_INV: the inverse of the factor is formed alongside in Xb
+// (block forward substitution).  Per block column k two phases, as in smalln::potrf_lds:
+//   P  [every wave]   panel L_ik = A_ik inv_kk^T and X_ki = inv_kk T_ki; results go to the scratch AND stay in LDS
+//                     (slot i: the panel tile for i > k, the inverse's tile for i <= k); MODE 1 also stages block row k
+//                     of the finished factor (slots NT + i)
+//   L  [wave 0]       next diagonal tile: update, 16x16 factorisation + inverse (diag16)
+//      [waves 1..7]   trailing update A_ij -= L_ik L_jk^T, inverse update T_ji -= L_jk X_ki, extra(k): every operand is an LDS
+//                     tile, every output one coalesced read-modify-write of a scratch tile
+// MODE 0: nothing extra.  MODE 1 (the kernel matrix): G_ij += L_ki^T D_k L_kj into Gb and wv += L_k*^T (y / nu)_k.
+// MODE 2 (Lam): S_ij += X_ki^T X_kj into Gb (the caller passes Sb).
+template <bool WITH_INV, int MODE>
+__device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, double* Gb, const double* rs, const double* yd, double* wv,
+                                        int bad) {
+  const int NT = c.NT, wave = c.wave, lane = c.lane;
+  const Lane& o = c.o;
+  double* Dk = c.slot(2 * NT);
+  double* Wk = c.slot(2 * NT + 1);
+  if (wave == 0) {
+    st_tile(Wk, o, ldn(A, lane));
+    LWAIT();
+    diag16(ld_tile_sym64(Wk, o), Wk, Dk, lane, 0, bad, o);
+    LWAIT();
+    stn(A, lane, ld_tile(Wk, o));
+  }
   GSYNC();
+  auto extra = [&](int k) {                    // waves 1..7; block row k of the factor (MODE 1) / of its inverse (MODE 2) is in LDS
+    if (MODE == 0) return;
+    int i = 0, j = 0;
+    unpack_step(i, j, wave - 1);
+#pragma unroll 1
+    for (int p = wave - 1; p < c.NTT; p += NW - 1) {
+      if (i > k) break;                        // packed order: every later tile has i > k too
+      double* gt = Gb + (size_t)p * TS;
+      v4d acc = {0, 0, 0, 0};
+      if (k > i) acc = ldn(gt, lane);          // first touched by block row k == i
+      if (MODE == 1) {
+        const double* ta = c.slot(NT + i);
+        const double* tb = c.slot(NT + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double scl = rs[16 * k + o.kq[q]];
+          acc = MFMA(ta[o.cr[q]] * scl, tb[o.cr[q]] * scl, acc);
+        }
+      } else {
+        acc = mma<true, false>(acc, c.slot(i), c.slot(j), o);
+      }
+      stn(gt, lane, acc);
+      unpack_step(i, j, NW - 1);
+    }
+    if (MODE == 1) {                           // wv_j += L_kj^T (y / nu)_k, j <= k: every j has one owner wave
+#pragma unroll 1
+      for (int jj = wave - 1; jj <= k; jj += NW - 1) {
+        const double s = tile_mv(c.slot(NT + jj), true, yd + 16 * k, o);
+        if (o.lk == 0) wv[16 * jj + o.lr] += s;
+      }
+    }
+  };
 #pragma unroll 1
   for (int k = 0; k < NT; ++k) {
     const int below = NT - 1 - k;
-    const double* dk = D + k * TS;
+    const int n_inv = WITH_INV ? k : 0, n_row = MODE == 1 ? k + 1 : 0;
 #pragma unroll 1
-    for (int q = wave; q < below + (WITH_INV ? k + 1 : 0); q += NW) {
+    for (int q = wave; q < below + n_inv + n_row; q += NW) {
       if (q < below) {                                    // panel: L_ik = A_ik inv_kk^T
-        double* t = A + lt(k + 1 + q, k) * TS;
+        const int i = k + 1 + q;
+        double* t = A + lt(i, k) * TS;
+        double* s = c.slot(i);
+        st_tile(s, o, ldn(t, lane));
+        LWAIT();
         v4d acc = {0, 0, 0, 0};
-        acc = mma<false, true>(acc, t, dk, o);
-        st_tile(t, o, acc);
-      } else {
+        acc = mma<false, true>(acc, s, Dk, o);
+        stn(t, lane, acc);
+        LWAIT();                                          // (this wave's operand reads of the slot are done)
+        st_tile(s, o, acc);
+      } else if (q < below + n_inv) {                     // X_ki = inv_kk T_ki (T_ki is the B operand as it lies in the scratch)
         const int i = q - below;
         double* t = Xb + lt(k, i) * TS;
-        if (i < k) {                                      // X_ki = inv_kk T_ki
-          v4d acc = {0, 0, 0, 0};
-          acc = mma<false, false>(acc, dk, t, o);
-          st_tile(t, o, acc);
-        } else {
-          st_tile(t, o, ld_tile(dk, o));                  // X_kk = inv_kk
-        }
+        v4d acc = {0, 0, 0, 0};
+        acc = mma_nb(acc, Dk, ldn(t, lane), o);
+        stn(t, lane, acc);
+        st_tile(c.slot(i), o, acc);
+      } else {                                            // block row k of the finished factor -> slots NT + i
+        const int i = q - below - n_inv;
+        st_tile(c.slot(NT + i), o, ldn(A + lt(k, i) * TS, lane));
       }
     }
+    if (WITH_INV && wave == NW - 1) {                     // X_kk = inv_kk
+      const v4d d = ld_tile(Dk, o);
+      stn(Xb + lt(k, k) * TS, lane, d);
+      st_tile(c.slot(k), o, d);
+    }
     GSYNC();
-    if (below == 0) break;
+    if (below == 0) {
+      if (wave != 0) extra(k);
+      break;
+    }
     if (wave == 0) {                                      // look-ahead: next diagonal tile, then its factorisation
       double* t = A + lt(k + 1, k + 1) * TS;
-      v4d acc = ld_tile_sym(t, o);
-      acc = mma<false, true>(acc, A + lt(k + 1, k) * TS, A + lt(k + 1, k) * TS, o, -1);
-      diag16(acc, t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);
+      st_tile(Wk, o, ldn(t, lane));
+      LWAIT();
+      v4d acc = ld_tile_sym(Wk, o);
+      acc = mma<false, true>(acc, c.slot(k + 1), c.slot(k + 1), o, -1);
+      LWAIT();
+      diag16(acc, Wk, Dk, lane, 16 * (k + 1), bad, o);   // (nobody reads inv_kk in this phase: inv_k+1,k+1 takes its slot)
+      LWAIT();
+      stn(t, lane, ld_tile(Wk, o));
     } else {
       int p = 0;
 #pragma unroll 1
@@ -124,9 +221,9 @@ __device__ __forceinline__ int potrf_tiles(int NT, double* A, double* D, double*
         for (int j = k + 1; j <= i; ++j)
           if (p++ % (NW - 1) == wave - 1) {               // A_ij -= L_ik L_jk^T
             double* t = A + lt(i, j) * TS;
-            v4d acc = ld_tile(t, o);
-            acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1);
-            st_tile(t, o, acc);
+            v4d acc = ldn(t, lane);
+            acc = mma<false, true>(acc, c.slot(i), c.slot(j), o, -1);
+            stn(t, lane, acc);
           }
       if (WITH_INV) {
 #pragma unroll 1
@@ -136,17 +233,54 @@ __device__ __forceinline__ int potrf_tiles(int NT, double* A, double* D, double*
             if (p++ % (NW - 1) == wave - 1) {             // T_ji -= L_jk X_ki   (first touched at k == i)
               double* t = Xb + lt(j, i) * TS;
               v4d acc = {0, 0, 0, 0};
-              if (k > i) acc = ld_tile(t, o);
-              acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1);
-              st_tile(t, o, acc);
+              if (k > i) acc = ldn(t, lane);
+              acc = mma<false, false>(acc, c.slot(j), c.slot(i), o, -1);
+              stn(t, lane, acc);
             }
       }
       extra(k);
     }
     GSYNC();
   }
-  if (wave != 0) extra(NT - 1);
+  GSYNC();
   return bad;
+}
+
+// ---- product phases: out_p = sum_k contrib_k for the packed output tiles p of a triangle (or a full square), PASS_TILES at a
+// time.  stage(k): the waves fill LDS slots for step k; use(k, i, j, acc): adds step k's contribution to the accumulator
+// of output tile (i, j); done(p, i, j, acc): epilogue + store.  `square`: outputs are the NT x NT tiles (i, j) = (p / NT, p % NT).
+template <class Stage, class Use, class Done>
+__device__ __forceinline__ void staged_product(const Ctx& c, int n_out, bool square, int k0, int k1, Stage stage, Use use, Done done) {
+#pragma unroll 1
+  for (int base = 0; base < n_out; base += PASS_TILES) {
+    v4d acc[TPW];
+    int ti[TPW], tj[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      acc[s] = v4d{0, 0, 0, 0};
+      const int p = base + c.wave + s * NW;
+      int i = 0, j = 0;
+      if (p < n_out) {
+        if (square) { i = p / c.NT; j = p - i * c.NT; }
+        else unpack_step(i, j, p);
+      }
+      ti[s] = p < n_out ? i : -1;
+      tj[s] = j;
+    }
+#pragma unroll 1
+    for (int k = k0; k < k1; ++k) {
+      stage(k);
+      GSYNC();
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+        if (ti[s] >= 0) acc[s] = use(k, ti[s], tj[s], acc[s]);
+      GSYNC();
+    }
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+      if (ti[s] >= 0) done(base + c.wave + s * NW, ti[s], tj[s], acc[s]);
+  }
+  GSYNC();
 }
 
 __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
@@ -163,23 +297,31 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
   double* av = mv + NP;                 // L m - y (loss samples); the posterior mean (prediction)
   double* wv = av + NP;                 // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
   double* uv = wv + NP;                 // u = G m - L^T (y / nu)
-  double* E0 = uv + NP;                 // staging of one tile row of A^T S (prediction), ping ...
-  double* E1 = E0 + (size_t)NT * TS;    // ... pong
-  // the workgroup's matrices: tile-packed lower triangles in an L2-resident HBM scratch
+  double* SA = uv + NP;                 // staging tiles (2 NT + 2)
+  // the workgroup's matrices: tile-packed lower triangles, accumulator-native tiles, in an L2-resident HBM scratch
   double* sc = g.scratch + (size_t)blockIdx.x * g.scratch_stride;
   double* Lb = sc;                              // K0 + J I -> L ; later C^-1, W
-  double* Cb = Lb + (size_t)NTT * TS;           // Lam -> C ; later Phi
+  double* Cb = Lb + (size_t)NTT * TS;           // Lam -> C ; later Phi ; in the prediction the bordered covariance and its factor
   double* Wb = Cb + (size_t)NTT * TS;           // L^-1
-  double* Gb = Wb + (size_t)NTT * TS;           // G = L^T D L ; in the prediction the bordered covariance and its factor
+  double* Gb = Wb + (size_t)NTT * TS;           // G = L^T D L ; in the prediction (with LamB behind it) E = A^T S, NT x NT tiles
   double* LamB = Gb + (size_t)NTT * TS;         // Lam (the natural parameter that persists over the iterations)
   double* Sb = LamB + (size_t)NTT * TS;         // S = C^-T C^-1
-  double* DLi = Sb + (size_t)NTT * TS;          // inverted diagonal tiles of L (of chol(cov) at the end)
-  double* DCi = DLi + (size_t)NT * TS;          // inverted diagonal tiles of C
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  Lane o;
-  lane_init(o, lane);
+  // (the wave index is made visibly wave-uniform: everything derived from it - tile indices, slot addresses - stays scalar)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Ctx c;
+  c.NT = NT; c.NTT = NTT; c.wave = wave; c.lane = lane; c.tid = tid; c.SA = SA;
+  lane_init(c.o, lane);
+  const Lane& o = c.o;
   const int N = g.N, R = g.R;
   const double J = g.jitter;
+
+  // the "cross" of k in a symmetric triangle: slot0 + i = tile (i, k) for i >= k, tile (k, i) for i < k (the user picks
+  // the orientation: S_ik = the slot as it lies for i >= k, its transpose for i < k)
+  auto stage_cross = [&](const double* Sym, int k, int slot0) {
+#pragma unroll 1
+    for (int i = wave; i < NT; i += NW)
+      st_tile(c.slot(slot0 + i), o, ldn(Sym + (size_t)(i >= k ? lt(i, k) : lt(k, i)) * TS, lane));
+  };
 
 #pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -205,8 +347,8 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         v4d id;
 #pragma unroll
         for (int r = 0; r < 4; ++r) id[r] = (i == j && o.kq[r] == o.lr) ? 1.0 : 0.0;
-        st_tile(LamB + (size_t)p * TS, o, id);           // Lam = I: q_sqrt = I
-        st_tile(Sb + (size_t)p * TS, o, id);             // S = I until the first natural-gradient step (n_iters = 0)
+        stn(LamB + (size_t)p * TS, lane, id);            // Lam = I: q_sqrt = I
+        stn(Sb + (size_t)p * TS, lane, id);              // S = I until the first natural-gradient step (n_iters = 0)
         unpack_step(i, j, NW);
       }
     }
@@ -238,40 +380,64 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
           kt[r] = K;
         }
-        st_tile(Lb + (size_t)p * TS, o, kt);
+        stn(Lb + (size_t)p * TS, lane, kt);
         unpack_step(i, j, NW);
       }
       GSYNC();
     };
-    // -ELBO sample (models.py:211-215) at the hypers whose factor L is in Lb, with the (m, S) of the last natural-gradient
-    // step (S in Sb, log det C in misc[11]) - smalln::neg_elbo with run-time tile counts
-    auto neg_elbo = [&](int slot) {
+    // out <- L x + beta y, L a scratch triangle: one staged pass over its block columns
+    auto lower_matvec = [&](const double* Lmat, const double* x, double beta, double* out) {
+      double part[2] = {0.0, 0.0};
 #pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mvr_lower(Lb, mv, i, o);
-        if (o.lk == 0) av[16 * i + o.lr] = s - yv[16 * i + o.lr];
-        double fr[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = 0; k < NT; ++k) {
 #pragma unroll 1
-        for (int j = 0; j <= i; ++j) {
-          v4d acc = {0, 0, 0, 0};
-          acc = acc_run(acc, 0, i + 1, [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; },
-                        [&](int k, int q) { return k >= j ? Sb[lt(k, j) * TS + o.cr[q]] : Sb[lt(j, k) * TS + o.rc[q]]; });
-          const v4d lt_ = ld_tile(Lb + lt(i, j) * TS, o);
+        for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lmat + lt(i, k) * TS, lane));
+        GSYNC();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) fr[r] = fma(acc[r], lt_[r], fr[r]);
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + u * NW;
+          if (i < NT && i >= k) part[u] += tile_mv(c.slot(i), false, x + 16 * k, o);
         }
+        GSYNC();
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double v = fr[r];
-          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-          if (o.lr == 0) wv[16 * i + o.kq[r]] = v;
-        }
+      for (int u = 0; u < 2; ++u) {
+        const int i = wave + u * NW;
+        if (i < NT && o.lk == 0) out[16 * i + o.lr] = part[u] + beta * yv[16 * i + o.lr];
       }
       GSYNC();
+    };
+    // -ELBO sample (models.py:211-215) at the hypers whose factor L is in Lb, with the (m, S) of the last natural-gradient
+    // step (S in Sb, log det C in misc[11]):
+    //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + (|m|^2 - N + 2 log det C + tr S) / 2
+    // (L S L^T)_tt = sum_j (L S)_tj L_tj over the lower tiles of L S (a staged lower x symmetric product); uses av and wv
+    auto neg_elbo = [&](int slot) {
+      lower_matvec(Lb, mv, -1.0, av);                                      // av = L m - y
+      for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
+      GSYNC();
+      staged_product(c, NTT, false, 0, NT,
+        [&](int k) {
+#pragma unroll 1
+          for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lb + lt(i, k) * TS, lane));
+          stage_cross(Sb, k, NT);
+        },
+        [&](int k, int i, int j, v4d acc) {
+          if (k > i) return acc;
+          return mma_rt(acc, c.slot(i), false, c.slot(NT + j), j > k, o);   // L_ik S_kj ; S_kj = slot j as it lies for j <= k... see stage_cross
+        },
+        [&](int, int i, int j, v4d acc) {
+          const v4d lt_ = ldn(Lb + lt(i, j) * TS, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double v = acc[r] * lt_[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (o.lr == 0) atomicAdd(&wv[16 * i + o.kq[r]], v);
+          }
+        });
       double part = 0.0;
       for (int t = tid; t < N; t += NTH) {
         const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
-        const double stt = Sb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)];
+        const double stt = Sb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)];
         part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
       }
       part = wave_sum(part);
@@ -291,31 +457,17 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       refresh_hypers();
       kmat();                                                              // K0 + J I at the current hypers  (models.py:209)
       MSTAMP(1);
-      // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L = sum_k (D^1/2 L)_k*^T (D^1/2 L)_k* is accumulated block row by
-      // block row behind the factorisation, every tile of Gb by the wave that owns it (waves 1..7)
-      auto g_rows = [&](int k) {
-        int i = 0, j = 0;
-        unpack_step(i, j, wave - 1);
-#pragma unroll 1
-        for (int p = wave - 1; p < NTT; p += NW - 1) {
-          if (i > k) break;                                                // packed order: every later tile has i > k too
-          const double* ta = Lb + lt(k, i) * TS;
-          const double* tb = Lb + lt(k, j) * TS;
-          double* gt = Gb + (size_t)p * TS;
-          v4d acc = {0, 0, 0, 0};
-          if (k > i) acc = ld_tile(gt, o);                                 // first touched by block row k == i
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const double scl = rs[16 * k + o.kq[q]];
-            acc = MFMA(ta[o.cr[q]] * scl, tb[o.cr[q]] * scl, acc);
-          }
-          st_tile(gt, o, acc);
-          unpack_step(i, j, NW - 1);
-        }
-      };
-      bad = potrf_tiles<true>(NT, Lb, DLi, Wb, o, wave, lane, bad, g_rows);
+      // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L and L^T (y / nu) accumulate block row by block row behind it
+      for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
       GSYNC();
-      if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
+      bad = potrf_v2<true, 1>(c, Lb, Wb, Gb, rs, yd, wv, bad);
+      if (g.loss && it > 0 && (it - 1) % 25 == 0) {                         // after the Adam step = at these hypers
+        for (int t = tid; t < NP; t += NTH) uv[t] = wv[t];                  // (the sample uses wv as scratch: keep L^T (y / nu) aside)
+        GSYNC();
+        neg_elbo((it - 1) / 25);
+        for (int t = tid; t < NP; t += NTH) wv[t] = uv[t];
+        GSYNC();
+      }
       MSTAMP(2);
       // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G) -> LamB and Cb; theta1 <- (1-g) theta1 + g L^T (y / nu)
       {
@@ -323,47 +475,25 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         unpack_step(i, j, wave);
 #pragma unroll 1
         for (int p = wave; p < NTT; p += NW) {
-          v4d lam = ld_tile(LamB + (size_t)p * TS, o);
-          const v4d gt = ld_tile(Gb + (size_t)p * TS, o);
+          v4d lam = ldn(LamB + (size_t)p * TS, lane);
+          const v4d gt = ldn(Gb + (size_t)p * TS, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             lam[r] = (1.0 - g.gamma) * lam[r] + g.gamma * (gt[r] + ((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0));
-          st_tile(LamB + (size_t)p * TS, o, lam);
-          st_tile(Cb + (size_t)p * TS, o, lam);
+          stn(LamB + (size_t)p * TS, lane, lam);
+          stn(Cb + (size_t)p * TS, lane, lam);
           unpack_step(i, j, NW);
         }
       }
-#pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mvr_lower_t(Lb, yd, i, NT, o);
-        if (o.lk == 0) {
-          th[16 * i + o.lr] = (1.0 - g.gamma) * th[16 * i + o.lr] + g.gamma * s;
-          wv[16 * i + o.lr] = s;               // L^T (y / nu): u = G m - L^T (y / nu) needs it, and L dies here
-        }
-      }
+      for (int t = tid; t < NP; t += NTH) th[t] = (1.0 - g.gamma) * th[t] + g.gamma * wv[t];
       GSYNC();
       MSTAMP(3);
-      // C = chol(Lam) in Cb, C^-1 in Lb (L is dead); S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated into Sb behind it
-      auto s_rows = [&](int k) {
-        int i = 0, j = 0;
-        unpack_step(i, j, wave - 1);
-#pragma unroll 1
-        for (int p = wave - 1; p < NTT; p += NW - 1) {
-          if (i > k) break;
-          double* stl = Sb + (size_t)p * TS;
-          v4d acc = {0, 0, 0, 0};
-          if (k > i) acc = ld_tile(stl, o);
-          acc = mma<true, false>(acc, Lb + lt(k, i) * TS, Lb + lt(k, j) * TS, o);
-          st_tile(stl, o, acc);
-          unpack_step(i, j, NW - 1);
-        }
-      };
-      bad = potrf_tiles<true>(NT, Cb, DCi, Lb, o, wave, lane, bad, s_rows);
-      GSYNC();
+      // C = chol(Lam) in Cb, C^-1 in Lb (L is dead); S = C^-T C^-1 accumulates into Sb behind it
+      bad = potrf_v2<true, 2>(c, Cb, Lb, Sb, rs, yd, wv, bad);
       MSTAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
         s = wave_sum(s);
         if (lane == 0) misc[32 + wave] = s;
         GSYNC();
@@ -374,82 +504,133 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         }
         GSYNC();
       }
-      // ---- m = S theta1 ; u = L^T D (L m - y) = G m - L^T (y / nu)
-#pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mvr_sym(Sb, th, i, NT, o);
-        if (o.lk == 0) mv[16 * i + o.lr] = s;
-      }
-      GSYNC();
-#pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mvr_sym(Gb, mv, i, NT, o);
-        if (o.lk == 0) uv[16 * i + o.lr] = s - wv[16 * i + o.lr];
-      }
-      GSYNC();
-      MSTAMP(5);
-      // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal -> Cb (C is dead)
+      // ---- m = S theta1: one staged pass over the crosses of S
       {
-        int i = 0, j = 0;
-        unpack_step(i, j, wave);
+        double part[2] = {0.0, 0.0};
 #pragma unroll 1
-        for (int p = wave; p < NTT; p += NW) {
-          v4d acc = {0, 0, 0, 0};
-          acc = acc_run(acc, 0, NT,
-                        [&](int k, int q) { return k <= i ? Gb[lt(i, k) * TS + o.rc[q]] : Gb[lt(k, i) * TS + o.cr[q]]; },
-                        [&](int k, int q) { return k >= j ? Sb[lt(k, j) * TS + o.cr[q]] : Sb[lt(j, k) * TS + o.rc[q]]; });
+        for (int k = 0; k < NT; ++k) {
+          stage_cross(Sb, k, 0);
+          GSYNC();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = o.kq[r];
-            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], acc[r]);
-            if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
-            acc[r] = v;
+          for (int u = 0; u < 2; ++u) {
+            const int i = wave + u * NW;
+            if (i < NT) part[u] += tile_mv(c.slot(i), i < k, th + 16 * k, o);   // S_ik = tile (i, k), or tile (k, i)^T above the diagonal
           }
-          st_tile(Cb + (size_t)p * TS, o, acc);
-          unpack_step(i, j, NW);
+          GSYNC();
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + u * NW;
+          if (i < NT && o.lk == 0) mv[16 * i + o.lr] = part[u];
+        }
+        GSYNC();
       }
-      GSYNC();
-      MSTAMP(6);
-      // ---- W = Phi L^-1 (lower; Phi in Cb, L^-1 in Wb) -> Lb (C^-1 is dead)
+      MSTAMP(5);
+      // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal -> Cb (C is dead).  u = L^T D (L m - y) = G m - L^T (y / nu) comes
+      // out of the same pass (the crosses of G are in LDS anyway) and, like m, enters Phi only in the epilogue.
       {
-        int i = 0, j = 0;
-        unpack_step(i, j, wave);
+        double gm[2] = {0.0, 0.0};
 #pragma unroll 1
-        for (int p = wave; p < NTT; p += NW) {
-          v4d acc = {0, 0, 0, 0};
-          acc = acc_run(acc, j, i + 1, [&](int k, int q) { return Cb[lt(i, k) * TS + o.rc[q]]; },
-                        [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
-          st_tile(Lb + (size_t)p * TS, o, acc);
-          unpack_step(i, j, NW);
+        for (int base = 0; base < NTT; base += PASS_TILES) {
+          v4d acc[TPW];
+          int ti[TPW], tj[TPW];
+#pragma unroll
+          for (int s = 0; s < TPW; ++s) {
+            acc[s] = v4d{0, 0, 0, 0};
+            const int p = base + wave + s * NW;
+            int i = 0, j = 0;
+            if (p < NTT) unpack_step(i, j, p);
+            ti[s] = p < NTT ? i : -1;
+            tj[s] = j;
+          }
+#pragma unroll 1
+          for (int k = 0; k < NT; ++k) {
+            stage_cross(Gb, k, 0);
+            stage_cross(Sb, k, NT);
+            GSYNC();
+#pragma unroll
+            for (int s = 0; s < TPW; ++s)
+              if (ti[s] >= 0)                                              // G_ik S_kj
+                acc[s] = mma_rt(acc[s], c.slot(ti[s]), ti[s] < k, c.slot(NT + tj[s]), tj[s] > k, o);
+            if (base == 0) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int i = wave + u * NW;
+                if (i < NT) gm[u] += tile_mv(c.slot(i), i < k, mv + 16 * k, o);
+              }
+            }
+            GSYNC();
+          }
+          if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = wave + u * NW;
+              if (i < NT && o.lk == 0) uv[16 * i + o.lr] = gm[u] - wv[16 * i + o.lr];
+            }
+            GSYNC();
+          }
+#pragma unroll
+          for (int s = 0; s < TPW; ++s)
+            if (ti[s] >= 0) {
+              const int i = ti[s], j = tj[s];
+              v4d a = acc[s];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int rl = o.kq[r];
+                double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], a[r]);
+                if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
+                a[r] = v;
+              }
+              stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, a);
+            }
         }
+        GSYNC();
       }
-      GSYNC();
+      MSTAMP(6);
+      // ---- W = Phi L^-1 (lower; Phi in Cb, L^-1 in Wb) -> Lb (C^-1 is dead): W_ij = sum_{k = j..i} Phi_ik Linv_kj
+      staged_product(c, NTT, false, 0, NT,
+        [&](int k) {
+#pragma unroll 1
+          for (int q = wave; q < NT + 1; q += NW) {
+            if (q < NT - k) st_tile(c.slot(k + q), o, ldn(Cb + lt(k + q, k) * TS, lane));               // Phi_ik, i >= k -> slot i
+            else st_tile(c.slot(NT + (q - (NT - k))), o, ldn(Wb + lt(k, q - (NT - k)) * TS, lane));      // Linv_kj, j <= k -> slot NT + j
+          }
+        },
+        [&](int k, int i, int j, v4d acc) {
+          if (k < j || k > i) return acc;
+          return mma_rt(acc, c.slot(i), false, c.slot(NT + j), false, o);
+        },
+        [&](int p, int, int, v4d acc) { stn(Lb + (size_t)p * TS, lane, acc); });
       MSTAMP(7);
-      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210)
+      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric: Kbar_ij and Kbar_ji^T
+      // = sum_k W_ki^T Linv_kj are accumulated together and the kernel function is evaluated once per unordered pair
       {
         const double var = misc[8], ls = misc[9], inv_ls2 = misc[10];
         double gv = 0.0, gl = 0.0;
-        int i = 0, j = 0;
-        unpack_step(i, j, wave);
+        staged_product(c, NTT, false, 0, NT,
+          [&](int k) {
 #pragma unroll 1
-        for (int p = wave; p < NTT; p += NW) {
-          v4d acc = {0, 0, 0, 0};
-          acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                        [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
-          if (i != j)
-            acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
-                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
-          const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+            for (int q = wave; q < 2 * (k + 1); q += NW) {
+              if (q <= k) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));                          // Linv_kj -> slot j
+              else st_tile(c.slot(NT + q - (k + 1)), o, ldn(Lb + lt(k, q - (k + 1)) * TS, lane));        // W_kj -> slot NT + j
+            }
+          },
+          [&](int k, int i, int j, v4d acc) {
+            if (k < i) return acc;
+            acc = mma_rt(acc, c.slot(i), true, c.slot(NT + j), false, o);                                // Linv_ki^T W_kj
+            if (i != j) acc = mma_rt(acc, c.slot(NT + i), true, c.slot(j), false, o);                    // W_ki^T Linv_kj
+            return acc;
+          },
+          [&](int, int i, int j, v4d acc) {
+            const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-            double k1, k2;
-            kern_unit<true>(g.kernel, r2[r], k1, k2);
-            if (row < N && col < N) { gv = fma(acc[r], k1, gv); gl = fma(acc[r], k2, gl); }
-          }
-          unpack_step(i, j, NW);
-        }
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+              double k1, k2;
+              kern_unit<true>(g.kernel, r2[r], k1, k2);
+              if (row < N && col < N) { gv = fma(acc[r], k1, gv); gl = fma(acc[r], k2, gl); }
+            }
+          });
         gv = wave_sum(gv);
         gl = wave_sum(gl);
         if (lane == 0) { misc[16 + wave] = gv; misc[24 + wave] = gl; }
@@ -479,105 +660,147 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     MSTAMP(9);
     refresh_hypers();
     kmat();
-    bad = potrf_tiles<true>(NT, Lb, DLi, Wb, o, wave, lane, bad, NoExtra());         // Lb = L, Wb = L^-1, Sb = S
-    GSYNC();
+    bad = potrf_v2<true, 0>(c, Lb, Wb, Gb, rs, yd, wv, bad);                 // Lb = L, Wb = L^-1, Sb = S
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     MSTAMP(10);
-    // mu = A^T m with A^T = K0 L^-T = L - J L^-T
+    // A^T = K0 L^-T = L - J L^-T.  Its block column k as NT explicit LDS tiles (slot0 + i = A^T(i, k)):
+    // L_ik below the diagonal, -J Linv_ki^T above it, L_kk - J Linv_kk^T on it
+    auto stage_at_col = [&](int k, int slot0) {
 #pragma unroll 1
-    for (int i = wave; i < NT; i += NW) {
-      const double s1 = mvr_lower(Lb, mv, i, o);
-      const double s2 = mvr_lower_t(Wb, mv, i, NT, o);
-      if (o.lk == 0) av[16 * i + o.lr] = s1 - J * s2;                       // av = mu (padded part 0)
-    }
-    // cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T S) A, one tile row at a time; E_i* = A^T_i* S is staged in LDS (ping-pong), so
-    // that tile row i of cov and the staging of row i + 1 share a phase.  The finished tiles go, bordered by the rows
-    // (1^T, mu^T) in the padding, straight into Gb (G is dead) for the factorisation that follows.
-    auto at_a = [&](int i, int k, int q) -> double {
-      const bool low = k <= i;
-      const double* t1 = low ? Lb + lt(i, k) * TS : Wb + lt(k, i) * TS;
-      const double v1 = t1[low ? o.rc[q] : o.cr[q]];
-      const double v2 = Wb[lt(i, i) * TS + o.cr[q]];
-      return fma(k == i ? -J : 0.0, v2, (low ? 1.0 : -J) * v1);
-    };
-    auto stage_row = [&](int i, double* Eb) {
-#pragma unroll 1
-      for (int l = NW - 1 - wave; l < NT; l += NW) {
-        v4d acc = {0, 0, 0, 0};
-        acc = acc_run(acc, 0, NT, [&](int k, int q) { return at_a(i, k, q); },
-                      [&](int k, int q) { return k >= l ? Sb[lt(k, l) * TS + o.cr[q]] : Sb[lt(l, k) * TS + o.rc[q]]; });
-        st_tile(Eb + (size_t)l * TS, o, acc);
-      }
-    };
-    stage_row(0, E0);
-    GSYNC();
-#pragma unroll 1
-    for (int i = 0; i < NT; ++i) {
-      double* Eb = (i & 1) ? E1 : E0;
-#pragma unroll 1
-      for (int j = wave; j <= i; j += NW) {
-        v4d acc = {0, 0, 0, 0};
-        acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                      [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+      for (int i = wave; i < NT; i += NW) {
+        double* s = c.slot(slot0 + i);
+        if (i > k) st_tile(s, o, ldn(Lb + lt(i, k) * TS, lane));
+        else {
+          v4d x = ldn(Wb + lt(k, i) * TS, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = acc[r] * (-J * J);
-        acc = acc_run(acc, 0, NT, [&](int l, int q) { return Eb[(size_t)l * TS + o.rc[q]]; },
-                      [&](int l, int q) { return at_a(j, l, q); });
-        v4d t = acc;
+          for (int r = 0; r < 4; ++r) x[r] *= -J;
+          st_tile_t(s, o, x);
+          if (i == k) {                                                    // (+ L_kk: elementwise on the same LDS tile, same wave)
+            const v4d l = ldn(Lb + lt(k, k) * TS, lane);
+            LWAIT();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-          if (row == col) acc[r] = acc[r] + (1.0 / dv[row] + J);
-          t[r] = acc[r];
-          if (row < N && col < N) {
-            if (g.cov && (i != j || col <= row)) {
-              g.cov[((long)b * N + row) * N + col] = acc[r];
-              if (i != j) g.cov[((long)b * N + col) * N + row] = acc[r];
-            }
-            if (g.var && row == col) g.var[(long)b * N + row] = acc[r];
-          } else {
-            // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
-            double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
-            if (col < N && row == N) v = 1.0;
-            if (col < N && row == N + 1) v = av[col];
-            t[r] = v;
+            for (int r = 0; r < 4; ++r) s[o.cr[r]] += l[r];
           }
         }
-        st_tile(Gb + (size_t)lt(i, j) * TS, o, t);
       }
-      if (i + 1 < NT) stage_row(i + 1, (i & 1) ? E0 : E1);
+    };
+    // mu = A^T m
+    {
+      double part[2] = {0.0, 0.0};
+#pragma unroll 1
+      for (int k = 0; k < NT; ++k) {
+        stage_at_col(k, 0);
+        GSYNC();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + u * NW;
+          if (i < NT) part[u] += tile_mv(c.slot(i), false, mv + 16 * k, o);
+        }
+        GSYNC();
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = wave + u * NW;
+        if (i < NT && o.lk == 0) av[16 * i + o.lr] = part[u];              // av = mu (padded part 0)
+      }
       GSYNC();
+    }
+    // E = A^T S, all NT x NT tiles -> the square buffer at Gb (G and Lam are dead): E_il = sum_k A^T(i, k) S_kl
+    double* Eb = Gb;
+    staged_product(c, NT * NT, true, 0, NT,
+      [&](int k) { stage_at_col(k, 0); stage_cross(Sb, k, NT); },
+      [&](int k, int i, int l, v4d acc) { return mma_rt(acc, c.slot(i), false, c.slot(NT + l), l > k, o); },
+      [&](int p, int, int, v4d acc) { stn(Eb + (size_t)p * TS, lane, acc); });
+    // cov = diag(nu + J) - J^2 L^-T L^-1 + E A: lower tiles (i, j): -J^2 sum_{k >= i} Linv_ki^T Linv_kj, then sum_l E_il A^T(j, l)^T.
+    // The finished tiles go, bordered by the rows (1^T, mu^T) in the padding, into Cb for the factorisation that follows.
+#pragma unroll 1
+    for (int base = 0; base < NTT; base += PASS_TILES) {
+      v4d acc[TPW];
+      int ti[TPW], tj[TPW];
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) {
+        acc[s] = v4d{0, 0, 0, 0};
+        const int p = base + wave + s * NW;
+        int i = 0, j = 0;
+        if (p < NTT) unpack_step(i, j, p);
+        ti[s] = p < NTT ? i : -1;
+        tj[s] = j;
+      }
+#pragma unroll 1
+      for (int k = 0; k < NT; ++k) {                                       // block row k of L^-1 -> slots j <= k
+#pragma unroll 1
+        for (int q = wave; q <= k; q += NW) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));
+        GSYNC();
+#pragma unroll
+        for (int s = 0; s < TPW; ++s)
+          if (ti[s] >= 0 && k >= ti[s]) acc[s] = mma_rt(acc[s], c.slot(ti[s]), true, c.slot(tj[s]), false, o);
+        GSYNC();
+      }
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] *= -J * J;
+#pragma unroll 1
+      for (int l = 0; l < NT; ++l) {                                       // block column l of E (slots i) and of A^T (slots NT + j)
+#pragma unroll 1
+        for (int i = wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Eb + (size_t)(i * NT + l) * TS, lane));
+        stage_at_col(l, NT);
+        GSYNC();
+#pragma unroll
+        for (int s = 0; s < TPW; ++s)
+          if (ti[s] >= 0) acc[s] = mma_rt(acc[s], c.slot(ti[s]), false, c.slot(NT + tj[s]), true, o);
+        GSYNC();
+      }
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+        if (ti[s] >= 0) {
+          const int i = ti[s], j = tj[s];
+          v4d a = acc[s], t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+            if (row == col) a[r] = a[r] + (1.0 / dv[row] + J);
+            t[r] = a[r];
+            if (row < N && col < N) {
+              // (a diagonal tile is a full 16x16 accumulation: its lower half is exported and mirrored, so that cov is exactly symmetric)
+              if (g.cov && (i != j || col <= row)) {
+                g.cov[((long)b * N + row) * N + col] = a[r];
+                g.cov[((long)b * N + col) * N + row] = a[r];
+              }
+              if (g.var && row == col) g.var[(long)b * N + row] = a[r];
+            } else {
+              // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
+              double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
+              if (col < N && row == N) v = 1.0;
+              if (col < N && row == N + 1) v = av[col];
+              t[r] = v;
+            }
+          }
+          stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, t);
+        }
     }
     if (g.mu)
       for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = av[t];
-    if (g.cov) {      // exact symmetry inside the diagonal tiles: upper element = lower element
-      for (int e = tid; e < NT * 256; e += NTH) {
-        const int i = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-        const int row = 16 * i + rr, col = 16 * i + cc;
-        if (cc > rr && row < N && col < N) g.cov[((long)b * N + row) * N + col] = Gb[lt(i, i) * TS + swz(cc, rr)];
-      }
-      GSYNC();      // (the factorisation below overwrites the diagonal tiles)
-    }
+    GSYNC();
     MSTAMP(11);
     if (g.chol || g.logdet || g.basis) {
-      bad = potrf_tiles<false>(NT, Gb, DLi, (double*)nullptr, o, wave, lane, bad, NoExtra());   // Distribution.__post_init__ (data.py:38-39)
-      GSYNC();
+      bad = potrf_v2<false, 0>(c, Cb, (double*)nullptr, Gb, rs, yd, wv, bad);   // Distribution.__post_init__ (data.py:38-39)
       if (g.chol) {
         for (int e = tid; e < NT * NT * 256; e += NTH) {
           const int tt = e >> 8, i = tt / NT, j = tt - i * NT, rr = (e >> 4) & 15, cc = e & 15;
           const int row = 16 * i + rr, col = 16 * j + cc;
-          if (row < N && col < N) g.chol[((long)b * N + row) * N + col] = col <= row ? Gb[lt(i, j) * TS + swz(rr, cc)] : 0.0;
+          if (row < N && col < N) g.chol[((long)b * N + row) * N + col] = col <= row ? Cb[lt(i, j) * TS + nidx(rr, cc)] : 0.0;
         }
       }
       if (g.basis) {
         for (int e = tid; e < 2 * N; e += NTH) {
-          const int which = e / N, c = e - which * N, row = N + which;
-          g.basis[((long)b * 2 + which) * N + c] = Gb[lt(row >> 4, c >> 4) * TS + swz(row & 15, c & 15)];
+          const int which = e / N, cc = e - which * N, row = N + which;
+          g.basis[((long)b * 2 + which) * N + cc] = Cb[lt(row >> 4, cc >> 4) * TS + nidx(row & 15, cc & 15)];
         }
       }
       if (g.logdet) {
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Gb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
         s = wave_sum(s);
         if (lane == 0) misc[16 + wave] = s;
         GSYNC();
@@ -601,12 +824,12 @@ bool medium_fit_supported(int N, int R) { return N > smalln::SMALL_MAX_N && N <=
 
 size_t medium_scratch_doubles(int N) {
   const int NT = medium_tiles(N), NTT = NT * (NT + 1) / 2;
-  return ((size_t)6 * NTT + 2 * NT) * TS;
+  return (size_t)6 * NTT * TS;
 }
 
 static size_t medium_lds_bytes(int N) {
   const int NT = medium_tiles(N), NP = 16 * NT;
-  return ((size_t)NP + 64 + 9 * (size_t)NP + 2 * (size_t)NT * TS) * sizeof(double);
+  return ((size_t)NP + 64 + 9 * (size_t)NP + (2 * (size_t)NT + 2) * TS) * sizeof(double);
 }
 
 int medium_grid(int B, int N, int n_cus) {
