@@ -256,7 +256,8 @@ class Context:
         self._check(self.lib.bayens_set_groups(self.h, int(n)))
 
     def set_medium_min_batch(self, n):
-        """Batch size from which members with 94 < N <= 254 take the fused mid-size kernel (default 128; 1 = always)."""
+        """Batch size from which members with 94 < N <= 254 take the fused mid-size kernel (1 = always, huge = never,
+        0 = the default choice by size)."""
         self._check(self.lib.bayens_set_medium_min_batch(self.h, int(n)))
 
     def profile_enable(self, on=True):

@@ -97,7 +97,7 @@ struct bayens_ctx {
     return sscratch;
   }
   int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
-  int medium_min_batch = 128;      // batches of at least this many mid-size members take the fused kernel (medium.hip)
+  int medium_min_batch = 0;        // > 0: batches of at least this many mid-size members take the fused kernel (medium.hip); 0: by size
   double* mscratch = nullptr;      // tile scratch of the fused mid-size kernel (medium.hip), grown on demand
   size_t mscratch_cap = 0;
   double* medium_scratch(size_t count) {
@@ -454,7 +454,7 @@ int bayens_set_groups(bayens_ctx* c, int n_groups) {
 }
 
 int bayens_set_medium_min_batch(bayens_ctx* c, int min_batch) {
-  if (!c || min_batch < 1) return BAYENS_E_ARG;
+  if (!c || min_batch < 0) return BAYENS_E_ARG;
   c->medium_min_batch = min_batch;
   return 0;
 }
@@ -472,11 +472,13 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     const bool small = !no_small && smalln::small_fit_supported(N, R);
     // mid-size members (94 < N <= 254, the reference's N = 165 series): ONE kernel too, matrices in an L2-resident scratch
     // (medium.hip; BAYENS_NO_MEDIUM=1 forces the general path)
-    // Measured at N = 165 (profiles/r03_medium_kernel.txt): 441 us per optimiser iteration whatever the batch (one CU per
-    // member) against 356 (20 members) ... 724 (256 members) through the general path, which shares every launch between
-    // the members: the fused kernel takes over from medium_min_batch members on (default 128; bayens_set_medium_min_batch).
+    // Measured (profiles/r03_medium_kernel.txt, us per optimiser iteration): the fused kernel is flat in the batch - one CU per
+    // member: 124 at N = 100, 322 at N = 165, 858 at N = 250 up to 256 members - where the general path, which shares every
+    // launch between the members, goes 228 / 357 / 488 at 20 members and 717 at (N = 165, 256 members).  So: up to 12 tiles
+    // per side (N <= 190) the fused kernel always; above that from 128 members on (bayens_set_medium_min_batch overrides).
     static const bool no_medium = getenv("BAYENS_NO_MEDIUM") != nullptr;
-    const bool medium = !small && !no_medium && B >= c->medium_min_batch && mediumn::medium_fit_supported(N, R);
+    const int medium_from = c->medium_min_batch > 0 ? c->medium_min_batch : ((N + 2 + 15) / 16 <= 12 ? 1 : 128);
+    const bool medium = !small && !no_medium && B >= medium_from && mediumn::medium_fit_supported(N, R);
     const int Np = pad_to_leaf(N);
     if (!small && !medium) ensure_ws(c, B, Np);
     Stage st(c, loc);

@@ -134,14 +134,7 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
   GSYNC();
   auto extra = [&](int k) {                    // waves 1..7; block row k of the factor (MODE 1) / of its inverse (MODE 2) is in LDS
     if (MODE == 0) return;
-    int i = 0, j = 0;
-    unpack_step(i, j, wave - 1);
-#pragma unroll 1
-    for (int p = wave - 1; p < c.NTT; p += NW - 1) {
-      if (i > k) break;                        // packed order: every later tile has i > k too
-      double* gt = Gb + (size_t)p * TS;
-      v4d acc = {0, 0, 0, 0};
-      if (k > i) acc = ldn(gt, lane);          // first touched by block row k == i
+    auto gram = [&](v4d acc, int i, int j) {
       if (MODE == 1) {
         const double* ta = c.slot(NT + i);
         const double* tb = c.slot(NT + j);
@@ -150,10 +143,29 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
           const double scl = rs[16 * k + o.kq[q]];
           acc = MFMA(ta[o.cr[q]] * scl, tb[o.cr[q]] * scl, acc);
         }
-      } else {
-        acc = mma<true, false>(acc, c.slot(i), c.slot(j), o);
+        return acc;
       }
-      stn(gt, lane, acc);
+      return mma<true, false>(acc, c.slot(i), c.slot(j), o);
+    };
+    int i = 0, j = 0;
+    unpack_step(i, j, wave - 1);
+    const v4d zero = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int p = wave - 1; p < c.NTT; p += 2 * (NW - 1)) {     // two of this wave's tiles per trip, both requested up front
+      if (i > k) break;                        // packed order: every later tile has i > k too
+      int i1 = i, j1 = j;
+      unpack_step(i1, j1, NW - 1);
+      const bool two = p + (NW - 1) < c.NTT && i1 <= k;
+      double* g0 = Gb + (size_t)p * TS;
+      double* g1 = Gb + (size_t)(two ? p + (NW - 1) : p) * TS;
+      v4d a0 = ldn(g0, lane), a1 = ldn(g1, lane);
+      a0 = gram(k > i ? a0 : zero, i, j);      // first touched by block row k == i
+      stn(g0, lane, a0);
+      if (two) {
+        a1 = gram(k > i1 ? a1 : zero, i1, j1);
+        stn(g1, lane, a1);
+      }
+      i = i1; j = j1;
       unpack_step(i, j, NW - 1);
     }
     if (MODE == 1) {                           // wv_j += L_kj^T (y / nu)_k, j <= k: every j has one owner wave
@@ -214,29 +226,52 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
       LWAIT();
       stn(t, lane, ld_tile(Wk, o));
     } else {
-      int p = 0;
+      // Two tile updates at a time: both output tiles are requested before either product runs (the scratch is ~700 cycles
+      // away; one load -> product -> store chain per tile left the waves waiting: 1.5 k cycles per update, ~250 of them
+      // arithmetic).  Plain scalar bookkeeping on purpose - a descriptor queue cost more scalar registers than it saved.
+      int p = 0, have = 0, hi = 0, hj = 0;
+      auto trailing2 = [&](int i0, int j0, int i1, int j1, bool two) {         // A_ij -= L_ik L_jk^T
+        double* t0 = A + lt(i0, j0) * TS;
+        double* t1 = A + lt(i1, j1) * TS;
+        v4d a0 = ldn(t0, lane), a1 = ldn(t1, lane);
+        a0 = mma<false, true>(a0, c.slot(i0), c.slot(j0), o, -1);
+        stn(t0, lane, a0);
+        if (two) {
+          a1 = mma<false, true>(a1, c.slot(i1), c.slot(j1), o, -1);
+          stn(t1, lane, a1);
+        }
+      };
 #pragma unroll 1
       for (int i = k + 2; i < NT; ++i)
 #pragma unroll 1
         for (int j = k + 1; j <= i; ++j)
-          if (p++ % (NW - 1) == wave - 1) {               // A_ij -= L_ik L_jk^T
-            double* t = A + lt(i, j) * TS;
-            v4d acc = ldn(t, lane);
-            acc = mma<false, true>(acc, c.slot(i), c.slot(j), o, -1);
-            stn(t, lane, acc);
+          if (p++ % (NW - 1) == wave - 1) {
+            if (!have) { hi = i; hj = j; have = 1; }
+            else { trailing2(hi, hj, i, j, true); have = 0; }
           }
+      if (have) { trailing2(hi, hj, hi, hj, false); have = 0; }
       if (WITH_INV) {
+        auto inverse2 = [&](int j0, int i0, int j1, int i1, bool two) {        // T_ji -= L_jk X_ki   (first touched at k == i)
+          double* t0 = Xb + lt(j0, i0) * TS;
+          double* t1 = Xb + lt(j1, i1) * TS;
+          v4d a0 = ldn(t0, lane), a1 = ldn(t1, lane);
+          const v4d zero = {0, 0, 0, 0};
+          a0 = mma<false, false>(k > i0 ? a0 : zero, c.slot(j0), c.slot(i0), o, -1);
+          stn(t0, lane, a0);
+          if (two) {
+            a1 = mma<false, false>(k > i1 ? a1 : zero, c.slot(j1), c.slot(i1), o, -1);
+            stn(t1, lane, a1);
+          }
+        };
 #pragma unroll 1
         for (int j = k + 1; j < NT; ++j)
 #pragma unroll 1
           for (int i = 0; i <= k; ++i)
-            if (p++ % (NW - 1) == wave - 1) {             // T_ji -= L_jk X_ki   (first touched at k == i)
-              double* t = Xb + lt(j, i) * TS;
-              v4d acc = {0, 0, 0, 0};
-              if (k > i) acc = ldn(t, lane);
-              acc = mma<false, false>(acc, c.slot(j), c.slot(i), o, -1);
-              stn(t, lane, acc);
+            if (p++ % (NW - 1) == wave - 1) {
+              if (!have) { hi = i; hj = j; have = 1; }
+              else { inverse2(hj, hi, j, i, true); have = 0; }
             }
+        if (have) { inverse2(hj, hi, hj, hi, false); have = 0; }
       }
       extra(k);
     }
@@ -317,10 +352,16 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 
   // the "cross" of k in a symmetric triangle: slot0 + i = tile (i, k) for i >= k, tile (k, i) for i < k (the user picks
   // the orientation: S_ik = the slot as it lies for i >= k, its transpose for i < k)
+  // (a wave stages at most two tiles of a cross, NT <= 16: both are requested before either is written to LDS - a scratch
+  //  access is ~1.5 k cycles away and the staging loops used to pay that once per tile)
   auto stage_cross = [&](const double* Sym, int k, int slot0) {
-#pragma unroll 1
-    for (int i = wave; i < NT; i += NW)
-      st_tile(c.slot(slot0 + i), o, ldn(Sym + (size_t)(i >= k ? lt(i, k) : lt(k, i)) * TS, lane));
+    const int i0 = wave, i1 = wave + NW;
+    const bool h0 = i0 < NT, h1 = i1 < NT;
+    const int c0 = h0 ? i0 : 0, c1 = h1 ? i1 : c0;
+    const v4d a0 = ldn(Sym + (size_t)(c0 >= k ? lt(c0, k) : lt(k, c0)) * TS, lane);
+    const v4d a1 = ldn(Sym + (size_t)(c1 >= k ? lt(c1, k) : lt(k, c1)) * TS, lane);
+    if (h0) st_tile(c.slot(slot0 + i0), o, a0);
+    if (h1) st_tile(c.slot(slot0 + i1), o, a1);
   };
 
 #pragma unroll 1
@@ -425,15 +466,25 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           if (k > i) return acc;
           return mma_rt(acc, c.slot(i), false, c.slot(NT + j), j > k, o);   // L_ik S_kj ; S_kj = slot j as it lies for j <= k... see stage_cross
         },
-        [&](int, int i, int j, v4d acc) {
+        [&](int p, int i, int j, v4d acc) {
+          // row sums of (L S)_ij o L_ij, one 16-vector per tile, parked in Cb (dead here: Phi of the previous iteration) and
+          // added up below in a fixed order - no atomics, the sample is reproducible bit for bit
           const v4d lt_ = ldn(Lb + lt(i, j) * TS, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             double v = acc[r] * lt_[r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (o.lr == 0) atomicAdd(&wv[16 * i + o.kq[r]], v);
+            if (o.lr == 0) Cb[(size_t)p * 16 + o.kq[r]] = v;
           }
         });
+      GSYNC();
+      for (int t = tid; t < NP; t += NTH) {
+        const int i = t >> 4;
+        double f = 0.0;
+        for (int j = 0; j <= i; ++j) f += Cb[(size_t)lt(i, j) * 16 + (t & 15)];
+        wv[t] = f;
+      }
+      GSYNC();
       double part = 0.0;
       for (int t = tid; t < N; t += NTH) {
         const double nu = 1.0 / dv[t], a = av[t], m = mv[t];

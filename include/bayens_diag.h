@@ -52,8 +52,10 @@ int bayens_test_trsm(bayens_ctx* ctx, int nb, int m, int n, const double* L, dou
 
 /* Members with 94 < N <= 254 time points (the reference's N = 165 annual series) have two routes through
  * bayens_gp_fit_batch: the general path (batched launches shared by all members) and the fused mid-size kernel
- * (csrc/medium.hip: one workgroup per member, matrices in an L2-resident scratch), which wins once the batch is large.
- * This sets the batch size from which the fused kernel is used (default 128; 1 = always, for the parity tests). */
+ * (csrc/medium.hip: one workgroup per member, matrices in an L2-resident scratch).  By default the route is chosen by size
+ * (N <= 190: always the fused kernel; above: from 128 members on).  min_batch > 0 overrides: the fused kernel is used from
+ * min_batch members on (1 = always, a huge value = never - what the parity tests use to hold the two routes against each
+ * other); 0 restores the default. */
 int bayens_set_medium_min_batch(bayens_ctx* ctx, int min_batch);
 
 /* Diagnostic: the pack -> [ncclAllGather image] -> unpack index arithmetic of bayens_allgather_member_rows without a

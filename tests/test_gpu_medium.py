@@ -1,7 +1,7 @@
 """The fused mid-size fit kernel (csrc/medium.hip): members with 94 < N <= 254 time points - the reference's real workload,
 historical annual series N = 165 fitted with n_optim_nits = 2000-2500 (experiments/full_experiment_script.py:57,87-113) -
-one workgroup per member, matrices in an L2-resident scratch.  bayens_gp_fit_batch takes it for large batches (where it
-beats the general path); here it is forced for every batch size and held to the oracle, to the reference's own pickled
+one workgroup per member, matrices in an L2-resident scratch.  bayens_gp_fit_batch takes it by size (N <= 190 always, above
+that for large batches); here it is forced for every size and held to the oracle, to the reference's own pickled
 N = 165 posteriors, and to the general path."""
 import os
 
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def mctx(ctx):
     ctx.set_medium_min_batch(1)
     yield ctx
-    ctx.set_medium_min_batch(128)
+    ctx.set_medium_min_batch(0)
 
 
 @pytest.mark.parametrize("M,N,R,T,kernel", [
@@ -47,6 +47,9 @@ def test_medium_kernel_matches_the_oracle(mctx, M, N, R, T, kernel):
             import scipy.linalg as sla
             assert relerr(out["basis"][m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 10 * tight
             assert relerr(out["basis"][m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 10 * tight
+    again = mctx.gp_fit_batch(X, y, nu, T, kernel=kernel, want_loss=True)        # reproducible bit for bit, loss samples included
+    for key in ("mu", "cov", "chol", "logdet", "hyp", "basis") + (("loss",) if T > 0 else ()):
+        assert np.array_equal(out[key], again[key]), key
 
 
 @pytest.mark.parametrize("fname", [f for f in golden_files() if "hist" in f])
@@ -62,9 +65,9 @@ def test_medium_kernel_reproduces_the_references_pickled_n165_posterior(mctx, fn
 
 
 def test_medium_and_general_paths_agree_and_large_batches_take_the_fused_kernel(ctx):
-    """A batch of 130 members of N = 120 (more members than the default threshold of 128, and than half the CUs): the
-    default dispatch (fused kernel) against the general path (threshold raised), member by member; every member of the
-    batch against the oracle at the edges of the grid of workgroups."""
+    """A batch of 130 members of N = 120: the default dispatch (fused kernel) against the general path (forced), member by
+    member; members at the edges of the grid of workgroups against the oracle.  And N = 200 (13 tiles per side): general
+    path for a small batch by default, fused kernel when forced - both on the oracle."""
     M, N, R, T = 130, 120, 4, 2
     data, _ = go.synthetic_ensemble(M, N, R=R, seed=7)
     X, y, nu = member_inputs(data)
@@ -73,7 +76,7 @@ def test_medium_and_general_paths_agree_and_large_batches_take_the_fused_kernel(
     try:
         general = ctx.gp_fit_batch(X, y, nu, T)
     finally:
-        ctx.set_medium_min_batch(128)
+        ctx.set_medium_min_batch(0)
     for k in ("mu", "cov", "chol", "hyp", "basis"):
         assert relerr(fused[k], general[k]) < 1e-10, k
     assert not np.array_equal(fused["cov"], general["cov"])          # two different programs (else the dispatch did not switch)
@@ -81,6 +84,15 @@ def test_medium_and_general_paths_agree_and_large_batches_take_the_fused_kernel(
         for m in (0, 1, 64, 128, 129):
             mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T)
             assert relerr(fused["mu"][m], mo) < 1e-10 and relerr(fused["cov"][m], co) < 1e-10 and relerr(fused["hyp"][m], ho) < 1e-10
+    data, _ = go.synthetic_ensemble(2, 200, R=4, seed=8)
+    X, y, nu = member_inputs(data)
+    by_default = ctx.gp_fit_batch(X, y, nu, T)
+    ctx.set_medium_min_batch(1)
+    try:
+        forced = ctx.gp_fit_batch(X, y, nu, T)
+    finally:
+        ctx.set_medium_min_batch(0)
+    assert relerr(forced["cov"], by_default["cov"]) < 1e-10 and not np.array_equal(forced["cov"], by_default["cov"])
 
 
 def test_more_members_than_workgroups(mctx):

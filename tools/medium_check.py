@@ -27,7 +27,7 @@ with threadpool_limits(4):
             e = max(e, max(errs.values()))
         print(f"M={M} N={N} R={R} T={T} k={k}: worst {e:.2e} {errs} sym {np.array_equal(out['cov'][0], out['cov'][0].T)} info {out['info'].max()}", flush=True)
 # timing at the reference's workload
-for (M, N, R, T) in [(20, 165, 9, 250), (20, 165, 9, 2500), (64, 165, 9, 250), (128, 165, 9, 250), (256, 165, 9, 250), (512, 165, 9, 250)]:
+for (M, N, R, T) in [(1, 165, 9, 250), (4, 165, 9, 250), (8, 165, 9, 250), (20, 165, 9, 250), (20, 165, 9, 2500), (64, 165, 9, 250), (128, 165, 9, 250), (256, 165, 9, 250), (512, 165, 9, 250), (20, 100, 9, 250), (20, 250, 9, 250)]:
     data, _ = go.synthetic_ensemble(M, N, R=R, seed=1)
     X = np.ascontiguousarray(np.swapaxes(data, 1, 2)); y = data.mean(axis=1); nu = data.var(axis=1)
     dX, dy, dnu = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu)

@@ -28,3 +28,4 @@ d = np.diff(st[:13])
 for k, nme in enumerate(names):
     print(f"  {nme:24s} {d[k]:9d}")
 print("iteration total", st[8] - st[0], "predict total", st[12] - st[9])
+
