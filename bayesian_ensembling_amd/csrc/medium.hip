@@ -53,6 +53,12 @@ __device__ __forceinline__ void unpack_step(int& i, int& j, int step) {      // 
 __device__ __forceinline__ int nidx(int row, int col) { return ((col + 16 * (row & 3)) << 2) + (row >> 2); }
 __device__ __forceinline__ v4d ldn(const double* t, int lane) { return reinterpret_cast<const v4d*>(t)[lane]; }
 __device__ __forceinline__ void stn(double* t, int lane, v4d a) { reinterpret_cast<v4d*>(t)[lane] = a; }
+// the same through pointers that carry the GLOBAL address space in their type: a pointer that crosses a real function call
+// is a generic one, its accesses FLAT ones (which also count as LDS operations: every operand read would wait for them)
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) v4d gv4d;
+__device__ __forceinline__ v4d ldg(const gdouble* t, int lane) { return reinterpret_cast<const gv4d*>(t)[lane]; }
+__device__ __forceinline__ void stg(gdouble* t, int lane, v4d a) { reinterpret_cast<gv4d*>(t)[lane] = a; }
 // LDS tile <- accumulator registers, transposed (element (row, col) of the registers lands at (col, row))
 __device__ __forceinline__ void st_tile_t(double* t, const Lane& o, v4d a) {
 #pragma unroll
@@ -98,7 +104,7 @@ __device__ __forceinline__ double tile_mv(const double* T, bool ta, const double
 
 // hides a wave-uniform value from loop-invariant code motion: without it the compiler hoists the LDS addresses of every
 // (accumulator tile, operand, orientation) combination out of the k loops - ~150 VGPRs of addresses, i.e. hundreds of spills
-__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ int opaque(int x) { x = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); return x; }
 
 struct Ctx {            // what every phase needs
   int NT, NTT, wave, lane, tid;
@@ -117,27 +123,58 @@ struct Ctx {            // what every phase needs
 //                     tile, every output one coalesced read-modify-write of a scratch tile
 // MODE 0: nothing extra.  MODE 1 (the kernel matrix): G_ij += L_ki^T D_k L_kj into Gb and wv += L_k*^T (y / nu)_k.
 // MODE 2 (Lam): S_ij += X_ki^T X_kj into Gb (the caller passes Sb).
+// (NOT inlined: the fit kernel keeps dozens of pointers and sizes alive and the factorisation's own loop state on top of them
+//  overflowed the scalar register file - ~500 scalar spills, every tile address recomputed through v_readlane chains.  As a
+//  function of its own it sees only its arguments; LDS regions arrive as offsets and the scratch as an address-space-typed
+//  pointer, so no access degrades to a flat one.)
+struct PotrfArgs {
+  gdouble* sc;                 // the workgroup's scratch
+  long oA, oX, oG;             // offsets of the triangle, of its inverse (WITH_INV) and of the Gram triangle (MODE 1 / 2)
+  int NT, NTT;
+  int sa_off, rs_off, yd_off, wv_off;   // LDS offsets (doubles): staging tiles, 1 / sqrt(nu), y / nu, wv
+};
+// arguments of a real function arrive in vector registers: tell the compiler that these are wave-uniform
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long uni(long x) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)x), hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)x >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
 template <bool WITH_INV, int MODE>
-__device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, double* Gb, const double* rs, const double* yd, double* wv,
-                                        int bad) {
-  const int NT = c.NT, wave = c.wave, lane = c.lane;
-  const Lane& o = c.o;
-  double* Dk = c.slot(2 * NT);
-  double* Wk = c.slot(2 * NT + 1);
+__device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Lane o;
+  lane_init(o, lane);
+  PotrfArgs e;
+  e.sc = (gdouble*)uni((long)e_in.sc);
+  e.oA = uni(e_in.oA); e.oX = uni(e_in.oX); e.oG = uni(e_in.oG);
+  e.NT = uni(e_in.NT); e.NTT = uni(e_in.NTT);
+  e.sa_off = uni(e_in.sa_off); e.rs_off = uni(e_in.rs_off); e.yd_off = uni(e_in.yd_off); e.wv_off = uni(e_in.wv_off);
+  const int NT = e.NT;
+  double* lds = lds_base();
+  double* SA = lds + e.sa_off;
+  const double* rs = lds + e.rs_off;
+  const double* yd = lds + e.yd_off;
+  double* wv = lds + e.wv_off;
+  auto slot = [&](int sidx) { return SA + (size_t)opaque(sidx) * TS; };
+  gdouble* A = e.sc + e.oA;
+  gdouble* Xb = e.sc + e.oX;
+  gdouble* Gb = e.sc + e.oG;
+  double* Dk = slot(2 * NT);
+  double* Wk = slot(2 * NT + 1);
   if (wave == 0) {
-    st_tile(Wk, o, ldn(A, lane));
+    st_tile(Wk, o, ldg(A, lane));
     LWAIT();
     diag16(ld_tile_sym64(Wk, o), Wk, Dk, lane, 0, bad, o);
     LWAIT();
-    stn(A, lane, ld_tile(Wk, o));
+    stg(A, lane, ld_tile(Wk, o));
   }
   GSYNC();
   auto extra = [&](int k) {                    // waves 1..7; block row k of the factor (MODE 1) / of its inverse (MODE 2) is in LDS
     if (MODE == 0) return;
     auto gram = [&](v4d acc, int i, int j) {
       if (MODE == 1) {
-        const double* ta = c.slot(NT + i);
-        const double* tb = c.slot(NT + j);
+        const double* ta = slot(NT + i);
+        const double* tb = slot(NT + j);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const double scl = rs[16 * k + o.kq[q]];
@@ -145,25 +182,25 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
         }
         return acc;
       }
-      return mma<true, false>(acc, c.slot(i), c.slot(j), o);
+      return mma<true, false>(acc, slot(i), slot(j), o);
     };
     int i = 0, j = 0;
     unpack_step(i, j, wave - 1);
     const v4d zero = {0, 0, 0, 0};
 #pragma unroll 1
-    for (int p = wave - 1; p < c.NTT; p += 2 * (NW - 1)) {     // two of this wave's tiles per trip, both requested up front
+    for (int p = wave - 1; p < e.NTT; p += 2 * (NW - 1)) {     // two of this wave's tiles per trip, both requested up front
       if (i > k) break;                        // packed order: every later tile has i > k too
       int i1 = i, j1 = j;
       unpack_step(i1, j1, NW - 1);
-      const bool two = p + (NW - 1) < c.NTT && i1 <= k;
-      double* g0 = Gb + (size_t)p * TS;
-      double* g1 = Gb + (size_t)(two ? p + (NW - 1) : p) * TS;
-      v4d a0 = ldn(g0, lane), a1 = ldn(g1, lane);
+      const bool two = p + (NW - 1) < e.NTT && i1 <= k;
+      gdouble* g0 = Gb + (size_t)p * TS;
+      gdouble* g1 = Gb + (size_t)(two ? p + (NW - 1) : p) * TS;
+      v4d a0 = ldg(g0, lane), a1 = ldg(g1, lane);
       a0 = gram(k > i ? a0 : zero, i, j);      // first touched by block row k == i
-      stn(g0, lane, a0);
+      stg(g0, lane, a0);
       if (two) {
         a1 = gram(k > i1 ? a1 : zero, i1, j1);
-        stn(g1, lane, a1);
+        stg(g1, lane, a1);
       }
       i = i1; j = j1;
       unpack_step(i, j, NW - 1);
@@ -171,7 +208,7 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
     if (MODE == 1) {                           // wv_j += L_kj^T (y / nu)_k, j <= k: every j has one owner wave
 #pragma unroll 1
       for (int jj = wave - 1; jj <= k; jj += NW - 1) {
-        const double s = tile_mv(c.slot(NT + jj), true, yd + 16 * k, o);
+        const double s = tile_mv(slot(NT + jj), true, yd + 16 * k, o);
         if (o.lk == 0) wv[16 * jj + o.lr] += s;
       }
     }
@@ -184,31 +221,31 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
     for (int q = wave; q < below + n_inv + n_row; q += NW) {
       if (q < below) {                                    // panel: L_ik = A_ik inv_kk^T
         const int i = k + 1 + q;
-        double* t = A + lt(i, k) * TS;
-        double* s = c.slot(i);
-        st_tile(s, o, ldn(t, lane));
+        gdouble* t = A + lt(i, k) * TS;
+        double* s = slot(i);
+        st_tile(s, o, ldg(t, lane));
         LWAIT();
         v4d acc = {0, 0, 0, 0};
         acc = mma<false, true>(acc, s, Dk, o);
-        stn(t, lane, acc);
+        stg(t, lane, acc);
         LWAIT();                                          // (this wave's operand reads of the slot are done)
         st_tile(s, o, acc);
       } else if (q < below + n_inv) {                     // X_ki = inv_kk T_ki (T_ki is the B operand as it lies in the scratch)
         const int i = q - below;
-        double* t = Xb + lt(k, i) * TS;
+        gdouble* t = Xb + lt(k, i) * TS;
         v4d acc = {0, 0, 0, 0};
-        acc = mma_nb(acc, Dk, ldn(t, lane), o);
-        stn(t, lane, acc);
-        st_tile(c.slot(i), o, acc);
+        acc = mma_nb(acc, Dk, ldg(t, lane), o);
+        stg(t, lane, acc);
+        st_tile(slot(i), o, acc);
       } else {                                            // block row k of the finished factor -> slots NT + i
         const int i = q - below - n_inv;
-        st_tile(c.slot(NT + i), o, ldn(A + lt(k, i) * TS, lane));
+        st_tile(slot(NT + i), o, ldg(A + lt(k, i) * TS, lane));
       }
     }
     if (WITH_INV && wave == NW - 1) {                     // X_kk = inv_kk
       const v4d d = ld_tile(Dk, o);
-      stn(Xb + lt(k, k) * TS, lane, d);
-      st_tile(c.slot(k), o, d);
+      stg(Xb + lt(k, k) * TS, lane, d);
+      st_tile(slot(k), o, d);
     }
     GSYNC();
     if (below == 0) {
@@ -216,29 +253,27 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
       break;
     }
     if (wave == 0) {                                      // look-ahead: next diagonal tile, then its factorisation
-      double* t = A + lt(k + 1, k + 1) * TS;
-      st_tile(Wk, o, ldn(t, lane));
+      gdouble* t = A + lt(k + 1, k + 1) * TS;
+      st_tile(Wk, o, ldg(t, lane));
       LWAIT();
       v4d acc = ld_tile_sym(Wk, o);
-      acc = mma<false, true>(acc, c.slot(k + 1), c.slot(k + 1), o, -1);
+      acc = mma<false, true>(acc, slot(k + 1), slot(k + 1), o, -1);
       LWAIT();
       diag16(acc, Wk, Dk, lane, 16 * (k + 1), bad, o);   // (nobody reads inv_kk in this phase: inv_k+1,k+1 takes its slot)
       LWAIT();
-      stn(t, lane, ld_tile(Wk, o));
+      stg(t, lane, ld_tile(Wk, o));
     } else {
-      // Two tile updates at a time: both output tiles are requested before either product runs (the scratch is ~700 cycles
-      // away; one load -> product -> store chain per tile left the waves waiting: 1.5 k cycles per update, ~250 of them
-      // arithmetic).  Plain scalar bookkeeping on purpose - a descriptor queue cost more scalar registers than it saved.
+      // Two tile updates at a time: both output tiles are requested before either product runs.
       int p = 0, have = 0, hi = 0, hj = 0;
       auto trailing2 = [&](int i0, int j0, int i1, int j1, bool two) {         // A_ij -= L_ik L_jk^T
-        double* t0 = A + lt(i0, j0) * TS;
-        double* t1 = A + lt(i1, j1) * TS;
-        v4d a0 = ldn(t0, lane), a1 = ldn(t1, lane);
-        a0 = mma<false, true>(a0, c.slot(i0), c.slot(j0), o, -1);
-        stn(t0, lane, a0);
+        gdouble* t0 = A + lt(i0, j0) * TS;
+        gdouble* t1 = A + lt(i1, j1) * TS;
+        v4d a0 = ldg(t0, lane), a1 = ldg(t1, lane);
+        a0 = mma<false, true>(a0, slot(i0), slot(j0), o, -1);
+        stg(t0, lane, a0);
         if (two) {
-          a1 = mma<false, true>(a1, c.slot(i1), c.slot(j1), o, -1);
-          stn(t1, lane, a1);
+          a1 = mma<false, true>(a1, slot(i1), slot(j1), o, -1);
+          stg(t1, lane, a1);
         }
       };
 #pragma unroll 1
@@ -252,15 +287,15 @@ __device__ __forceinline__ int potrf_v2(const Ctx& c, double* A, double* Xb, dou
       if (have) { trailing2(hi, hj, hi, hj, false); have = 0; }
       if (WITH_INV) {
         auto inverse2 = [&](int j0, int i0, int j1, int i1, bool two) {        // T_ji -= L_jk X_ki   (first touched at k == i)
-          double* t0 = Xb + lt(j0, i0) * TS;
-          double* t1 = Xb + lt(j1, i1) * TS;
-          v4d a0 = ldn(t0, lane), a1 = ldn(t1, lane);
+          gdouble* t0 = Xb + lt(j0, i0) * TS;
+          gdouble* t1 = Xb + lt(j1, i1) * TS;
+          v4d a0 = ldg(t0, lane), a1 = ldg(t1, lane);
           const v4d zero = {0, 0, 0, 0};
-          a0 = mma<false, false>(k > i0 ? a0 : zero, c.slot(j0), c.slot(i0), o, -1);
-          stn(t0, lane, a0);
+          a0 = mma<false, false>(k > i0 ? a0 : zero, slot(j0), slot(i0), o, -1);
+          stg(t0, lane, a0);
           if (two) {
-            a1 = mma<false, false>(k > i1 ? a1 : zero, c.slot(j1), c.slot(i1), o, -1);
-            stn(t1, lane, a1);
+            a1 = mma<false, false>(k > i1 ? a1 : zero, slot(j1), slot(i1), o, -1);
+            stg(t1, lane, a1);
           }
         };
 #pragma unroll 1
@@ -350,6 +385,12 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
   const int N = g.N, R = g.R;
   const double J = g.jitter;
 
+  auto pargs = [&](double* A_, double* X_, double* G_) {
+    PotrfArgs e;
+    e.sc = (gdouble*)sc; e.oA = A_ - sc; e.oX = X_ - sc; e.oG = G_ - sc; e.NT = NT; e.NTT = NTT;
+    e.sa_off = (int)(SA - lds); e.rs_off = (int)(rs - lds); e.yd_off = (int)(yd - lds); e.wv_off = (int)(wv - lds);
+    return e;
+  };
   // the "cross" of k in a symmetric triangle: slot0 + i = tile (i, k) for i >= k, tile (k, i) for i < k (the user picks
   // the orientation: S_ik = the slot as it lies for i >= k, its transpose for i < k)
   // (a wave stages at most two tiles of a cross, NT <= 16: both are requested before either is written to LDS - a scratch
@@ -511,7 +552,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L and L^T (y / nu) accumulate block row by block row behind it
       for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
       GSYNC();
-      bad = potrf_v2<true, 1>(c, Lb, Wb, Gb, rs, yd, wv, bad);
+      bad = potrf_v2<true, 1>(pargs(Lb, Wb, Gb), bad);
       if (g.loss && it > 0 && (it - 1) % 25 == 0) {                         // after the Adam step = at these hypers
         for (int t = tid; t < NP; t += NTH) uv[t] = wv[t];                  // (the sample uses wv as scratch: keep L^T (y / nu) aside)
         GSYNC();
@@ -540,7 +581,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       GSYNC();
       MSTAMP(3);
       // C = chol(Lam) in Cb, C^-1 in Lb (L is dead); S = C^-T C^-1 accumulates into Sb behind it
-      bad = potrf_v2<true, 2>(c, Cb, Lb, Sb, rs, yd, wv, bad);
+      bad = potrf_v2<true, 2>(pargs(Cb, Lb, Sb), bad);
       MSTAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
@@ -711,7 +752,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     MSTAMP(9);
     refresh_hypers();
     kmat();
-    bad = potrf_v2<true, 0>(c, Lb, Wb, Gb, rs, yd, wv, bad);                 // Lb = L, Wb = L^-1, Sb = S
+    bad = potrf_v2<true, 0>(pargs(Lb, Wb, Gb), bad);                            // Lb = L, Wb = L^-1, Sb = S
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     MSTAMP(10);
     // A^T = K0 L^-T = L - J L^-T.  Its block column k as NT explicit LDS tiles (slot0 + i = A^T(i, k)):
@@ -835,7 +876,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     GSYNC();
     MSTAMP(11);
     if (g.chol || g.logdet || g.basis) {
-      bad = potrf_v2<false, 0>(c, Cb, (double*)nullptr, Gb, rs, yd, wv, bad);   // Distribution.__post_init__ (data.py:38-39)
+      bad = potrf_v2<false, 0>(pargs(Cb, Cb, Gb), bad);                       // Distribution.__post_init__ (data.py:38-39)
       if (g.chol) {
         for (int e = tid; e < NT * NT * 256; e += NTH) {
           const int tt = e >> 8, i = tt / NT, j = tt - i * NT, rr = (e >> 4) & 15, cc = e & 15;
