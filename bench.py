@@ -300,21 +300,24 @@ class FieldWorkload:
         out_b = es * (N * N + N) if self.export == "full" else 8.0 * (4 * N + 3)
         gbs = self.B * (in_b + out_b) / (fit_ms * 1e-3) / 1e9
         tfl = self.B * fit_flops(N, R, self.T) / (fit_ms * 1e-3) / 1e12
+        peak_tfl = F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS
         return {"value": round(self.B * steps / elapsed, 1), "unit": "member-fits/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "fits_per_step": self.B, "export": self.export, "fit_kernel_ms": round(fit_ms, 3),
                 "weighted_posterior_latency_ms": round(wp_ms, 4), "barycentre_not_converged": int(bad),
-                "roofline": {"bound": "hbm", "kernel": ("bayens_f32" if self.f32 else "bayens") + "::smalln::small_fit_kernel<6>", "achieved": round(gbs, 2),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                             "algorithmic_bytes_per_fit": in_b + out_b, "launches_per_step": 1,
+                # primary roofline of config 5: the fp64 matrix pipes (SURVEY 8(d)'s HBM floor for this config was
+                # mis-scaled by 10^3 - 29.5 GB at 6.29 TB/s is 4.7 ms, not 4.7 s - so HBM does not bind; the HBM figure stays beside it)
+                "roofline": {"bound": "mfma", "kernel": ("bayens_f32" if self.f32 else "bayens") + "::smalln::small_fit_kernel<6>",
+                             "achieved": round(tfl, 3), "peak": peak_tfl, "unit": "TFLOP/s", "frac": round(tfl / peak_tfl, 4), "traffic": None,
+                             "algorithmic_flop_per_fit": fit_flops(N, R, self.T), "launches_per_step": 1,
                              "avg_launch_us": round(fit_ms * 1e3, 1),
-                             "note": "SURVEY 8(d) prices config 5 against HBM; with every matrix resident in LDS the kernel is "
-                                     "bound by the fp64 matrix / vector pipes and its serial 16x16 factorisations, not by "
-                                     "HBM - see roofline_mfma"},
-                "roofline_mfma": {"bound": "mfma", "achieved": round(tfl, 3),
-                                  "peak": F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tfl / (F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS), 4),
-                                  "algorithmic_flop_per_fit": fit_flops(N, R, self.T)}}
-
+                             "note": "one launch of the fused small-member kernel per step; achieved = algorithmic flop of the B fits / its "
+                                     "duration (HIP events on its stream).  SURVEY 8(d) priced config 5 against HBM with a floor that "
+                                     "was mis-scaled by 10^3: with every matrix resident in LDS the kernel moves 9.7 KB per fit and is "
+                                     "bound by the fp64 matrix / vector pipes and its serial 16x16 factorisations - see roofline_hbm"},
+                "roofline_hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_fit": in_b + out_b},
+                "roofline_mfma": {"bound": "mfma", "achieved": round(tfl, 3), "peak": peak_tfl, "unit": "TFLOP/s",
+                                  "frac": round(tfl / peak_tfl, 4), "algorithmic_flop_per_fit": fit_flops(N, R, self.T)}}
 
 def cpu_baseline_small(N, R, T, fits):
     from threadpoolctl import threadpool_info
@@ -411,6 +414,41 @@ def api_path_c5(ctx, M, n_lat, n_lon, N, R, T, reps=3):
                                 "field out; best of %d" % reps}
 
 
+def mid_size_line(ctx, M=20, N=165, R=9, T=2500):
+    """The reference's real workload (experiments/full_experiment_script.py:57,87-113; pre_fitting_cmip6models.py:76-77): a
+    collection of ~20 members, historical annual series N = 165, GPDTW1D fitted with n_optim_nits = 2000-2500.  One
+    bayens_gp_fit_batch call on resident buffers: the fused mid-size kernel (csrc/medium.hip) by default, the general path
+    (batched launches) beside it."""
+    from bayesian_ensembling_amd.synthetic import synthetic_ensemble
+    data, _ = synthetic_ensemble(M, N, R=R, R_obs=3, seed=0x165)
+    X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
+    dX, dy, dnu = ctx.to_device(X), ctx.to_device(data.mean(axis=1)), ctx.to_device(data.var(axis=1))
+    dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
+    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
+    fit = lambda t: ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, t, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
+    out = {}
+    try:
+        for key, min_batch in (("fused_kernel", 0), ("general_path", 10 ** 6)):
+            ctx.set_medium_min_batch(min_batch)
+            fit(2)
+            ctx.timer_start(); fit(T); ms = ctx.timer_stop()
+            tfl = M * fit_flops(N, R, T) / (ms * 1e-3) / 1e12
+            out[key] = {"collection_fit_s": round(ms * 1e-3, 4), "us_per_iteration": round(ms * 1e3 / T, 1),
+                        "fit_algorithmic_tflops": round(tfl, 3)}
+    finally:
+        ctx.set_medium_min_batch(0)
+        for b in (dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis):
+            b.free()
+    cus = min(M, ctx.device_info()["compute_units"])
+    per_cu_peak = F64_MFMA_PEAK_TFLOPS / ctx.device_info()["compute_units"]
+    out["fused_kernel"]["frac_of_mfma_peak_of_the_cus_in_use"] = round(out["fused_kernel"]["fit_algorithmic_tflops"] / (per_cu_peak * cus), 4)
+    out["workload"] = (f"{M} members x N={N} (historical annual series), R={R}, matern32, n_optim_nits={T}: the reference's "
+                       "paper workload; fused_kernel = csrc/medium.hip, one workgroup (= one CU) per member; general_path = the "
+                       "batched launches of the N=2000 machinery (round 2's route for this size)")
+    out["speedup_vs_general_path"] = round(out["general_path"]["collection_fit_s"] / out["fused_kernel"]["collection_fit_s"], 3)
+    return out
+
+
 def spawn_ranks(args):
     """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
     rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
@@ -474,7 +512,7 @@ def run_config5(args, ctx, rank, world, exchange, rdzv):
                       "preset": "c5", "members": M, "grid_points_per_gpu": G, "fits_per_gpu": fw.B, "timesteps": N,
                       "realisations": R, "n_optim_nits": T, "export": args.export,
                       "parallelism": f"grid points sharded x{world}, no collective" if world > 1 else "single GPU"},
-           "roofline": d["roofline"], "roofline_mfma": d["roofline_mfma"], "cpu_baseline": cpu,
+           "roofline": d["roofline"], "roofline_hbm": d["roofline_hbm"], "cpu_baseline": cpu,
            "fit_kernel_ms": d["fit_kernel_ms"], "weighted_posterior_latency_ms": d["weighted_posterior_latency_ms"]}
     print(json.dumps(out), flush=True)
 
@@ -603,7 +641,7 @@ def main():
         fw = FieldWorkload(ctx, 32, 432, 86, 8, T, "full")
         c5f = fw.measure(3, 1)
         fw.free()
-        c5["full_export"] = {k: c5f[k] for k in ("value", "fits_per_step", "fit_kernel_ms", "roofline")}
+        c5["full_export"] = {k: c5f[k] for k in ("value", "fits_per_step", "fit_kernel_ms", "roofline", "roofline_hbm")}
         fw = FieldWorkload(ctx, 32, 432, 86, 8, T, "full", f32=True)
         c5s = fw.measure(3, 1)
         fw.free()
@@ -611,6 +649,7 @@ def main():
         c5["workload"] = ("BASELINE config 5, one GPU's share: 32 members x 1728 grid points (96x144 over 8 GPUs) of "
                           "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
         extra["config5"] = c5
+        extra["n165_T2500"] = mid_size_line(ctx)
         extra.update(api_path_c5(ctx, 32, 36, 48, 86, 8, T))
         extra["api_path_c5_vs_resident_step"] = round(extra["api_path_c5_ms_per_step"] / c5["ms_per_step"], 3)
         for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):

@@ -43,4 +43,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/${TAG}_ktp -o ktp -- python3 
 cd $R
 python3 tools/rocpd_seq.py $(find $OUT/${TAG}_ktp -name "*.db" | head -1) > $OUT/${TAG}_potrf_sequence.txt
 rm -rf $OUT/${TAG}_ktp
+# the fused mid-size kernel (csrc/medium.hip) at the reference's workload: timing table against the general path, phase stamps,
+# kernel trace and matrix-pipe utilisation of one collection fit
+(timeout -k 10 300 python3 tools/medium_check.py | grep timing; BAYENS_NO_MEDIUM=1 timeout -k 10 300 python3 tools/medium_check.py | grep timing; timeout -k 10 100 python3 tools/medium_phases.py 165 20 | tail -15) > $OUT/${TAG}_medium_kernel.txt 2>&1 || exit 14
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ktm -o ktm -- python3 $R/tools/n165_fit.py > $OUT/${TAG}_ktm.log 2>&1 || exit 15
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pmm -o m -- python3 $R/tools/n165_fit.py > $OUT/${TAG}_pmm.log 2>&1 || exit 16
+cd $R
+python3 tools/rocpd_stats.py $(find $OUT/${TAG}_ktm -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_n165.txt > /dev/null
+python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pmm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util_n165.txt > /dev/null
+rm -rf $OUT/${TAG}_ktm $OUT/${TAG}_pmm
+timeout -k 10 300 python3 tools/api_path_c5.py > $OUT/${TAG}_api_path_c5.json 2> /dev/null || exit 17
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
