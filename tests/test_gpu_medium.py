@@ -106,3 +106,32 @@ def test_more_members_than_workgroups(mctx):
         for m in (0, 255, 256, 299):
             mo, co, _ = go.gp_fit(X[m], y[m], nu[m], T)
             assert relerr(out["mu"][m], mo) < 1e-10 and relerr(out["cov"][m], co) < 1e-10
+
+
+def test_plugin_api_takes_the_fused_kernel_for_the_papers_series_length(ctx):
+    """ModelCollection.fit(GPDTW1D) on members of the paper's length (N = 165 is what experiments/full_experiment_script.py
+    fits; 3 members x N = 130 here to keep the oracle cheap): resident posteriors produced by the fused mid-size kernel,
+    LogLikelihoodWeight and Barycentre on them, against the oracle; loss samples kept with progress_bar=True."""
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    M, N, R, T = 3, 130, 5, 27
+    data, obs = go.synthetic_ensemble(M, N, R=R, R_obs=2, seed=165)
+    time = np.arange(N)
+    pm = lambda a, name: es.ProcessModel(DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": time}), name)
+    mc = es.ModelCollection([pm(data[m], f"m{m}") for m in range(M)])
+    mc.fit(model=es.GPDTW1D(), n_optim_nits=T)                        # progress_bar=True: two loss samples
+    w = es.LogLikelihoodWeight()(mc, pm(obs, "obs"), standardisation_constant=1e-3)
+    post = es.Barycentre()(mc, w)
+    lls, mus, vs = [], [], []
+    with threadpool_limits(2):
+        for m in range(M):
+            X, y, nu = go.prologue(data[m])
+            mo, co, _, lo = go.gp_fit(X, y, nu, T, loss_every=25)
+            assert relerr(mc[m].distribution.mean.values, mo) < 1e-9 and relerr(np.asarray(mc[m].distribution.covariance), co) < 1e-9
+            assert np.allclose(mc[m].distribution.losses, lo, rtol=1e-9)
+            lls.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, *go.mvn_factor(co), obs)))
+            mus.append(mo); vs.append(np.diag(co))
+    w_ref, _ = go.loglik_weights(np.stack(lls), 1e-3)
+    assert relerr(w.values, w_ref) < 1e-8
+    rm, rv, _ = go.barycentre(w_ref, np.stack(mus), np.stack(vs))
+    assert relerr(post.mu, rm) < 1e-8 and relerr(post.covariance, rv) < 1e-8
