@@ -397,31 +397,41 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
       diag16(acc, t, D + (k + 1) * TS, lane, 16 * (k + 1), bad, o);   // the updated tile goes straight into the factorisation
 #endif
     } else {
-      int p = 0;
+      // The trailing tiles (i, j), i = k+2 .. NT-1, j = k+1 .. i ((k+1, k+1) is wave 0's), and behind them the inverse's tiles
+      // (j, i), j = k+1 .. NT-1, i = 0 .. k, form ONE sequence dealt round-robin over waves 1..NW-1.  A wave steps through
+      // its own positions directly, NW-1 at a time (round 3: scanning the whole sequence with a modulo test per candidate
+      // cost more scalar time than the tile updates it found - measured in medium.hip, where this loop was first fixed).
+      const int n_trail = (below - 1) * (below + 2) / 2;                      // sum_{i = k+2}^{NT-1} (i - k)
+      int pos = wave - 1;
+      {
+        int i = k + 2, j = k + 1 + pos;                                       // row i holds i - k tiles
+        while (i < NT && j > i) { j -= i - k; ++i; }
 #pragma unroll 1
-      for (int i = k + 1; i < NT; ++i)
-#pragma unroll 1
-        for (int j = k + 1; j <= i; ++j) {
-          if (i == k + 1) continue;                       // (k+1, k+1) is wave 0's
-          if (p++ % (NW - 1) == wave - 1) {               // A_ij -= L_ik L_jk^T
-            real* t = A + lt(i, j) * TS;
-            v4r acc = ld_tile(t, o);
-            acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1);
-            st_tile(t, o, acc);
-          }
+        while (pos < n_trail) {                                               // A_ij -= L_ik L_jk^T
+          real* t = A + lt(i, j) * TS;
+          v4r acc = ld_tile(t, o);
+          acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1);
+          st_tile(t, o, acc);
+          pos += NW - 1;
+          j += NW - 1;
+          while (i < NT && j > i) { j -= i - k; ++i; }
         }
+      }
       if (WITH_INV) {
+        const int n_inv_ops = below * (k + 1);
+        int q = pos - n_trail;                                                // position inside the inverse's part of the sequence
+        int j = k + 1 + q / (k + 1), i = q - (j - (k + 1)) * (k + 1);
 #pragma unroll 1
-        for (int j = k + 1; j < NT; ++j)
-#pragma unroll 1
-          for (int i = 0; i <= k; ++i)
-            if (p++ % (NW - 1) == wave - 1) {             // T_ji -= L_jk X_ki   (first touched at k == i)
-              real* t = Xb + lt(j, i) * TS;
-              v4r acc = {0, 0, 0, 0};
-              if (k > i) acc = ld_tile(t, o);
-              acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1);
-              st_tile(t, o, acc);
-            }
+        while (q < n_inv_ops) {                                               // T_ji -= L_jk X_ki   (first touched at k == i)
+          real* t = Xb + lt(j, i) * TS;
+          v4r acc = {0, 0, 0, 0};
+          if (k > i) acc = ld_tile(t, o);
+          acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1);
+          st_tile(t, o, acc);
+          q += NW - 1;
+          i += NW - 1;
+          while (i > k) { i -= k + 1; ++j; }
+        }
       }
       extra(k);
     }
