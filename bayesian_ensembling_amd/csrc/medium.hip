@@ -8,8 +8,8 @@
 // tile-packed lower triangles, explicit triangular inverses riding along with the blocked factorisations, MFMA-based
 // 16x16 diagonal factorisation) - reference ensembles/models.py:185-220 + data.py:38-39, SURVEY.md Appendix A.  What
 // differs is where the matrices live.  At NT = 11 tiles per side a tile-packed triangle is 132 KB: the matrices cannot
-// share the CU's 160 KB of LDS.  They live in a per-workgroup scratch in HBM that stays L2-resident (six triangles,
-// ~0.8 MB per member at N = 165), and LDS is the staging area between that scratch and the matrix cores:
+// share the CU's 160 KB of LDS.  They live in a per-workgroup scratch in HBM that stays L2-resident (eight triangles,
+// ~1.1 MB per member at N = 165), and LDS is the staging area between that scratch and the matrix cores:
 //   * a tile in the scratch is stored in ACCUMULATOR-NATIVE order - lane (lr, lk)'s four accumulator elements
 //     (rows lk + 4r of column lr) are 32 contiguous bytes - so every load / store of a tile is one fully coalesced 2 KB
 //     wave access (the first version of this kernel read MFMA operands straight from the scratch, 8 scattered bytes per
@@ -390,6 +390,8 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
   double* Gb = Wb + (size_t)NTT * TS;           // G = L^T D L ; in the prediction (with LamB behind it) E = A^T S, NT x NT tiles
   double* LamB = Gb + (size_t)NTT * TS;         // Lam (the natural parameter that persists over the iterations)
   double* Sb = LamB + (size_t)NTT * TS;         // S = C^-T C^-1
+  double* K1b = Sb + (size_t)NTT * TS;          // unit-variance kernel values k1 of this iteration's kernel matrix ...
+  double* K2b = K1b + (size_t)NTT * TS;         // ... and k2 (d/d lengthscale): kept for the hyper-gradient instead of re-evaluating sqrt / exp
   // (the wave index is made visibly wave-uniform: everything derived from it - tile indices, slot addresses - stays scalar)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   Ctx c;
@@ -458,25 +460,29 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       GSYNC();
     };
     // Lb <- tril(K0) + J I (identity in the padding)
-    auto kmat = [&]() {
+    // `keep`: the unit-variance kernel values (k1, k2) of every tile are parked in the scratch for this iteration's hyper-gradient
+    auto kmat = [&](bool keep) {
       const double var = misc[8], inv_ls2 = misc[10];
       int i = 0, j = 0;
       unpack_step(i, j, wave);
 #pragma unroll 1
       for (int p = wave; p < NTT; p += NW) {
         const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
-        v4d kt;
+        v4d kt, k1t, k2t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
           double k1, k2;
-          kern_unit<false>(g.kernel, r2[r], k1, k2);
+          kern_unit<true>(g.kernel, r2[r], k1, k2);
           double K = var * k1;
           if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
           else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
           kt[r] = K;
+          k1t[r] = (row < N && col < N) ? k1 : 0.0;         // (the padding contributes no gradient)
+          k2t[r] = (row < N && col < N) ? k2 : 0.0;
         }
         stn(Lb + (size_t)p * TS, lane, kt);
+        if (keep) { stn(K1b + (size_t)p * TS, lane, k1t); stn(K2b + (size_t)p * TS, lane, k2t); }
         unpack_step(i, j, NW);
       }
       GSYNC();
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     for (int it = 0; it < g.n_iters; ++it) {
       MSTAMP(0);
       refresh_hypers();
-      kmat();                                                              // K0 + J I at the current hypers  (models.py:209)
+      kmat(true);                                                          // K0 + J I at the current hypers  (models.py:209)
       MSTAMP(1);
       // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L and L^T (y / nu) accumulate block row by block row behind it
       for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric: Kbar_ij and Kbar_ji^T
       // = sum_k W_ki^T Linv_kj are accumulated together and the kernel function is evaluated once per unordered pair
       {
-        const double var = misc[8], ls = misc[9], inv_ls2 = misc[10];
+        const double var = misc[8], ls = misc[9];
         double gv = 0.0, gl = 0.0;
         staged_product(c, NTT, false, 0, NT,
           [&](int k) {
@@ -727,15 +733,11 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
             if (i != j) acc = mma_rt(acc, c.slot(NT + i), true, c.slot(j), false, o);                    // W_ki^T Linv_kj
             return acc;
           },
-          [&](int, int i, int j, v4d acc) {
-            const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+          [&](int p, int, int, v4d acc) {
+            // <Kbar, k1>, <Kbar, k2> with the kernel values this iteration's kmat parked (zero in the padding)
+            const v4d k1t = ldn(K1b + (size_t)p * TS, lane), k2t = ldn(K2b + (size_t)p * TS, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-              double k1, k2;
-              kern_unit<true>(g.kernel, r2[r], k1, k2);
-              if (row < N && col < N) { gv = fma(acc[r], k1, gv); gl = fma(acc[r], k2, gl); }
-            }
+            for (int r = 0; r < 4; ++r) { gv = fma(acc[r], k1t[r], gv); gl = fma(acc[r], k2t[r], gl); }
           });
         gv = wave_sum(gv);
         gl = wave_sum(gl);
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     // ---- prediction at the final hypers with the (m, S) of the last step    (models.py:217-220)
     MSTAMP(9);
     refresh_hypers();
-    kmat();
+    kmat(false);
     bad = potrf_v2<true, 0>(pargs(Lb, Wb, Gb), bad);                            // Lb = L, Wb = L^-1, Sb = S
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     MSTAMP(10);
@@ -930,7 +932,7 @@ bool medium_fit_supported(int N, int R) { return N > smalln::SMALL_MAX_N && N <=
 
 size_t medium_scratch_doubles(int N) {
   const int NT = medium_tiles(N), NTT = NT * (NT + 1) / 2;
-  return (size_t)6 * NTT * TS;
+  return (size_t)8 * NTT * TS;
 }
 
 static size_t medium_lds_bytes(int N) {
