@@ -30,5 +30,3 @@ for k, nme in enumerate(names):
 print("iteration total", st[8] - st[0], "predict total", st[12] - st[9])
 
 
-q = st[16:20]
-print("probe (wave 1, column 5, first trailing pair): 2-tile load %d, product %d, store+ack %d cycles" % (q[1]-q[0], q[2]-q[1], q[3]-q[2]))
