@@ -218,18 +218,38 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     P.mark("potrf Lam");
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
     P.mark("G S solves");
-    // [G; theta1^T] C^-T C^-1 = [G S; m^T].  G S is all the Adam step (models.py:210) needs of S: for i >= j
+    // G S is all the Adam step (models.py:210) needs of S: for i >= j
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
-    // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.  The variational mean
-    // m = S theta1 rides through the same two solves as one extra row (the last padded row when there is padding).
-    P.aug_set(nb, Np, trow, ws.theta1, in_pad ? 0 : LEAF - 1);
-    trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);            // [G; theta1^T] C^-T
-    trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);     // ... C^-1
-    P.aug_get(nb, Np, trow, ws.mvec);                                 // m
+    // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.
+    const bool first = it == 0 && fp.gamma > 0.0;
+    if (first) {
+      // First iteration: the VGP starts at q_sqrt = I, i.e. Lam_old = I EXACTLY, so Lam = I + gamma G and
+      //   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma :
+      // the two full solves below (2 N^3) shrink to the explicit S = C^-T C^-1 - the triangular inverse (a lower-rhs solve
+      // on I, N^3/3) and one lower x lower product (N^3/3).  The variational mean m = S theta1 rides through the two
+      // solves alone, in a 64-row block (T1's appended rows).
+      P.identity(nb, Np, ws.T2);
+      trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);       // C^-1 (lower)
+      P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 0.0, ws.T1, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);   // S (lower blocks)
+      Mat mrow = ws.T1.sub(Np, 0);
+      P.aug_set(nb, Np, mrow, ws.theta1, LEAF - 1);
+      trsm_rlt(P, nb, LEAF, Np, ws.Cb, ws.invC, is, mrow);            // theta1^T C^-T
+      trsm_rln(P, nb, LEAF, Np, ws.Cb, ws.invC, is, mrow, false);     // ... C^-1
+      P.aug_get(nb, Np, mrow, ws.mvec);                               // m
+    } else {
+      // [G; theta1^T] C^-T C^-1 = [G S; m^T]: m = S theta1 rides through the same two solves as one extra row (the last
+      // padded row when there is padding).
+      P.aug_set(nb, Np, trow, ws.theta1, in_pad ? 0 : LEAF - 1);
+      trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);          // [G; theta1^T] C^-T
+      trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);   // ... C^-1
+      P.aug_get(nb, Np, trow, ws.mvec);                               // m
+    }
     P.mark("Phi");
     P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
     P.lt_dvec(nb, Np, ws.Lb, ws.avec, ws.nu, 1.0, 0.0, ws.uvec);      // u = L^T D a
-    P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2);               // Phi(L^T Lbar), clean lower triangle
+    // Phi(L^T Lbar), clean lower triangle, from G S - or in the first iteration from S: G S = (I - S) / gamma
+    if (first) P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2, -1.0 / fp.gamma, 1.0 / fp.gamma);
+    else P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2, 1.0, 0.0);
     P.mark("Phi L^-1");
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
     P.mark("W^T L^-1");
@@ -329,9 +349,10 @@ int polar_nuclear(Prims& P, FitWorkspace& ws, int nb, double* nuc, double* scrat
 double fit_flops(int N, int R, int n_iters) {
   // per iteration: chol K 1/3, G = L^T D L 1/3, chol Lam 1/3, G C^-T 1, (.) C^-1 1,
   //                Phi L^-1 1/3, W^T L^-1 1  => 13/3 N^3 ; kernel matrix 2 N^2 R
+  // first iteration (Lam_old = I: G S = (I - S) / gamma): C^-1 1/3 + C^-T C^-1 1/3 replace the two solves => 3 N^3
   // prediction: chol K 1/3, L^-1 1/3, A^T C^-T 1, L^-T L^-1 1/3, rank-N update 1 => 3 N^3, chol(cov) 1/3
   double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
-  return n_iters * (13.0 / 3.0 * n3 + n2r) + (3.0 * n3 + n2r) + n3 / 3.0;
+  return n_iters * (13.0 / 3.0 * n3 + n2r) - (n_iters > 0 ? 4.0 / 3.0 * n3 : 0.0) + (3.0 * n3 + n2r) + n3 / 3.0;
 }
 
 }  // namespace BAYENS_NS

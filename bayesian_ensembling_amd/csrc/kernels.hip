@@ -148,7 +148,7 @@ __global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
 }
 
 // Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
-__global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, Mat Phi) {
+__global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
@@ -161,7 +161,7 @@ __global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, 
     const int i = i0 + 4 * q;
     v[q] = 0.0;
     if (j <= i) {
-      v[q] = u[(long)b * n + i] * mj + g[(long)i * GS.ld + j];
+      v[q] = u[(long)b * n + i] * mj + (scale * (double)g[(long)i * GS.ld + j] + (j == i ? diag_add : 0.0));
       if (j == i) v[q] *= 0.5;
     }
   }
@@ -1606,8 +1606,8 @@ void HipPrims::resid(int nb, int n, Mat L, const real* mvec, const real* y, real
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
   LAUNCH_CHECK();
 }
-void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi) {
-  hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi);
+void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) {
+  hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi, scale, diag_add);
   LAUNCH_CHECK();
 }
 void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr) {

@@ -107,8 +107,11 @@ struct Prims {
   //   Gfull <- G mirrored to a full symmetric matrix
   virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) = 0;
   // Phi(L^T Lbar) without forming Lbar: for i >= j, (L^T Lbar)_ij = u_i m_j + (G S)_ij with u = L^T D (L m - y)
-  //   Phi_ij = u_i m_j + GS_ij (i > j), half of it on the diagonal, 0 above
-  virtual void form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi) = 0;
+  //   Phi_ij = u_i m_j + GS_ij (i > j), half of it on the diagonal, 0 above,   GS_ij = scale * M_ij + diag_add * delta_ij.
+  // (scale, diag_add) = (1, 0): M is G S itself.  In the FIRST iteration Lam_old = I, so Lam = I + gamma G and
+  // G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma: M = S (lower) with (scale, diag_add) = (-1/gamma, 1/gamma) - the two
+  // full solves that form G S (2 N^3) shrink to the explicit S = C^-T C^-1 (2/3 N^3).
+  virtual void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) = 0;
   // a row of an n-column right-hand side that carries a vector through the same triangular solves
   // (x^T C^-T C^-1 = (C^-T C^-1 x)^T): rows[0][:] = vec and the `zero_rows` rows after it are cleared.
   // The row is either the first of a 64-row block appended below the matrix (zero_rows = 63) or, when the

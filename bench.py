@@ -40,8 +40,10 @@ METRIC = "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step
 
 
 def fit_flops(N, R, T):
+    """Algorithmic flop of one member fit (= fit_flops in csrc/driver.cpp): 13/3 N^3 per iteration, 3 N^3 in
+    the first one (Lam_old = I: G S = (I - S) / gamma needs S only), 3 N^3 for the prediction, N^3/3 for chol(cov)."""
     n3, n2r = float(N) ** 3, 2.0 * N * N * R
-    return T * (13.0 / 3.0 * n3 + n2r) + (3.0 * n3 + n2r) + n3 / 3.0
+    return T * (13.0 / 3.0 * n3 + n2r) - (4.0 / 3.0 * n3 if T > 0 else 0.0) + (3.0 * n3 + n2r) + n3 / 3.0
 
 
 def make_inputs(M, N, R, R_obs, seed):
