@@ -221,7 +221,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     // G S is all the Adam step (models.py:210) needs of S: for i >= j
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
     // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.
-    const bool first = it == 0 && fp.gamma > 0.0;
+    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the solves: I - S cancels)
     if (first) {
       // First iteration: the VGP starts at q_sqrt = I, i.e. Lam_old = I EXACTLY, so Lam = I + gamma G and
       //   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma :

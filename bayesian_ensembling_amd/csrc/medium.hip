@@ -640,7 +640,28 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       MSTAMP(5);
       // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal -> Cb (C is dead).  u = L^T D (L m - y) = G m - L^T (y / nu) comes
       // out of the same pass (the crosses of G are in LDS anyway) and, like m, enters Phi only in the epilogue.
-      {
+      if (it == 0 && g.gamma > 0.0) {
+        // First iteration: Lam_old = I exactly, so Lam = I + gamma G, G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma and
+        // G m = (Lam m - m) / gamma = (theta1 - m) / gamma: no product, one pass over the tiles of S.
+        for (int t = tid; t < NP; t += NTH) uv[t] = (th[t] - mv[t]) / g.gamma - wv[t];
+        GSYNC();
+        int i = 0, j = 0;
+        unpack_step(i, j, wave);
+#pragma unroll 1
+        for (int p = wave; p < NTT; p += NW) {
+          v4d a = ldn(Sb + (size_t)p * TS, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = o.kq[r];
+            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], (((i == j && rl == o.lr) ? 1.0 : 0.0) - a[r]) / g.gamma);
+            if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
+            a[r] = v;
+          }
+          stn(Cb + (size_t)p * TS, lane, a);
+          unpack_step(i, j, NW);
+        }
+        GSYNC();
+      } else {
         double gm[2] = {0.0, 0.0};
 #pragma unroll 1
         for (int base = 0; base < NTT; base += PASS_TILES) {

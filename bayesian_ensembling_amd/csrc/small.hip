@@ -718,6 +718,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       SYNC();
       STAMP(3);
       // C = chol(Lam) in Cb, C^-1 in Lb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
+      const bool first = it == 0 && g.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the product: I - S cancels)
       v4r st[TPW];
 #pragma unroll
       for (int s = 0; s < TPW; ++s) st[s] = v4r{0, 0, 0, 0};
@@ -775,9 +776,17 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           int i, j;
           unpack_lower(p, i, j);
           v4r acc = {0, 0, 0, 0};
-          acc = acc_run(acc, 0, NT,
-                        [&](int k, int q) { return k <= i ? Lb[lt(i, k) * TS + o.rc[q]] : Lb[lt(k, i) * TS + o.cr[q]]; },
-                        [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
+          if (first) {
+            // first iteration: Lam_old = I exactly, so Lam = I + gamma G and G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma;
+            // this wave still holds its S tile in st[s] (same element layout) - no product
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[r] = (real)((((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0) - (double)st[s][r]) / g.gamma);
+          } else {
+            acc = acc_run(acc, 0, NT,
+                          [&](int k, int q) { return k <= i ? Lb[lt(i, k) * TS + o.rc[q]] : Lb[lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rl = o.kq[r];
