@@ -211,9 +211,20 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY);
     P.mark("Lam update");
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
+    // First iteration: the VGP starts at q_mu = 0, q_sqrt = I, i.e. Lam_old = I EXACTLY and theta1_old = 0, so
+    //   Lam = I + gamma G,   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma,
+    //   Lam m = theta1 = gamma L^T (y/nu)  =>  u = L^T D (L m - y) = G m - theta1 / gamma = -m / gamma :
+    // the product's epilogue writes Lam itself (no separate G), and the two full solves that form G S (2 N^3) shrink to the
+    // explicit S = C^-T C^-1 - the triangular inverse (a lower-rhs solve on I, N^3/3) and one lower x lower product (N^3/3).
+    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the solves: I - S cancels)
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
-    P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 0.0, ws.T2, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
-    P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1);     // Lam, Cb = tril(Lam), T1 = G (full)
+    if (first) {
+      P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 0.0, ws.Lam, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 1.0);
+      P.tri_copy(nb, Np, ws.Lam, ws.Cb);
+    } else {
+      P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 0.0, ws.T2, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
+      P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1);   // Lam, Cb = tril(Lam), T1 = G (full)
+    }
     P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
     P.mark("potrf Lam");
     potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
@@ -221,21 +232,14 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     // G S is all the Adam step (models.py:210) needs of S: for i >= j
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
     // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.
-    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the solves: I - S cancels)
     if (first) {
-      // First iteration: the VGP starts at q_sqrt = I, i.e. Lam_old = I EXACTLY, so Lam = I + gamma G and
-      //   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma :
-      // the two full solves below (2 N^3) shrink to the explicit S = C^-T C^-1 - the triangular inverse (a lower-rhs solve
-      // on I, N^3/3) and one lower x lower product (N^3/3).  The variational mean m = S theta1 rides through the two
-      // solves alone, in a 64-row block (T1's appended rows).
       P.identity(nb, Np, ws.T2);
       trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);       // C^-1 (lower)
       P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 0.0, ws.T1, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);   // S (lower blocks)
-      Mat mrow = ws.T1.sub(Np, 0);
-      P.aug_set(nb, Np, mrow, ws.theta1, LEAF - 1);
-      trsm_rlt(P, nb, LEAF, Np, ws.Cb, ws.invC, is, mrow);            // theta1^T C^-T
-      trsm_rln(P, nb, LEAF, Np, ws.Cb, ws.invC, is, mrow, false);     // ... C^-1
-      P.aug_get(nb, Np, mrow, ws.mvec);                               // m
+      P.symv_lower(nb, Np, ws.T1, ws.theta1, ws.mvec);                // m = S theta1
+      P.mark("Phi");
+      // Phi(L^T Lbar), clean lower triangle: -(m m^T + S) / gamma + I / gamma
+      P.form_phi(nb, Np, ws.T1, ws.mvec, ws.mvec, ws.T2, -1.0 / fp.gamma, 1.0 / fp.gamma, -1.0 / fp.gamma);
     } else {
       // [G; theta1^T] C^-T C^-1 = [G S; m^T]: m = S theta1 rides through the same two solves as one extra row (the last
       // padded row when there is padding).
@@ -243,13 +247,11 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
       trsm_rlt(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1);          // [G; theta1^T] C^-T
       trsm_rln(P, nb, mrows, Np, ws.Cb, ws.invC, is, ws.T1, false);   // ... C^-1
       P.aug_get(nb, Np, trow, ws.mvec);                               // m
+      P.mark("Phi");
+      P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                 // a = L m - y
+      P.lt_dvec(nb, Np, ws.Lb, ws.avec, ws.nu, 1.0, 0.0, ws.uvec);    // u = L^T D a
+      P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2, 1.0, 0.0, 1.0);   // Phi(L^T Lbar), clean lower triangle
     }
-    P.mark("Phi");
-    P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                   // a = L m - y
-    P.lt_dvec(nb, Np, ws.Lb, ws.avec, ws.nu, 1.0, 0.0, ws.uvec);      // u = L^T D a
-    // Phi(L^T Lbar), clean lower triangle, from G S - or in the first iteration from S: G S = (I - S) / gamma
-    if (first) P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2, -1.0 / fp.gamma, 1.0 / fp.gamma);
-    else P.form_phi(nb, Np, ws.T1, ws.uvec, ws.mvec, ws.T2, 1.0, 0.0);
     P.mark("Phi L^-1");
     trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);         // W = Phi L^-1 (lower)
     P.mark("W^T L^-1");

@@ -100,7 +100,9 @@ struct HipPrims : Prims {
   void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                real* out) override;
   void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override;
-  void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) override;
+  void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add,
+                double u_scale) override;
+  void symv_lower(int nb, int n, Mat S, const real* v, real* out) override;
   void aug_set(int nb, int n, Mat rows, const real* vec, int zero_rows) override;
   void aug_get(int nb, int n, Mat rows, real* vec) override;
   void basis_rows_set(int nb, int N, int Np, Mat rows, const real* mu_pad, int in_padding) override;

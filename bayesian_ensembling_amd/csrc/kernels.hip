@@ -148,7 +148,8 @@ __global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
 }
 
 // Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
-__global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) {
+__global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add,
+                                double u_scale) {
   const int b = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
@@ -161,7 +162,7 @@ __global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, 
     const int i = i0 + 4 * q;
     v[q] = 0.0;
     if (j <= i) {
-      v[q] = u[(long)b * n + i] * mj + (scale * (double)g[(long)i * GS.ld + j] + (j == i ? diag_add : 0.0));
+      v[q] = u_scale * (double)u[(long)b * n + i] * mj + (scale * (double)g[(long)i * GS.ld + j] + (j == i ? diag_add : 0.0));
       if (j == i) v[q] *= 0.5;
     }
   }
@@ -783,6 +784,41 @@ __global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* 
     real* t = theta1 + (long)b * n + j0 + c;
     *t = (beta != 0.0 ? beta * (*t) : 0.0) + alpha * tot;
   }
+}
+
+// out = S v, S symmetric, elements on and below the diagonal read only: one workgroup per 64 columns j0..j0+63 sums the
+// column part sum_{i >= j} S_ij v_i (lanes = columns, the 4 waves split the rows, as in lt_dvec_kernel) and the row part
+// sum_{k < j} S_jk v_k (16 rows per wave, lanes stride k): 64 n elements per workgroup wherever the strip lies.
+__global__ __launch_bounds__(256) void symv_lower_kernel(int n, Mat S, const real* v, real* out) {
+  __shared__ double part[4][64];
+  __shared__ double rowp[64];
+  const int b = blockIdx.y, j0 = blockIdx.x * 64;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const real* s = S.p + b * S.stride;
+  const long vb = (long)b * n;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = j0 + w;
+  for (; i + 12 < n; i += 16) {
+    const double a0 = s[(long)i * S.ld + j0 + c], a1 = s[(long)(i + 4) * S.ld + j0 + c];
+    const double a2 = s[(long)(i + 8) * S.ld + j0 + c], a3 = s[(long)(i + 12) * S.ld + j0 + c];
+    s0 += (i >= j0 + c ? a0 : 0.0) * (double)v[vb + i];
+    s1 += (i + 4 >= j0 + c ? a1 : 0.0) * (double)v[vb + i + 4];
+    s2 += (i + 8 >= j0 + c ? a2 : 0.0) * (double)v[vb + i + 8];
+    s3 += (i + 12 >= j0 + c ? a3 : 0.0) * (double)v[vb + i + 12];
+  }
+  for (; i < n; i += 4) s0 += (i >= j0 + c ? (double)s[(long)i * S.ld + j0 + c] : 0.0) * (double)v[vb + i];
+  part[w][c] = (s0 + s1) + (s2 + s3);
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int j = j0 + 16 * w + q;
+    const real* row = s + (long)j * S.ld;
+    double t = 0.0;
+    for (int k = c; k < j; k += 64) t += (double)row[k] * (double)v[vb + k];
+    t = wave_sum(t);
+    if (c == 0) rowp[16 * w + q] = t;
+  }
+  __syncthreads();
+  if (w == 0) out[vb + j0 + c] = (real)(((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + rowp[c]);
 }
 
 // out_i = sum_{k < klim(i)} A_ik x_k - (sub ? sub_i : 0); one wave per row, lanes stride k.
@@ -1570,6 +1606,10 @@ void HipPrims::lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, doub
   hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, v, nu, alpha, beta, out);
   LAUNCH_CHECK();
 }
+void HipPrims::symv_lower(int nb, int n, Mat S, const real* v, real* out) {
+  hipLaunchKernelGGL(symv_lower_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, S, v, out);
+  LAUNCH_CHECK();
+}
 void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
   hipLaunchKernelGGL(lam_update_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, G, gamma, Lam, Cb, Gfull);
   LAUNCH_CHECK();
@@ -1606,8 +1646,9 @@ void HipPrims::resid(int nb, int n, Mat L, const real* mvec, const real* y, real
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(n / 4, nb), dim3(256), 0, stream, n, L, mvec, y, a, 1);
   LAUNCH_CHECK();
 }
-void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) {
-  hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi, scale, diag_add);
+void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, Mat Phi, double scale, double diag_add,
+                        double u_scale) {
+  hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi, scale, diag_add, u_scale);
   LAUNCH_CHECK();
 }
 void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr) {

@@ -111,7 +111,11 @@ struct Prims {
   // (scale, diag_add) = (1, 0): M is G S itself.  In the FIRST iteration Lam_old = I, so Lam = I + gamma G and
   // G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma: M = S (lower) with (scale, diag_add) = (-1/gamma, 1/gamma) - the two
   // full solves that form G S (2 N^3) shrink to the explicit S = C^-T C^-1 (2/3 N^3).
-  virtual void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add) = 0;
+  // u enters as u_scale * u (the first iteration has u = -m / gamma: Lam m = theta1 = gamma L^T (y/nu) there).
+  virtual void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add,
+                        double u_scale) = 0;
+  // out = S v for a symmetric S of which only the elements on and below the diagonal are read
+  virtual void symv_lower(int nb, int n, Mat S, const real* v, real* out) = 0;
   // a row of an n-column right-hand side that carries a vector through the same triangular solves
   // (x^T C^-T C^-1 = (C^-T C^-1 x)^T): rows[0][:] = vec and the `zero_rows` rows after it are cleared.
   // The row is either the first of a 64-row block appended below the matrix (zero_rows = 63) or, when the

@@ -199,12 +199,21 @@ struct CpuPrims : Prims {
           Gfull.p[b * Gfull.stride + (size_t)j * Gfull.ld + i] = g;
         }
   }
-  void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi, double scale, double diag_add) override {
+  void symv_lower(int nb, int n, Mat S, const double* v, double* out) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i) {
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += (j <= i ? S.p[b * S.stride + (size_t)i * S.ld + j] : S.p[b * S.stride + (size_t)j * S.ld + i]) * v[(size_t)b * n + j];
+        out[(size_t)b * n + i] = t;
+      }
+  }
+  void form_phi(int nb, int n, Mat GS, const double* u, const double* mvec, Mat Phi, double scale, double diag_add,
+                double u_scale) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
           double v = 0.0;
-          if (j <= i) v = u[(size_t)b * n + i] * mvec[(size_t)b * n + j] +
+          if (j <= i) v = u_scale * u[(size_t)b * n + i] * mvec[(size_t)b * n + j] +
                           (scale * GS.p[b * GS.stride + (size_t)i * GS.ld + j] + (j == i ? diag_add : 0.0));
           if (j == i) v *= 0.5;
           Phi.p[b * Phi.stride + (size_t)i * Phi.ld + j] = v;
