@@ -114,6 +114,7 @@ def load():
     lib.bayens_bench_gemm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_bench_leaf.argtypes = [_vp, C.c_int, C.c_int, _dp, _vp]
     lib.bayens_bench_potrf.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
+    lib.bayens_bench_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_bench_mfma_peak.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_bench_mfma_lds.argtypes = [_vp, C.c_int, _dp]
     lib.bayens_test_potrf.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
@@ -671,6 +672,12 @@ class Context:
         tf = C.c_double()
         self._check(self.lib.bayens_bench_mfma_lds(self.h, mode, C.byref(tf)))
         return tf.value
+
+    def bench_trsm(self, nb=32, m=2048, n=2048, mode=0, rhs_lower=False, reps=10):
+        """Diagnostic: microseconds per blocked triangular solve X op(L) = B (bayens_diag.h)."""
+        us = C.c_double(0.0)
+        self._check(self.lib.bayens_bench_trsm(self.h, nb, m, n, mode, int(rhs_lower), reps, C.byref(us)))
+        return us.value
 
     def bench_potrf(self, nb=32, n=2048, reps=10):
         us = C.c_double()

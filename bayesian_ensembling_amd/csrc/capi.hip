@@ -1920,6 +1920,41 @@ int bayens_bench_potrf(bayens_ctx* c, int nb, int n, int reps, double* us_per_fa
   });
 }
 
+int bayens_bench_trsm(bayens_ctx* c, int nb, int m, int n, int mode, int rhs_lower, int reps, double* us_per_solve) {
+  return guarded(c, [&]() {
+    if (n % LEAF || m % LEAF || n <= 0 || m <= 0 || reps <= 0 || (rhs_lower && (mode != 1 || m != n)))
+      return fail(c, BAYENS_E_ARG, "bench_trsm: m, n positive multiples of 64; rhs_lower needs mode 1 and m == n");
+    Stage st(c, BAYENS_DEVICE);
+    const size_t an = (size_t)nb * n * n, bn = (size_t)nb * m * n;
+    double* dA = st.scratch<double>(an);
+    double* dS = st.scratch<double>(an);
+    double* dB = st.scratch<double>(bn);
+    double* inv = st.scratch<double>((size_t)nb * n * LEAF);
+    int* dinfo = st.scratch<int>(nb);
+    BAYENS_HIP(hipMemsetAsync(dinfo, 0, nb * sizeof(int), c->stream));
+    c->prims->fill_random(dA, an, 11);
+    Mat A{dA, n, (long)n * n}, S{dS, n, (long)n * n}, Bm{dB, n, (long)m * n};
+    c->prims->gemm(nb, n, n, n, 1.0 / n, A, A, 0.0, S, GEMM_TB, 1.0);   // S = A A^T / n + I
+    potrf(*c->prims, nb, n, S, inv, (long)n * LEAF, dinfo);
+    if (rhs_lower) c->prims->identity(nb, n, Bm); else c->prims->fill_random(dB, bn, 12);
+    auto timed = [&]() {
+      BAYENS_HIP(hipEventRecord(c->t0, c->stream));
+      for (int r = 0; r < reps; ++r) {
+        if (mode == 0) trsm_rlt(*c->prims, nb, m, n, S, inv, (long)n * LEAF, Bm);
+        else trsm_rln(*c->prims, nb, m, n, S, inv, (long)n * LEAF, Bm, rhs_lower != 0);
+      }
+      BAYENS_HIP(hipEventRecord(c->t1, c->stream));
+      BAYENS_HIP(hipEventSynchronize(c->t1));
+      float f = 0;
+      BAYENS_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+      return (double)f * 1e3 / reps;
+    };
+    timed();   // warm-up
+    if (us_per_solve) *us_per_solve = timed();
+    return 0;
+  });
+}
+
 int bayens_test_potrf(bayens_ctx* c, int nb, int n, double* A, int* info) {
   return guarded(c, [&]() {
     if (n % LEAF) return fail(c, BAYENS_E_ARG, "test_potrf: n must be a multiple of 64");

@@ -58,9 +58,9 @@ static void trsm_rln_rec(Prims& P, int nb, int m, int n, Mat L, const real* inv,
   int n1 = split_point(n), n2 = n - n1;
   trsm_rln_rec(P, nb, m, n2, L.sub(n1, n1), inv_at(inv, n1 / LEAF), inv_stride, B.sub(0, n1), rhs_lower,
                c0 + n1);
-  int r2 = rhs_lower ? c0 + n1 : 0;   // X2 is zero above row c0+n1
+  int r2 = rhs_lower ? c0 + n1 : 0;   // X2 is zero above row c0+n1 - and lower trapezoidal below it: row i ends at column i
   if (r2 < m)
-    P.gemm(nb, m - r2, n1, n2, -1.0, B.sub(r2, n1), L.sub(n1, 0), 1.0, B.sub(r2, 0), 0, 0.0);
+    P.gemm(nb, m - r2, n1, n2, -1.0, B.sub(r2, n1), L.sub(n1, 0), 1.0, B.sub(r2, 0), rhs_lower ? GEMM_KTRIM_A_LOWER : 0, 0.0);
   trsm_rln_rec(P, nb, m, n1, L, inv, inv_stride, B, rhs_lower, c0);
 }
 

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
 
   int kbeg = 0;
   if (g.flags & GEMM_KTRIM_TN_LOWER) kbeg = row0 > col0 ? row0 : col0;
-  const int nk = (g.k - kbeg) / BK;
+  int kend = g.k;
+  if ((g.flags & GEMM_KTRIM_A_LOWER) && row0 + BM < kend) kend = row0 + BM;   // A_ik = 0 for k > i: nothing beyond the tile's rows
+  const int nk = (kend - kbeg) / BK;
 
   v4d acc[4][4];
 #pragma unroll
@@ -317,7 +319,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
 
   int kbeg = 0;
   if (g.flags & GEMM_KTRIM_TN_LOWER) kbeg = row0 > col0 ? row0 : col0;
-  const int nk = (g.k - kbeg) / BK;
+  int kend = g.k;
+  if ((g.flags & GEMM_KTRIM_A_LOWER) && row0 + BM < kend) kend = row0 + BM;   // A_ik = 0 for k > i: nothing beyond the tile's rows
+  const int nk = (kend - kbeg) / BK;
 
   v4d acc[4][4];
 #pragma unroll
@@ -651,6 +655,10 @@ double out_elems(int m, int n, int flags) {
 }
 double algorithmic_flop(int nb, int m, int n, int k, int flags) {
   if ((flags & GEMM_TRI_OUT) && (flags & GEMM_KTRIM_TN_LOWER)) return 2.0 * m * (double)n * k * nb / 6.0;
+  if (flags & GEMM_KTRIM_A_LOWER) {   // row i of A ends at column i: sum_i min(k, i + 1)
+    const double kk = k < m ? k : m;
+    return 2.0 * n * nb * (0.5 * kk * kk + (double)(m - kk) * k);
+  }
   return 2.0 * k * out_elems(m, n, flags) * nb;
 }
 // operand bytes a launch has to move at least once: A and B read (half each when both are lower triangles),

@@ -41,6 +41,7 @@ enum : int {
   GEMM_TB = 2,             // B is stored n x k (use B^T)
   GEMM_TRI_OUT = 4,        // C square: skip 64x64 blocks strictly above the diagonal (not written)
   GEMM_KTRIM_TN_LOWER = 8, // with TA, !TB: A and B are lower triangular => k starts at max(i0, j0)
+  GEMM_KTRIM_A_LOWER = 16, // with !TA: A (m x k) is lower trapezoidal, A_ik = 0 for k > i => k ends at the tile's last row
   GEMM_ZERO_SKIPPED = 32,  // with TRI_OUT: the skipped 64x64 blocks are written with zeros instead of left alone
 };
 

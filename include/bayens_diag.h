@@ -26,6 +26,10 @@ int bayens_bench_leaf(bayens_ctx* ctx, int nb, int reps, double* us_per_launch, 
 /* Diagnostic: nb device-generated SPD matrices of order n (a multiple of 64); us_per_factor = time of one batched
  * blocked Cholesky (the copy that restores the input between repetitions is timed separately and subtracted). */
 int bayens_bench_potrf(bayens_ctx* ctx, int nb, int n, int reps, double* us_per_factor);
+/* Diagnostic: times the blocked triangular solve  X op(L) = B  (mode 0: op(L) = L^T, 1: op(L) = L; rhs_lower: B lower
+ * triangular, mode 1 only) on an m x n right-hand side against the factor of a device-generated SPD matrix of order n;
+ * n <= 256 is one fused panel launch (trsm_panel_kernel), above it the recursion of csrc/driver.cpp. */
+int bayens_bench_trsm(bayens_ctx* ctx, int nb, int m, int n, int mode, int rhs_lower, int reps, double* us_per_solve);
 /* Diagnostic: what the fp64 matrix pipes sustain from registers alone (16 independent v_mfma_f64_16x16x4_f64
  * accumulators per wave, waves_per_simd = 1 or 2 waves on every SIMD, no memory traffic) - the measured ceiling the
  * GEMM's K loop is compared with. */

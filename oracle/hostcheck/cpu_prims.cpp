@@ -37,8 +37,10 @@ struct CpuPrims : Prims {
             int r0 = (i / 128) * 128, c0 = (j / 128) * 128;
             k0 = r0 > c0 ? r0 : c0;
           }
+          int k1 = k;
+          if ((flags & GEMM_KTRIM_A_LOWER) && (i / 128) * 128 + 128 < k1) k1 = (i / 128) * 128 + 128;   // (per 128-tile, as on the device)
           double s = 0;
-          for (int kk = k0; kk < k; ++kk) {
+          for (int kk = k0; kk < k1; ++kk) {
             double av = ta ? a[(size_t)kk * A.ld + i] : a[(size_t)i * A.ld + kk];
             double bv = tb ? bb[(size_t)j * B.ld + kk] : bb[(size_t)kk * B.ld + j];
             s += av * bv;
