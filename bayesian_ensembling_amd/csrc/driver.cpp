@@ -171,9 +171,13 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
 // inverse).  Scratch: T1, T2, avec, uvec, dscratch.  The reference evaluates the loss after the Adam step, i.e. at the
 // NEXT iteration's hypers: the caller invokes this right after that iteration's (or the prediction's) Cholesky of
 // K, before Lam/C are advanced, so no extra kernel matrix or factorisation is needed.
-static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot) {
+static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot, bool c_stale = false) {
   const int nb = ws.nb, Np = ws.Np, N = fp.N;
   const long is = ws.inv_stride();
+  if (c_stale) {   // the first iteration took its hyper-gradient without C = chol(Lam) (see gp_fit): factor it for the sample
+    P.tri_copy(nb, Np, ws.Lam, ws.Cb);
+    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);
+  }
   P.resid(nb, Np, ws.Lb, ws.mvec, ws.y, ws.avec);                      // a = L m - y
   P.copy(nb, Np, ws.Lb, ws.T1);
   trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);                  // L C^-T
@@ -202,32 +206,57 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   const bool in_pad = Np > N;
   const int mrows = in_pad ? Np : Np + LEAF;
   Mat trow = ws.T1.sub(in_pad ? Np - 1 : Np, 0);
+  bool c_stale = false;
   for (int it = 0; it < fp.n_iters; ++it) {
+    // First iteration: the VGP starts at q_mu = 0, q_sqrt = I, i.e. Lam_old = I EXACTLY and theta1_old = 0, so
+    //   Lam = I + gamma G,   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma,
+    //   Lam m = theta1 = gamma L^T (y/nu)  =>  u = L^T D (L m - y) = G m - theta1 / gamma = -m / gamma
+    // (fp32 keeps the general form: I - S cancels).
+    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);
+    // ... and M = u m^T + G S is SYMMETRIC there, so the Cholesky backpropagation collapses: Phi(M) + Phi(M)^T = M gives
+    //   sym(Kbar) = L^-T M L^-1 / 2,   and with Woodbury  S = I - gamma L^T P L,  P = (diag(nu) + gamma (K0 + J I))^-1 :
+    //   L^-T (I - S) L^-1 / gamma = P,   m = gamma L^T P y,   sym(Kbar) = (P - gamma (P y)(P y)^T) / 2.
+    // The hyper-gradient then needs P alone (a factorisation, its triangular inverse, one lower x lower product: N^3) - no
+    // C = chol(Lam), S, Phi, W or Kbar (8/3 N^3).  C itself is only missing when nothing refreshes it before it is used:
+    // the prediction after a single iteration (the general form is kept there) and the loss sample of iteration 0
+    // (refactored for it).
+    const bool woodbury = first && fp.n_iters >= 2;
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.mark("kmat");
     P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
+    if (woodbury) P.tri_scale_diag(nb, Np, ws.Lb, fp.gamma, ws.nu, ws.Cb);   // diag(nu) + gamma (K0 + J I)
     P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
-    if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY);
+    if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) {
+      neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY, c_stale);
+      c_stale = false;
+    }
     P.mark("Lam update");
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
-    // First iteration: the VGP starts at q_mu = 0, q_sqrt = I, i.e. Lam_old = I EXACTLY and theta1_old = 0, so
-    //   Lam = I + gamma G,   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma,
-    //   Lam m = theta1 = gamma L^T (y/nu)  =>  u = L^T D (L m - y) = G m - theta1 / gamma = -m / gamma :
-    // the product's epilogue writes Lam itself (no separate G), and the two full solves that form G S (2 N^3) shrink to the
-    // explicit S = C^-T C^-1 - the triangular inverse (a lower-rhs solve on I, N^3/3) and one lower x lower product (N^3/3).
-    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the solves: I - S cancels)
+    // (first iteration: the product's epilogue writes Lam = I + gamma G itself, no separate G)
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
     if (first) {
       P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 0.0, ws.Lam, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 1.0);
-      P.tri_copy(nb, Np, ws.Lam, ws.Cb);
+      if (!woodbury) P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     } else {
       P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 0.0, ws.T2, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
       P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1);   // Lam, Cb = tril(Lam), T1 = G (full)
     }
     P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
     P.mark("potrf Lam");
-    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)
+    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)   (woodbury: chol(diag(nu) + gamma K))
+    if (woodbury) {
+      P.mark("P = (nu + gamma K)^-1");
+      P.identity(nb, Np, ws.T2);
+      trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);       // triangular inverse (lower)
+      P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 0.0, ws.T1, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);   // P (lower blocks)
+      P.symv_lower(nb, Np, ws.T1, ws.y, ws.avec);                     // p = P y
+      if (fp.loss_trace) P.lt_dvec(nb, Np, ws.Lb, ws.avec, nullptr, fp.gamma, 0.0, ws.mvec);   // m = gamma L^T p, for the sample
+      c_stale = true;                                                 // Cb does not hold chol(Lam)
+      P.mark("grad+adam");
+      P.grad_adam(nb, N, Np, fp.R, X, fp.kernel, ws.T1, ws.ustate, fp.lr, ws.avec, fp.gamma);
+      continue;
+    }
     P.mark("G S solves");
     // G S is all the Adam step (models.py:210) needs of S: for i >= j
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
@@ -353,8 +382,10 @@ double fit_flops(int N, int R, int n_iters) {
   //                Phi L^-1 1/3, W^T L^-1 1  => 13/3 N^3 ; kernel matrix 2 N^2 R
   // first iteration (Lam_old = I: G S = (I - S) / gamma): C^-1 1/3 + C^-T C^-1 1/3 replace the two solves => 3 N^3
   // prediction: chol K 1/3, L^-1 1/3, A^T C^-T 1, L^-T L^-1 1/3, rank-N update 1 => 3 N^3, chol(cov) 1/3
+  // ... and when another iteration follows, the symmetric form: chol K, G, chol(nu + gamma K), its inverse, P => 5/3 N^3
   double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
-  return n_iters * (13.0 / 3.0 * n3 + n2r) - (n_iters > 0 ? 4.0 / 3.0 * n3 : 0.0) + (3.0 * n3 + n2r) + n3 / 3.0;
+  const double first_saves = n_iters >= 2 ? 8.0 / 3.0 * n3 : (n_iters == 1 ? 4.0 / 3.0 * n3 : 0.0);
+  return n_iters * (13.0 / 3.0 * n3 + n2r) - first_saves + (3.0 * n3 + n2r) + n3 / 3.0;
 }
 
 }  // namespace BAYENS_NS

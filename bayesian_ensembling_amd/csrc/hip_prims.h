@@ -91,6 +91,7 @@ struct HipPrims : Prims {
   void potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;
+  void tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) override;
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override;
   void init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
                   const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info) override;
@@ -108,8 +109,8 @@ struct HipPrims : Prims {
   void basis_rows_set(int nb, int N, int Np, Mat rows, const real* mu_pad, int in_padding) override;
   void basis_rows_get(int nb, int N, int Np, Mat rows, real* basis) override;
   void resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) override;
-  void grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate,
-                 double lr) override;
+  void grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr,
+                 const real* pvec = nullptr, double sym_gamma = 0.0) override;
   void gemv_n(int nb, int n, Mat A, const real* x, real* y) override;
   void row_sqsum(int nb, int n, Mat A, real* out) override;
   void elbo_combine(int nb, int N, int Np, const real* a, const real* f, const real* nu, const real* mvec,

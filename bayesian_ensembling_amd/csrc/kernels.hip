@@ -77,6 +77,23 @@ __global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
   for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
 }
 
+// dst = tril(alpha src + diag(d)), zeros above (prims.h tri_scale_diag)
+__global__ void tri_scale_diag_kernel(int n, Mat src, double alpha, const real* dvec, Mat dst) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const real* s = src.p + b * src.stride;
+  real* d = dst.p + b * dst.stride;
+  real v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    v[q] = j > i ? (real)0 : (real)(alpha * (double)s[(long)i * src.ld + j] + (j == i ? (double)dvec[(long)b * n + i] : 0.0));
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
+}
+
 __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
   __shared__ double tile[64][65];
   const int b = blockIdx.z;
@@ -371,7 +388,7 @@ __global__ void xprep_kernel(int N, int Np, int R, int R4, const real* X, const 
 template <bool GRAD>
 __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
                                                    const double* ustate, int kernel, double jitter, Mat Lb,
-                                                   Mat Kbt, double* gpart) {
+                                                   Mat Kbt, double* gpart, const real* pvec, double sym_gamma) {
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -387,7 +404,10 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
         Lb.p[b * Lb.stride + (long)(i0 + lk + 4 * r) * Lb.ld + j0 + jt * 16 + lr] = 0.0;
     return;
   }
-  for (int jt = 0; jt < 4; ++jt) {
+  // GRAD with pvec: the weights are the symmetric (P - sym_gamma p p^T) / 2, P's lower triangle in Kbt: tiles above the
+  // diagonal contribute through their mirror images (pairs counted once, twice the weight)
+  const bool sym = GRAD && pvec != nullptr;
+  for (int jt = 0; jt < ((sym && blockIdx.x > blockIdx.y) ? 0 : 4); ++jt) {
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     for (int kk = 0; kk < R4; kk += 4) {
       const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
@@ -403,8 +423,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
       double K, dK;
       kern_eval(kernel, var, ls, r2, K, dK);
       if (GRAD) {
-        if (i < N && j < N) {
-          const double kb = Kbt.p[b * Kbt.stride + (long)i * Kbt.ld + j];
+        if (i < N && j < N && !(sym && j > i)) {
+          double kb = Kbt.p[b * Kbt.stride + (long)i * Kbt.ld + j];
+          if (sym) {
+            kb -= sym_gamma * (double)pvec[(long)b * Np + i] * (double)pvec[(long)b * Np + j];
+            if (i == j) kb *= 0.5;
+          }
           gv += kb * K;
           gl += kb * dK;
         }
@@ -770,12 +794,12 @@ __global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* 
   for (; i + 12 < n; i += 16) {
     const double a0 = l[(long)i * L.ld + j0 + c], a1 = l[(long)(i + 4) * L.ld + j0 + c];
     const double a2 = l[(long)(i + 8) * L.ld + j0 + c], a3 = l[(long)(i + 12) * L.ld + j0 + c];
-    s0 += a0 * ((double)y[vb + i] / (double)nu[vb + i]);
-    s1 += a1 * ((double)y[vb + i + 4] / (double)nu[vb + i + 4]);
-    s2 += a2 * ((double)y[vb + i + 8] / (double)nu[vb + i + 8]);
-    s3 += a3 * ((double)y[vb + i + 12] / (double)nu[vb + i + 12]);
+    s0 += a0 * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
+    s1 += a1 * ((double)y[vb + i + 4] / (nu ? (double)nu[vb + i + 4] : 1.0));
+    s2 += a2 * ((double)y[vb + i + 8] / (nu ? (double)nu[vb + i + 8] : 1.0));
+    s3 += a3 * ((double)y[vb + i + 12] / (nu ? (double)nu[vb + i + 12] : 1.0));
   }
-  for (; i < n; i += 4) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (double)nu[vb + i]);
+  for (; i < n; i += 4) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
   const double s = (s0 + s1) + (s2 + s3);
   part[w][c] = s;
   __syncthreads();
@@ -1578,6 +1602,10 @@ void HipPrims::tri_copy(int nb, int n, Mat src, Mat dst) {
   hipLaunchKernelGGL(copy_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, dst, 1);
   LAUNCH_CHECK();
 }
+void HipPrims::tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) {
+  hipLaunchKernelGGL(tri_scale_diag_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, alpha, d, dst);
+  LAUNCH_CHECK();
+}
 void HipPrims::transpose_lower(int nb, int n, Mat W, Mat Wt) {
   hipLaunchKernelGGL(transpose_lower_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, W, Wt);
   LAUNCH_CHECK();
@@ -1595,7 +1623,7 @@ void HipPrims::kmat(int nb, int N, int Np, int R, const real* X, const double* u
   ensure_scratch(nb, Np, R4);
   hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq);
   hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
-                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr);
+                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0);
   LAUNCH_CHECK();
 }
 void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) {
@@ -1651,12 +1679,13 @@ void HipPrims::form_phi(int nb, int n, Mat GS, const real* u, const real* mvec, 
   hipLaunchKernelGGL(form_phi_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, GS, u, mvec, Phi, scale, diag_add, u_scale);
   LAUNCH_CHECK();
 }
-void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr) {
+void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt, double* ustate, double lr,
+                         const real* pvec, double sym_gamma) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
   hipLaunchKernelGGL((kmat_kernel<true>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate, kernel,
-                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart);
+                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart, pvec, sym_gamma);
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
   LAUNCH_CHECK();
 }

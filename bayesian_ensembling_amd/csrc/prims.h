@@ -85,6 +85,8 @@ struct Prims {
 
   virtual void copy(int nb, int n, Mat src, Mat dst) = 0;        // full n x n copy
   virtual void tri_copy(int nb, int n, Mat src, Mat dst) = 0;    // dst = tril(src), zeros above
+  // dst = tril(alpha src + diag(d)), zeros above (d: [nb][n])
+  virtual void tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) = 0;
   virtual void transpose_lower(int nb, int n, Mat W, Mat Wt) = 0;  // Wt = tril(W)^T (zeros below diag)
 
   // state initialisation: Lam = I (n x n); theta1 = m = 0; u = softplus^-1(1); adam = 0; y/nu padded
@@ -100,6 +102,7 @@ struct Prims {
 
   virtual void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
   // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)
+  // (nu == nullptr: L^T v)
   virtual void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                        real* out) = 0;
   // natural-gradient precision update from G = L^T D L (lower 64-blocks of G valid):
@@ -133,8 +136,10 @@ struct Prims {
   virtual void resid(int nb, int n, Mat L, const real* mvec, const real* y, real* a) = 0;  // a = L m - y
   // g = <Kbt, dK/dtheta> over the real N x N part (Kbt = Kbar^T; dK symmetric), then one Adam step on
   // the unconstrained hypers.  ustate per member: [u_var, u_ls, m_var, m_ls, v_var, v_ls, t, pad]
+  // With pvec: Kbt holds the lower triangle of a symmetric P and the weight of dK is the symmetric
+  // (P - sym_gamma p p^T) / 2 (off-diagonal pairs counted once with twice the weight; nothing above the diagonal is read).
   virtual void grad_adam(int nb, int N, int Np, int R, const real* X, int kernel, Mat Kbt,
-                         double* ustate, double lr) = 0;
+                         double* ustate, double lr, const real* pvec = nullptr, double sym_gamma = 0.0) = 0;
   // out_i = sum_k A_ik^2 (all n columns)
   virtual void row_sqsum(int nb, int n, Mat A, real* out) = 0;
   // -ELBO of the whitened VGP with the heteroskedastic Gaussian likelihood from its pieces (models.py:142-149,

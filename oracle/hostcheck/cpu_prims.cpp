@@ -119,6 +119,13 @@ struct CpuPrims : Prims {
         for (int j = 0; j < n; ++j)
           dst.p[b * dst.stride + (size_t)i * dst.ld + j] = j <= i ? src.p[b * src.stride + (size_t)i * src.ld + j] : 0.0;
   }
+  void tri_scale_diag(int nb, int n, Mat src, double alpha, const double* d, Mat dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          dst.p[b * dst.stride + (size_t)i * dst.ld + j] =
+              j <= i ? alpha * src.p[b * src.stride + (size_t)i * src.ld + j] + (j == i ? d[(size_t)b * n + i] : 0.0) : 0.0;
+  }
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
@@ -182,7 +189,7 @@ struct CpuPrims : Prims {
     for (int b = 0; b < nb; ++b)
       for (int j = 0; j < n; ++j) {
         double s = 0;
-        for (int i = j; i < n; ++i) s += L.p[b * L.stride + (size_t)i * L.ld + j] * (v[(size_t)b * n + i] / nu[(size_t)b * n + i]);
+        for (int i = j; i < n; ++i) s += L.p[b * L.stride + (size_t)i * L.ld + j] * (v[(size_t)b * n + i] / (nu ? nu[(size_t)b * n + i] : 1.0));
         out[(size_t)b * n + j] = (beta != 0.0 ? beta * out[(size_t)b * n + j] : 0.0) + alpha * s;
       }
   }
@@ -253,8 +260,8 @@ struct CpuPrims : Prims {
         a[(size_t)b * n + i] = s - y[(size_t)b * n + i];
       }
   }
-  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr) override {
-    (void)Np;
+  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr,
+                 const double* pvec, double sym_gamma) override {
     for (int b = 0; b < nb; ++b) {
       double* u = ustate + b * 8;
       double var = softplus(u[0]), ls = softplus(u[1]);
@@ -265,6 +272,11 @@ struct CpuPrims : Prims {
           double K, d;
           kern(kernel, var, ls, r2_of(Xb, R, i, j, ls), K, d);
           double kb = Kbt.p[b * Kbt.stride + (size_t)i * Kbt.ld + j];
+          if (pvec) {   // symmetric weights (P - gamma p p^T) / 2 from P's lower triangle
+            if (j > i) continue;
+            kb -= sym_gamma * pvec[(size_t)b * Np + i] * pvec[(size_t)b * Np + j];
+            if (i == j) kb *= 0.5;
+          }
           gv += kb * K; gl += kb * d;
         }
       gv /= var;
