@@ -596,7 +596,8 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       SYNC();
     };
     // Lb <- tril(K0) + J I (identity in the padding)
-    auto kmat = [&]() {
+    // (with_m: also Cb <- tril(gamma (K0 + J I) + diag(nu)), the matrix whose inverse the first iteration's gradient needs)
+    auto kmat = [&](bool with_m = false) {
       const double var = misc[8], inv_ls2 = misc[10];
 #pragma unroll 1
       for (int p = wave; p < NTT; p += NW) {
@@ -615,6 +616,14 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           kt[r] = (real)K;
         }
         st_tile(Lb + p * TS, o, kt);
+        if (with_m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+            kt[r] = (real)(g.gamma * (double)kt[r] + (row == col ? 1.0 / (double)dv[row] : 0.0));
+          }
+          st_tile(Cb + p * TS, o, kt);
+        }
       }
       SYNC();
     };
@@ -667,8 +676,16 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll 1
     for (int it = 0; it < g.n_iters; ++it) {
       STAMP(0);
+      // First iteration: Lam_old = I exactly and theta1_old = 0, so Lam = I + gamma G, G S = (I - S) / gamma, u = -m / gamma
+      // and M = u m^T + G S is symmetric: Phi(M) + Phi(M)^T = M collapses the Cholesky backpropagation to
+      //   sym(Kbar) = L^-T M L^-1 / 2 = (P - gamma (P y)(P y)^T) / 2,   P = (diag(nu) + gamma (K0 + J I))^-1
+      // (Woodbury: S = I - gamma L^T P L, m = gamma L^T P y) - no C, S, Phi, W or Kbar in that iteration (csrc/driver.cpp has
+      // the same form).  Kept to the general form when C itself is needed: a single iteration (the prediction uses it), the loss
+      // sample of iteration 0; and in fp32 (I - S cancels).
+      const bool first = it == 0 && g.gamma > 0.0 && sizeof(real) == sizeof(double);
+      const bool wb = first && g.n_iters >= 2 && !g.loss;
       refresh_hypers();
-      kmat();                                                              // K0 + J I at the current hypers  (models.py:209)
+      kmat(wb);                                                            // K0 + J I at the current hypers  (models.py:209)
       STAMP(1);
       // L = chol(K0 + J I); G = L^T D L = sum_k (D^1/2 L)_k*^T (D^1/2 L)_k* is accumulated block row by block row behind
       // the factorisation (registers gt[], tiles dealt over waves 1..7)
@@ -691,7 +708,8 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           }
         }
       };
-      bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, g_rows);      // L in Lb, L^-1 rides along into Wb
+      if (wb) bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, g_rows);  // (nothing in that iteration uses L^-1)
+      else bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, g_rows);  // L in Lb, L^-1 rides along into Wb
       if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
       STAMP(2);
       // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
@@ -704,7 +722,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             lam[s][r] = (real)((1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0)));
-          st_tile(Cb + p * TS, o, lam[s]);
+          if (!wb) st_tile(Cb + p * TS, o, lam[s]);
         }
       }
 #pragma unroll 1
@@ -718,7 +736,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       SYNC();
       STAMP(3);
       // C = chol(Lam) in Cb, C^-1 in Lb; S = C^-T C^-1 = sum_k (C^-1)_k*^T (C^-1)_k* accumulated behind it (registers st[])
-      const bool first = it == 0 && g.gamma > 0.0 && sizeof(real) == sizeof(double);   // (fp32 keeps the product: I - S cancels)
+      // (wb: the same for diag(nu) + gamma K - its factor, its inverse factor, and P in st[])
       v4r st[TPW];
 #pragma unroll
       for (int s = 0; s < TPW; ++s) st[s] = v4r{0, 0, 0, 0};
@@ -754,6 +772,14 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       }
       SYNC();
       STAMP(5);
+      if (wb) {                                                             // p = P y -> uv
+#pragma unroll 1
+        for (int i = wave; i < NT; i += NW) {
+          const double s = mv_sym<NT>(Cb, yv, i, o);
+          if (o.lk == 0) uv[16 * i + o.lr] = (vecr)s;
+        }
+        SYNC();
+      } else {
       // ---- m = S theta1 ; u = L^T D (L m - y) = G m - L^T (y / nu)
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
@@ -825,6 +851,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         if (p < NTT) st_tile(Lb + p * TS, o, st[s]);
       }
       SYNC();
+      }   // !wb
       STAMP(9);
       // ---- Kbar = L^-T W (L^-1 in Wb, W in Lb) ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric, so
       // the tiles (i, j) and (j, i) of Kbar meet the same kernel values: Kbar_ij and Kbar_ji^T = sum_k W_ki^T Linv_kj
@@ -837,11 +864,19 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           int i, j;
           unpack_lower(p, i, j);
           v4r acc = {0, 0, 0, 0};
-          acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                        [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
-          if (i != j)
-            acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
-                          [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+          if (wb) {                    // the symmetric weights: (P - gamma p p^T) / 2 for the tile and its mirror image together
+            acc = ld_tile(Cb + p * TS, o);
+            const double f = i == j ? 0.5 : 1.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[r] = (real)(f * ((double)acc[r] - g.gamma * (double)uv[16 * i + o.kq[r]] * (double)uv[16 * j + o.lr]));
+          } else {
+            acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
+            if (i != j)
+              acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
+                            [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+          }
           const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
