@@ -211,8 +211,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     // First iteration: the VGP starts at q_mu = 0, q_sqrt = I, i.e. Lam_old = I EXACTLY and theta1_old = 0, so
     //   Lam = I + gamma G,   G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma,
     //   Lam m = theta1 = gamma L^T (y/nu)  =>  u = L^T D (L m - y) = G m - theta1 / gamma = -m / gamma
-    // (fp32 keeps the general form: I - S cancels).
-    const bool first = it == 0 && fp.gamma > 0.0 && sizeof(real) == sizeof(double);
+    // (used for a single iteration in fp64; fp32 keeps the general form there: I - S cancels).
+    const bool it0 = it == 0 && fp.gamma > 0.0;
     // ... and M = u m^T + G S is SYMMETRIC there, so the Cholesky backpropagation collapses: Phi(M) + Phi(M)^T = M gives
     //   sym(Kbar) = L^-T M L^-1 / 2,   and with Woodbury  S = I - gamma L^T P L,  P = (diag(nu) + gamma (K0 + J I))^-1 :
     //   L^-T (I - S) L^-1 / gamma = P,   m = gamma L^T P y,   sym(Kbar) = (P - gamma (P y)(P y)^T) / 2.
@@ -220,7 +220,9 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     // C = chol(Lam), S, Phi, W or Kbar (8/3 N^3).  C itself is only missing when nothing refreshes it before it is used:
     // the prediction after a single iteration (the general form is kept there) and the loss sample of iteration 0
     // (refactored for it).
-    const bool woodbury = first && fp.n_iters >= 2;
+    const bool woodbury = it0 && fp.n_iters >= 2;
+    const bool first = it0 && !woodbury && sizeof(real) == sizeof(double);
+    const bool lam_direct = woodbury || first;
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.mark("kmat");
     P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
@@ -235,7 +237,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     // natural-gradient step:  G = L^T D L ;  Lam <- (1-g) Lam + g (I + G),  theta1 <- (1-g) theta1 + g L^T D y
     // (first iteration: the product's epilogue writes Lam = I + gamma G itself, no separate G)
     P.scale_rows_rsqrt(nb, Np, ws.Lb, ws.nu, ws.T1);                 // W = D^1/2 L
-    if (first) {
+    if (lam_direct) {
       P.gemm(nb, Np, Np, Np, fp.gamma, ws.T1, ws.T1, 0.0, ws.Lam, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 1.0);
       if (!woodbury) P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     } else {

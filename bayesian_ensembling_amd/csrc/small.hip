@@ -681,9 +681,9 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       //   sym(Kbar) = L^-T M L^-1 / 2 = (P - gamma (P y)(P y)^T) / 2,   P = (diag(nu) + gamma (K0 + J I))^-1
       // (Woodbury: S = I - gamma L^T P L, m = gamma L^T P y) - no C, S, Phi, W or Kbar in that iteration (csrc/driver.cpp has
       // the same form).  Kept to the general form when C itself is needed: a single iteration (the prediction uses it), the loss
-      // sample of iteration 0; and in fp32 (I - S cancels).
+      // sample of iteration 0 (there fp64 still takes G S = (I - S) / gamma from the S tiles; fp32 does not: I - S cancels).
+      const bool wb = it == 0 && g.gamma > 0.0 && g.n_iters >= 2 && !g.loss;
       const bool first = it == 0 && g.gamma > 0.0 && sizeof(real) == sizeof(double);
-      const bool wb = first && g.n_iters >= 2 && !g.loss;
       refresh_hypers();
       kmat(wb);                                                            // K0 + J I at the current hypers  (models.py:209)
       STAMP(1);

@@ -138,7 +138,10 @@ def test_loss_trace_is_the_references_training_loss(ctx, M, N, T):
     plain = ctx.gp_fit_batch(X, y, nu, T)
     assert plain["loss"] is None and out["loss"].shape == (M, (T + 24) // 25)
     for k in ("mu", "cov", "chol", "logdet", "hyp"):
-        assert np.array_equal(out[k], plain[k]), k
+        # bit for bit in the general path (the sample refactors C on the side).  The fused kernels (N <= 254) keep the first
+        # iteration in its general form when the sample of iteration 0 needs C and S: the same numbers through another
+        # (algebraically identical) route, equal to rounding
+        assert np.array_equal(out[k], plain[k]) or (N <= 254 and T >= 2 and relerr(out[k], plain[k]) < 1e-11), k
     with threadpool_limits(1):
         for m in range(M):
             ref = go.gp_fit(X[m], y[m], nu[m], T, loss_every=25)[3]
