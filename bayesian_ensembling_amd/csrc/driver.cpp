@@ -196,7 +196,10 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
             real* basis) {
   const int nb = ws.nb, Np = ws.Np, N = fp.N;
   const long is = ws.inv_stride();
-  P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info);
+  // (Lam = I is only stored when something reads it: no iteration, or a first iteration in the general form)
+  const bool lam_written_first = fp.n_iters >= 2 || (fp.n_iters == 1 && sizeof(real) == sizeof(double));
+  P.init_state(nb, N, Np, ws.Lam, ws.theta1, ws.mvec, ws.ustate, y_in, nu_in, ws.y, ws.nu, ws.info,
+               !(fp.gamma > 0.0 && lam_written_first));
 
   if (fp.n_iters == 0) {   // q(v) stays at its initial N(0, I): C = chol(I)
     P.tri_copy(nb, Np, ws.Lam, ws.Cb);
@@ -225,8 +228,10 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     const bool lam_direct = woodbury || first;
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.mark("kmat");
-    P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
-    if (woodbury) P.tri_scale_diag(nb, Np, ws.Lb, fp.gamma, ws.nu, ws.Cb);   // diag(nu) + gamma (K0 + J I)
+    // (the blocks above the block diagonal of Lb are cleared by the first call of the fit and stay clear; woodbury: the same
+    //  pass leaves diag(nu) + gamma (K0 + J I) in Cb)
+    if (woodbury) P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0, ws.Cb, fp.gamma, ws.nu);
+    else P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0);
     P.mark("potrf K");
     potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
     if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) {
@@ -294,7 +299,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
-  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb);
+  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, fp.n_iters == 0);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
   if (fp.loss_trace && fp.n_iters > 0 && (fp.n_iters - 1) % LOSS_EVERY == 0)
     neg_elbo(P, ws, fp, (fp.n_iters - 1) / LOSS_EVERY);

@@ -91,12 +91,12 @@ struct HipPrims : Prims {
   void potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;
-  void tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) override;
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override;
   void init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
-                  const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info) override;
+                  const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info, bool lam_identity = true) override;
   void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
-            Mat Lb) override;
+            Mat Lb, bool clear_upper = true, Mat Mb = Mat{nullptr, 0, 0}, double m_scale = 0.0,
+            const real* m_diag = nullptr) override;
   void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) override;
   void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                real* out) override;

@@ -77,23 +77,6 @@ __global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
   for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
 }
 
-// dst = tril(alpha src + diag(d)), zeros above (prims.h tri_scale_diag)
-__global__ void tri_scale_diag_kernel(int n, Mat src, double alpha, const real* dvec, Mat dst) {
-  const int b = blockIdx.z;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
-  const real* s = src.p + b * src.stride;
-  real* d = dst.p + b * dst.stride;
-  real v[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = i0 + 4 * q;
-    v[q] = j > i ? (real)0 : (real)(alpha * (double)s[(long)i * src.ld + j] + (j == i ? (double)dvec[(long)b * n + i] : 0.0));
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
-}
-
 __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
   __shared__ double tile[64][65];
   const int b = blockIdx.z;
@@ -388,7 +371,8 @@ __global__ void xprep_kernel(int N, int Np, int R, int R4, const real* X, const 
 template <bool GRAD>
 __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
                                                    const double* ustate, int kernel, double jitter, Mat Lb,
-                                                   Mat Kbt, double* gpart, const real* pvec, double sym_gamma) {
+                                                   Mat Kbt, double* gpart, const real* pvec, double sym_gamma,
+                                                   int clear_upper, Mat Mb, double m_scale, const real* m_diag) {
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -398,6 +382,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   const double* sb = ssq + (long)b * Np;
   double gv = 0.0, gl = 0.0;
   if (!GRAD && blockIdx.x > blockIdx.y) {   // tiles above the diagonal of the lower image: zeros, no kernel evaluation
+    if (!clear_upper) return;
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -434,7 +419,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
         }
       } else {
         if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
-        Lb.p[b * Lb.stride + (long)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+        const double kj = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+        Lb.p[b * Lb.stride + (long)i * Lb.ld + j] = kj;
+        if (Mb.p) Mb.p[b * Mb.stride + (long)i * Mb.ld + j] = m_scale * kj + (i == j ? (double)m_diag[(long)b * Np + i] : 0.0);
       }
     }
   }
@@ -780,9 +767,11 @@ __global__ __launch_bounds__(256, 2) void potrf_leaf2_kernel(Mat Ablk, real* inv
 // ------------------------------------------------------------------------------------------------
 // out = beta out + alpha L^T (v/nu): one workgroup per 64 columns; lanes = columns (512-byte coalesced row
 // segments), the 4 waves split the rows i >= j0 (L is lower triangular).
-__global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* y, const real* nu, double alpha,
-                                                      double beta, real* theta1) {
-  __shared__ double part[4][64];
+// (16 waves: the strip of column block 0 is n rows long and one workgroup's loads in flight bound its rate)
+constexpr int LTD_WAVES = 16;
+__global__ __launch_bounds__(64 * LTD_WAVES) void lt_dvec_kernel(int n, Mat L, const real* y, const real* nu, double alpha,
+                                                                 double beta, real* theta1) {
+  __shared__ double part[LTD_WAVES][64];
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const real* l = L.p + b * L.stride;
@@ -790,21 +779,24 @@ __global__ __launch_bounds__(256) void lt_dvec_kernel(int n, Mat L, const real* 
   // one row per wave and trip leaves the load latency exposed)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const long vb = (long)b * n;
+  constexpr int W = LTD_WAVES;
   int i = j0 + w;
-  for (; i + 12 < n; i += 16) {
-    const double a0 = l[(long)i * L.ld + j0 + c], a1 = l[(long)(i + 4) * L.ld + j0 + c];
-    const double a2 = l[(long)(i + 8) * L.ld + j0 + c], a3 = l[(long)(i + 12) * L.ld + j0 + c];
+  for (; i + 3 * W < n; i += 4 * W) {
+    const double a0 = l[(long)i * L.ld + j0 + c], a1 = l[(long)(i + W) * L.ld + j0 + c];
+    const double a2 = l[(long)(i + 2 * W) * L.ld + j0 + c], a3 = l[(long)(i + 3 * W) * L.ld + j0 + c];
     s0 += a0 * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
-    s1 += a1 * ((double)y[vb + i + 4] / (nu ? (double)nu[vb + i + 4] : 1.0));
-    s2 += a2 * ((double)y[vb + i + 8] / (nu ? (double)nu[vb + i + 8] : 1.0));
-    s3 += a3 * ((double)y[vb + i + 12] / (nu ? (double)nu[vb + i + 12] : 1.0));
+    s1 += a1 * ((double)y[vb + i + W] / (nu ? (double)nu[vb + i + W] : 1.0));
+    s2 += a2 * ((double)y[vb + i + 2 * W] / (nu ? (double)nu[vb + i + 2 * W] : 1.0));
+    s3 += a3 * ((double)y[vb + i + 3 * W] / (nu ? (double)nu[vb + i + 3 * W] : 1.0));
   }
-  for (; i < n; i += 4) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
+  for (; i < n; i += W) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
   const double s = (s0 + s1) + (s2 + s3);
   part[w][c] = s;
   __syncthreads();
   if (w == 0) {
-    const double tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) tot += part[q][c];
     real* t = theta1 + (long)b * n + j0 + c;
     *t = (beta != 0.0 ? beta * (*t) : 0.0) + alpha * tot;
   }
@@ -1602,28 +1594,25 @@ void HipPrims::tri_copy(int nb, int n, Mat src, Mat dst) {
   hipLaunchKernelGGL(copy_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, dst, 1);
   LAUNCH_CHECK();
 }
-void HipPrims::tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) {
-  hipLaunchKernelGGL(tri_scale_diag_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, src, alpha, d, dst);
-  LAUNCH_CHECK();
-}
 void HipPrims::transpose_lower(int nb, int n, Mat W, Mat Wt) {
   hipLaunchKernelGGL(transpose_lower_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, W, Wt);
   LAUNCH_CHECK();
 }
 void HipPrims::init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
-                          const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info) {
-  hipLaunchKernelGGL(fill_identity_kernel, tile_grid(Np, nb), dim3(256), 0, stream, Np, Lam);
+                          const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info, bool lam_identity) {
+  if (lam_identity) hipLaunchKernelGGL(fill_identity_kernel, tile_grid(Np, nb), dim3(256), 0, stream, Np, Lam);
   hipLaunchKernelGGL(init_vec_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, nb, N, Np, theta1, mvec,
                      ustate, y_in, nu_in, y_pad, nu_pad, info);
   LAUNCH_CHECK();
 }
 void HipPrims::kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
-                    Mat Lb) {
+                    Mat Lb, bool clear_upper, Mat Mb, double m_scale, const real* m_diag) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq);
   hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
-                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0);
+                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0, clear_upper ? 1 : 0, Mb,
+                     m_scale, m_diag);
   LAUNCH_CHECK();
 }
 void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) {
@@ -1631,7 +1620,7 @@ void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst)
   LAUNCH_CHECK();
 }
 void HipPrims::lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta, real* out) {
-  hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, L, v, nu, alpha, beta, out);
+  hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(64 * LTD_WAVES), 0, stream, n, L, v, nu, alpha, beta, out);
   LAUNCH_CHECK();
 }
 void HipPrims::symv_lower(int nb, int n, Mat S, const real* v, real* out) {
@@ -1685,7 +1674,7 @@ void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel
   ensure_scratch(nb, Np, R4);
   // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
   hipLaunchKernelGGL((kmat_kernel<true>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate, kernel,
-                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart, pvec, sym_gamma);
+                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart, pvec, sym_gamma, 1, Mat{nullptr, 0, 0}, 0.0, (const real*)nullptr);
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
   LAUNCH_CHECK();
 }

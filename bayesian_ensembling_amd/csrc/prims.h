@@ -85,20 +85,22 @@ struct Prims {
 
   virtual void copy(int nb, int n, Mat src, Mat dst) = 0;        // full n x n copy
   virtual void tri_copy(int nb, int n, Mat src, Mat dst) = 0;    // dst = tril(src), zeros above
-  // dst = tril(alpha src + diag(d)), zeros above (d: [nb][n])
-  virtual void tri_scale_diag(int nb, int n, Mat src, double alpha, const real* d, Mat dst) = 0;
   virtual void transpose_lower(int nb, int n, Mat W, Mat Wt) = 0;  // Wt = tril(W)^T (zeros below diag)
 
   // state initialisation: Lam = I (n x n); theta1 = m = 0; u = softplus^-1(1); adam = 0; y/nu padded
+  // (lam_identity = false: Lam is left alone - the first natural-gradient step writes it without reading it)
   virtual void init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mvec, double* ustate,
                           const real* y_in, const real* nu_in, real* y_pad, real* nu_pad,
-                          int* info) = 0;
+                          int* info, bool lam_identity = true) = 0;
 
   // Lb = tril(K0) + jitter*I (zeros above the diagonal; identity in the padded part) from the current hypers
   // softplus(ustate[b][0..1]).  X is [nb][N][R] compact.  K0 itself is never stored: the prediction uses
   // K0 = L L^T - jitter*I (driver.cpp) and the hyper-gradient re-evaluates the kernel (grad_adam).
+  // clear_upper = false: the 64x64 blocks above the block diagonal are not written (they hold zeros from an earlier call).
+  // With Mb: also Mb = tril(m_scale (K0 + jitter*I) + diag(m_diag)) on the blocks on and below the block diagonal.
   virtual void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel,
-                    double jitter, Mat Lb) = 0;
+                    double jitter, Mat Lb, bool clear_upper = true, Mat Mb = Mat{nullptr, 0, 0}, double m_scale = 0.0,
+                    const real* m_diag = nullptr) = 0;
 
   virtual void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
   // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)

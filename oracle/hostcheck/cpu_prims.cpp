@@ -119,13 +119,6 @@ struct CpuPrims : Prims {
         for (int j = 0; j < n; ++j)
           dst.p[b * dst.stride + (size_t)i * dst.ld + j] = j <= i ? src.p[b * src.stride + (size_t)i * src.ld + j] : 0.0;
   }
-  void tri_scale_diag(int nb, int n, Mat src, double alpha, const double* d, Mat dst) override {
-    for (int b = 0; b < nb; ++b)
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j)
-          dst.p[b * dst.stride + (size_t)i * dst.ld + j] =
-              j <= i ? alpha * src.p[b * src.stride + (size_t)i * src.ld + j] + (j == i ? d[(size_t)b * n + i] : 0.0) : 0.0;
-  }
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
@@ -133,11 +126,12 @@ struct CpuPrims : Prims {
           Wt.p[b * Wt.stride + (size_t)i * Wt.ld + j] = j >= i ? W.p[b * W.stride + (size_t)j * W.ld + i] : 0.0;
   }
   void init_state(int nb, int N, int Np, Mat Lam, double* theta1, double* mvec, double* ustate,
-                  const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info) override {
+                  const double* y_in, const double* nu_in, double* y_pad, double* nu_pad, int* info, bool lam_identity) override {
     const double u0 = std::log(std::exp(1.0) - 1.0);
     for (int b = 0; b < nb; ++b) {
       for (int i = 0; i < Np; ++i) {
-        for (int j = 0; j < Np; ++j) Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j] = i == j ? 1.0 : 0.0;
+        // (left alone: poisoned here, so that a driver that read it would be caught)
+        for (int j = 0; j < Np; ++j) Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j] = lam_identity ? (i == j ? 1.0 : 0.0) : NAN;
         theta1[(size_t)b * Np + i] = 0; mvec[(size_t)b * Np + i] = 0;
         y_pad[(size_t)b * Np + i] = i < N ? y_in[(size_t)b * N + i] : 0.0;
         nu_pad[(size_t)b * Np + i] = i < N ? nu_in[(size_t)b * N + i] : 1.0;
@@ -165,7 +159,7 @@ struct CpuPrims : Prims {
     return (-2.0 * g + si) + sj;
   }
   void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
-            Mat Lb) override {
+            Mat Lb, bool clear_upper, Mat Mb, double m_scale, const double* m_diag) override {
     for (int b = 0; b < nb; ++b) {
       double var = softplus(ustate[b * 8 + 0]), ls = softplus(ustate[b * 8 + 1]);
       const double* Xb = X + (size_t)b * N * R;
@@ -174,7 +168,10 @@ struct CpuPrims : Prims {
           double K, d;
           if (i < N && j < N) kern(kernel, var, ls, r2_of(Xb, R, i, j, ls), K, d);
           else K = i == j ? 1.0 : 0.0;
-          Lb.p[b * Lb.stride + (size_t)i * Lb.ld + j] = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+          if (!clear_upper && j / LEAF > i / LEAF) continue;
+          const double kj = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+          Lb.p[b * Lb.stride + (size_t)i * Lb.ld + j] = kj;
+          if (Mb.p && j / LEAF <= i / LEAF) Mb.p[b * Mb.stride + (size_t)i * Mb.ld + j] = m_scale * kj + (i == j ? m_diag[(size_t)b * Np + i] : 0.0);
         }
     }
   }
