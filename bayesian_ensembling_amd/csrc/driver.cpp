@@ -233,7 +233,17 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     if (woodbury) P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0, ws.Cb, fp.gamma, ws.nu);
     else P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0);
     P.mark("potrf K");
-    potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    // woodbury: K0 + J I and diag(nu) + gamma (K0 + J I) factor as ONE batch of 2 nb members (Lb and Cb are interleaved member by
+    // member, FitWorkspace::paired): the factorisation is bound by its chain of small kernels, not by its flop, and the
+    // chain is as long for 2 nb members as for nb
+    static const bool no_pair = std::getenv("BAYENS_NO_PAIR") != nullptr;   // (measurement switch)
+    const bool pair = woodbury && ws.paired() && !no_pair;
+    if (pair) {
+      potrf(P, 2 * nb, Np, Mat{ws.Lb.p, ws.Lb.ld, ws.Lb.stride / 2}, ws.invL, is / 2, ws.info_pair);
+      P.info_fold(nb, ws.info_pair, ws.info);
+    } else {
+      potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
+    }
     if (fp.loss_trace && it > 0 && (it - 1) % LOSS_EVERY == 0) {
       neg_elbo(P, ws, fp, (it - 1) / LOSS_EVERY, c_stale);
       c_stale = false;
@@ -251,7 +261,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     }
     P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
     P.mark("potrf Lam");
-    potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);                    // C = chol(Lam)   (woodbury: chol(diag(nu) + gamma K))
+    if (!pair) potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);         // C = chol(Lam)   (woodbury: chol(diag(nu) + gamma K))
     if (woodbury) {
       P.mark("P = (nu + gamma K)^-1");
       P.identity(nb, Np, ws.T2);

@@ -32,7 +32,16 @@ struct FitWorkspace {
   double* ustate = nullptr;        // [nb][8]
   double* dscratch = nullptr;      // [nb][4] double scalars (log-determinant / trace pieces of the loss)
   int* info = nullptr;             // [nb]
-  long inv_stride() const { return (long)Np * LEAF; }
+  // Lb / Cb (and invL / invC) are INTERLEAVED member by member: Cb.p = Lb.p + Lb.stride / 2, invC = invL + inv_stride() / 2,
+  // so that the pair (K, diag(nu) + gamma K) of the first iteration factors as ONE batch of 2 nb members at half the stride
+  // (driver.cpp); info_pair: [2 nb] pivot reports of that batch, folded into info.
+  int* info_pair = nullptr;
+  long inv_step = 0;               // stride between members of invL (and of invC); 0: the compact Np * LEAF
+  long inv_stride() const { return inv_step ? inv_step : (long)Np * LEAF; }
+  bool paired() const {
+    return info_pair && Lb.stride % 2 == 0 && Cb.p == Lb.p + Lb.stride / 2 && Cb.stride == Lb.stride && Cb.ld == Lb.ld &&
+           inv_stride() % 2 == 0 && invC == invL + inv_stride() / 2;
+  }
 };
 
 // Blocked Cholesky (lower, in place) of the n x n matrices A; inv receives the inverted diagonal blocks

@@ -121,6 +121,7 @@ struct HipPrims : Prims {
   void extract(int nb, int N, Mat src, real* dst, int mode) override;
   void extract_vec(int nb, int N, int Np, const real* src, real* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
+  void info_fold(int nb, int* pair, int* info) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;
   void frob_normalise(int nb, int n, Mat M, Mat X, const double* cap = nullptr, double cap_scale = 0.0) override;
   void axpby_rel(int nb, int n, double a, Mat X, double b, Mat T, double* rel) override;

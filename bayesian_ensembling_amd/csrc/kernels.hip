@@ -341,6 +341,15 @@ __global__ void hyp_out_kernel(int nb, const double* ustate, double* hyp) {
   }
 }
 
+__global__ void info_fold_kernel(int nb, int* pair, int* info) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const int p0 = pair[2 * b], p1 = pair[2 * b + 1];
+  if (info[b] == 0) info[b] = p0 ? p0 : p1;
+  pair[2 * b] = 0;
+  pair[2 * b + 1] = 0;
+}
+
 __global__ void extract_diag_kernel(int N, const double* cov, double* var) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1711,6 +1720,10 @@ void HipPrims::extract(int nb, int N, Mat src, real* dst, int mode) {
 }
 void HipPrims::extract_vec(int nb, int N, int Np, const real* src, real* dst) {
   hipLaunchKernelGGL(extract_vec_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::info_fold(int nb, int* pair, int* info) {
+  hipLaunchKernelGGL(info_fold_kernel, dim3((nb + 63) / 64), dim3(64), 0, stream, nb, pair, info);
   LAUNCH_CHECK();
 }
 void HipPrims::logdet(int nb, int N, Mat Lc, double* out) {

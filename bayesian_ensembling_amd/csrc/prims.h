@@ -163,6 +163,8 @@ struct Prims {
   virtual void extract(int nb, int N, Mat src, real* dst, int mode) = 0;
   virtual void extract_vec(int nb, int N, int Np, const real* src, real* dst) = 0;
   virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii
+  // info[b] = its own non-zero value, else the first non-zero of pair[2b], pair[2b+1]; pair is cleared
+  virtual void info_fold(int nb, int* pair, int* info) = 0;
   virtual void hyp_out(int nb, const double* ustate, double* hyp) = 0;  // softplus(u) -> (variance, lengthscale)
 
   // ---- pieces of the full-covariance Wasserstein distance (polar iteration on L_j^T L_i) ----

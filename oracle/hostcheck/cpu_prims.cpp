@@ -385,6 +385,12 @@ struct CpuPrims : Prims {
     }
   }
   void read_back(const double* dev, double* host, int n) override { std::memcpy(host, dev, n * sizeof(double)); }
+  void info_fold(int nb, int* pair, int* info) override {
+    for (int b = 0; b < nb; ++b) {
+      if (info[b] == 0) info[b] = pair[2 * b] ? pair[2 * b] : pair[2 * b + 1];
+      pair[2 * b] = pair[2 * b + 1] = 0;
+    }
+  }
   void hyp_out(int nb, const double* ustate, double* hyp) override {
     for (int b = 0; b < nb; ++b) { hyp[b * 2] = softplus(ustate[b * 8]); hyp[b * 2 + 1] = softplus(ustate[b * 8 + 1]); }
   }
@@ -393,21 +399,25 @@ struct CpuPrims : Prims {
 struct HostWs {
   FitWorkspace ws;
   std::vector<std::vector<double>> bufs;
-  std::vector<int> info;
+  std::vector<int> info, info_pair;
   // poisoned with NaN: any read of a region the driver never wrote shows up as a NaN in the result
   double* alloc(size_t n) { bufs.emplace_back(n, std::nan("")); return bufs.back().data(); }
   HostWs(int nb, int Np) {
     ws.nb = nb; ws.Np = Np;
     auto mat = [&]() { return Mat{alloc((size_t)nb * Np * Np), Np, (long)Np * Np}; };
-    ws.W0 = mat(); ws.Lb = mat(); ws.Lam = mat(); ws.Cb = mat(); ws.T2 = mat();
+    ws.W0 = mat(); ws.Lam = mat(); ws.T2 = mat();
+    double* lc = alloc((size_t)2 * nb * Np * Np);        // Lb and Cb interleaved member by member, as on the device (fit_ws.h)
+    ws.Lb = Mat{lc, Np, 2L * Np * Np};
+    ws.Cb = Mat{lc + (long)Np * Np, Np, 2L * Np * Np};
     ws.T1 = Mat{alloc((size_t)nb * (Np + LEAF) * Np), Np, (long)(Np + LEAF) * Np};
-    ws.invL = alloc((size_t)nb * Np * LEAF); ws.invC = alloc((size_t)nb * Np * LEAF);
+    ws.invL = alloc((size_t)2 * nb * Np * LEAF); ws.invC = ws.invL + (long)Np * LEAF; ws.inv_step = 2L * Np * LEAF;
     ws.theta1 = alloc((size_t)nb * Np); ws.mvec = alloc((size_t)nb * Np); ws.avec = alloc((size_t)nb * Np);
     ws.y = alloc((size_t)nb * Np); ws.nu = alloc((size_t)nb * Np); ws.muvec = alloc((size_t)nb * Np);
     ws.uvec = alloc((size_t)nb * Np);
     ws.ustate = alloc((size_t)nb * 8);
     ws.dscratch = alloc((size_t)nb * 4);
     info.assign(nb, 0); ws.info = info.data();
+    info_pair.assign(2 * nb, 0); ws.info_pair = info_pair.data();
   }
 };
 
