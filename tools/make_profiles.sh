@@ -54,4 +54,6 @@ python3 tools/rocpd_stats.py $(find $OUT/${TAG}_ktm -name "*.db" | head -1) $OUT
 python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pmm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util_n165.txt > /dev/null
 rm -rf $OUT/${TAG}_ktm $OUT/${TAG}_pmm
 timeout -k 10 300 python3 tools/api_path_c5.py > $OUT/${TAG}_api_path_c5.json 2> /dev/null || exit 17
+# the blocked triangular solves alone (panel launch, recursion, triangular inverse) and the factorisation against its batch size
+(timeout -k 10 200 python3 tools/trsm_bench.py; timeout -k 10 200 python3 tools/potrf_batch.py) > $OUT/${TAG}_trsm_potrf_bench.txt 2>&1 || exit 18
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
