@@ -366,6 +366,11 @@ __global__ void xprep_kernel(int N, int Np, int R, int R4, const real* X, const 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Np) return;
   const double ls = softplus_d(ustate[b * 8 + 1]);
+  if (i == 0) {   // (variance, lengthscale) of this member behind the squared norms: the tile kernels read them instead of
+    double* vl = ssq + (long)gridDim.y * Np + 2 * b;   // evaluating softplus in every thread of every workgroup
+    vl[0] = softplus_d(ustate[b * 8]);
+    vl[1] = ls;
+  }
   double s = 0.0;
   for (int d = 0; d < R4; ++d) {
     double v = (i < N && d < R) ? X[((long)b * N + i) * R + d] / ls : 0.0;
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int i0 = blockIdx.y * 64 + wave * 16, j0 = blockIdx.x * 64;
-  const double var = softplus_d(ustate[b * 8]), ls = softplus_d(ustate[b * 8 + 1]);
+  const double* vl = ssq + (long)gridDim.z * Np + 2 * b;    // written by xprep_kernel
+  const double var = vl[0], ls = vl[1];
   const double* xb = xs + (long)b * Np * R4;
   const double* sb = ssq + (long)b * Np;
   double gv = 0.0, gl = 0.0;
@@ -401,7 +407,26 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   // GRAD with pvec: the weights are the symmetric (P - sym_gamma p p^T) / 2, P's lower triangle in Kbt: tiles above the
   // diagonal contribute through their mirror images (pairs counted once, twice the weight)
   const bool sym = GRAD && pvec != nullptr;
-  for (int jt = 0; jt < ((sym && blockIdx.x > blockIdx.y) ? 0 : 4); ++jt) {
+  const int njt = (sym && blockIdx.x > blockIdx.y) ? 0 : 4;
+  // the weights of this thread's 16 elements are requested up front (inside the guarded accumulation below every load
+  // would be issued, and waited for, on its own); the padded rows / columns are valid memory and are masked by a select
+  double kbv[4][4], pi[4] = {0, 0, 0, 0}, pj[4] = {0, 0, 0, 0};
+  if (GRAD && njt) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbv[jt][r] = Kbt.p[b * Kbt.stride + (long)(i0 + lk + 4 * r) * Kbt.ld + j0 + jt * 16 + lr];
+    if (sym) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pi[q] = pvec[(long)b * Np + i0 + lk + 4 * q];
+        pj[q] = pvec[(long)b * Np + j0 + q * 16 + lr];
+      }
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    if (jt >= njt) break;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     for (int kk = 0; kk < R4; kk += 4) {
       const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
@@ -417,15 +442,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
       double K, dK;
       kern_eval(kernel, var, ls, r2, K, dK);
       if (GRAD) {
-        if (i < N && j < N && !(sym && j > i)) {
-          double kb = Kbt.p[b * Kbt.stride + (long)i * Kbt.ld + j];
-          if (sym) {
-            kb -= sym_gamma * (double)pvec[(long)b * Np + i] * (double)pvec[(long)b * Np + j];
-            if (i == j) kb *= 0.5;
-          }
-          gv += kb * K;
-          gl += kb * dK;
+        double kb = kbv[jt][r];
+        if (sym) {
+          kb = fma(-sym_gamma * pi[r], pj[jt], kb);
+          kb = i == j ? 0.5 * kb : kb;
         }
+        const bool use = i < N && j < N && !(sym && j > i);
+        gv = fma(use ? kb : 0.0, use ? K : 0.0, gv);
+        gl = fma(use ? kb : 0.0, use ? dK : 0.0, gl);
       } else {
         if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
         const double kj = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
@@ -1579,7 +1603,7 @@ void HipPrims::mark(const char* phase) {
 
 void HipPrims::ensure_scratch(int nb, int Np, int R4) {
   size_t need_xs = (size_t)nb * Np * R4 * sizeof(double);
-  size_t need_s = (size_t)nb * Np * sizeof(double);
+  size_t need_s = (size_t)nb * (Np + 2) * sizeof(double);   // squared norms, then (variance, lengthscale) per member
   size_t need_g = (size_t)nb * (Np / 64) * (Np / 64) * 2 * sizeof(double);
   if (need_xs > xs_cap) { if (xs) BAYENS_HIP(hipFree(xs)); BAYENS_HIP(hipMalloc(&xs, need_xs)); xs_cap = need_xs; }
   if (need_s > ssq_cap) { if (ssq) BAYENS_HIP(hipFree(ssq)); BAYENS_HIP(hipMalloc(&ssq, need_s)); ssq_cap = need_s; }
