@@ -41,8 +41,13 @@ with threadpool_limits(4):
                 errs["loss"] = max(errs["loss"], float(np.max(np.abs(out["loss"][m] - res[3])) / scale))
         e = max(errs.values())
         key = "f32" if f32 else "f64"
-        worst[key] = max(worst[key], e)
-        flag = "" if e < (1e-3 if f32 else 1e-6) else "   <-- CHECK"
+        # two (nearly) coinciding realisations leave a variance of ~0 at a time point: cond(Lam) ~ 1 / min(nu) and the fit
+        # is then determined to cond * eps at best - the oracle as little as the device (seed 32, case 21: nu_min 1e-11,
+        # cond(Lam) 1e11, the round-2 build and every route of round 3 differ from NumPy by the same amount)
+        degenerate = float(nu.min()) < 1e-9 * float(nu.max())
+        if not degenerate:
+            worst[key] = max(worst[key], e)
+        flag = "" if e < (1e-3 if f32 else 1e-6) else ("   (degenerate variance: not counted)" if degenerate else "   <-- CHECK")
         which = max(errs, key=errs.get)
         print(f"case {case:3d} M={M} N={N:4d} R={R:2d} T={T:2d} k={kern} {key}: max rel err {e:.2e} ({which}) info {int(out['info'].max())}{flag}", flush=True)
 print("worst", worst)
