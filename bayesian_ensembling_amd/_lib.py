@@ -18,7 +18,7 @@ HOST, DEVICE = 0, 1
 MATERN32, MATERN52, RBF = 0, 1, 2
 KERNEL_IDS = {"matern32": MATERN32, "matern52": MATERN52, "rbf": RBF}
 
-GEMM_TA, GEMM_TB, GEMM_TRI_OUT, GEMM_KTRIM_TN_LOWER, GEMM_ZERO_SKIPPED = 1, 2, 4, 8, 32
+GEMM_TA, GEMM_TB, GEMM_TRI_OUT, GEMM_KTRIM_TN_LOWER, GEMM_KTRIM_A_LOWER, GEMM_ZERO_SKIPPED = 1, 2, 4, 8, 16, 32
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

@@ -54,6 +54,25 @@ def test_gemm_triangular_output_and_ktrim(ctx, nb):
     assert relerr(out[:, blk], phi[:, blk]) < TOL and not out[:, ~blk].any()   # ... or are zero-filled on request
 
 
+@pytest.mark.parametrize("m,k,n", [(320, 320, 192), (448, 256, 128), (128, 384, 64)])
+def test_gemm_lower_trapezoidal_a_stops_at_the_tiles_last_row(ctx, m, k, n):
+    """GEMM_KTRIM_A_LOWER (the update product of the solve recursion with a lower-triangular right-hand side): A_ik = 0 for
+    k > i, so the k loop of a 128-row tile ends at its last row - same result as the untrimmed product; and the elements
+    beyond that row are really not read (NaNs planted there do not reach the result)."""
+    rng = np.random.default_rng(m + k + n)
+    A = np.tril(rng.standard_normal((2, m, k)))
+    B = rng.standard_normal((2, k, n))
+    C0 = rng.standard_normal((2, m, n))
+    ref = C0 - A @ B
+    out = ctx.test_gemm(A, B, C0, alpha=-1.0, beta=1.0, flags=L.GEMM_KTRIM_A_LOWER)
+    assert relerr(out, ref) < TOL
+    Ap = A.copy()
+    i = np.arange(m)[:, None]
+    Ap[:, np.broadcast_to(np.arange(k)[None, :] >= (i // 128) * 128 + 128, (m, k))] = np.nan
+    out = ctx.test_gemm(Ap, B, C0, alpha=-1.0, beta=1.0, flags=L.GEMM_KTRIM_A_LOWER)
+    assert relerr(out, ref) < TOL
+
+
 def test_gemm_empty_k_writes_beta_c(ctx):
     # k-trimmed tile whose k range is empty cannot occur for square operands; beta path with alpha=0 instead
     rng = np.random.default_rng(6)
