@@ -28,9 +28,11 @@ rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw
 # config 5 (the fused small-member kernel): kernel trace of the same command as the bench line
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt5 -o kt5 -- python3 $R/bench.py --config c5 --no-cpu-baseline > $OUT/${TAG}_kt5.log 2>&1 || exit 6
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm5 -o m -- python3 $R/bench.py --config c5 --no-cpu-baseline --steps 2 --warmup 1 > $OUT/${TAG}_pm5.log 2>&1 || exit 19
 cd $R
 python3 tools/rocpd_stats.py $(find $OUT/${TAG}_kt5 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_c5.txt > /dev/null
-rm -rf $OUT/${TAG}_kt5
+python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pm5 -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util_c5.txt > /dev/null
+rm -rf $OUT/${TAG}_kt5 $OUT/${TAG}_pm5
 timeout -k 10 300 python3 bench.py --config c5 --dtype f32 --grid-points 432 --no-cpu-baseline > $OUT/${TAG}_bench_c5_f32.json 2> $OUT/${TAG}_bench_c5_f32.err || exit 7
 timeout -k 10 300 python3 bench.py --config c3 --no-extras > $OUT/${TAG}_bench_c3.json 2> /dev/null || exit 12
 timeout -k 10 300 python3 bench.py --config c4 --no-extras > $OUT/${TAG}_bench_c4.json 2> /dev/null || exit 13
@@ -56,4 +58,8 @@ rm -rf $OUT/${TAG}_ktm $OUT/${TAG}_pmm
 timeout -k 10 300 python3 tools/api_path_c5.py > $OUT/${TAG}_api_path_c5.json 2> /dev/null || exit 17
 # the blocked triangular solves alone (panel launch, recursion, triangular inverse) and the factorisation against its batch size
 (timeout -k 10 200 python3 tools/trsm_bench.py; timeout -k 10 200 python3 tools/potrf_batch.py) > $OUT/${TAG}_trsm_potrf_bench.txt 2>&1 || exit 18
+# randomised sweeps of the device fit against the oracle (shapes, iteration counts, kernels, precisions, loss traces)
+timeout -k 10 400 python3 tests/dev/fuzz_fit.py 31 50 > $OUT/${TAG}_fuzz_seed31.log 2>&1 || exit 20
+timeout -k 10 400 python3 tests/dev/fuzz_fit.py 32 50 > $OUT/${TAG}_fuzz_seed32.log 2>&1 || exit 21
+timeout -k 10 400 python3 tests/dev/fuzz_fit.py 47 50 > $OUT/${TAG}_fuzz_seed47.log 2>&1 || exit 22
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
