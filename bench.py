@@ -623,6 +623,10 @@ def main():
     fit_tfl = M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12
     extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
              "fit_algorithmic_tflops": round(fit_tfl, 3), "fit_frac_of_mfma_peak": round(fit_tfl / peak, 4),
+             "fit_algorithmic_flop_per_member": fit_flops(N, R, T),
+             "fit_flop_note": "flop the device path executes by construction (fit_flops; DESIGN section 4): 13/3 N^3 per general "
+                              "iteration, 5/3 N^3 in a first iteration that another follows (symmetric form), 10/3 N^3 for the "
+                              "prediction + chol(cov); round 2 counted 9.6e10 for this workload, round 3 executes 7.5e10",
              "barycentre_not_converged": int(bad),
              "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4)}
     cpu = None
