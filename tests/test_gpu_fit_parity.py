@@ -158,7 +158,8 @@ F32_TOL = 1e-3      # BASELINE.json: 1e-3 relative for fp32
 
 @pytest.mark.parametrize("M,N,R,T,kernel", [
     (2, 86, 5, 2, 0), (3, 24, 3, 2, 0), (2, 200, 8, 2, 1),      # config 3 names Matern-5/2 (kernel id 1)
-    (1, 64, 2, 1, 0), (2, 7, 3, 2, 0), (1, 130, 4, 27, 0), (1, 1000, 8, 2, 1)])
+    (1, 64, 2, 1, 0), (2, 7, 3, 2, 0), (1, 130, 4, 27, 0), (1, 1000, 8, 2, 1),
+    (2, 320, 5, 1, 0), (2, 320, 5, 3, 0), (1, 257, 4, 2, 1)])   # general path: one iteration (general form in fp32), several
 def test_fp32_fit_against_the_fp64_oracle(ctx, M, N, R, T, kernel):
     """bayens_gp_fit_batch_f32 (fp32 storage and MFMA products) vs the float64 oracle: 1e-3 relative."""
     data, _ = go.synthetic_ensemble(M, N, R=R, seed=11)
@@ -358,7 +359,10 @@ def test_bench_contract_line(ctx):
 
 @pytest.mark.parametrize("M,N,R,T", [(2, 1, 3, 1), (2, 2, 3, 2), (1, 3, 2, 2), (2, 63, 3, 2), (2, 64, 3, 2), (2, 65, 3, 2),
                                      (1, 127, 50, 1), (1, 129, 4, 2), (1, 255, 6, 1), (1, 257, 6, 1), (3, 320, 7, 1),
-                                     (1, 1000, 8, 1), (1, 1980, 8, 1), (33, 100, 4, 1)])
+                                     (1, 1000, 8, 1), (1, 1980, 8, 1), (33, 100, 4, 1),
+                                     # T >= 2 in the general path: the symmetric first iteration with its paired factorisation
+                                     # (T = 1 above keeps C and takes G S = (I - S) / gamma), with and without padding
+                                     (1, 257, 6, 2), (3, 320, 7, 3), (5, 448, 4, 2), (1, 1980, 8, 2)])
 def test_edge_sizes(ctx, M, N, R, T):
     """N = 1, around the 64-row leaf, the 256-wide panel and the 128 tile; the monthly horizon 1980; M not a
     multiple of 8; many realisations."""
