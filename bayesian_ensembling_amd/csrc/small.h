@@ -28,6 +28,7 @@ struct SmallArgs {
   double* loss = nullptr;   // [B][loss_stride]: -ELBO after iterations 0, 25, 50, ... (models.py:211-215) or null
   int loss_stride = 0;
   unsigned long long* stamps = nullptr;   // diagnostic: 32 cycle-counter stamps of workgroup 0 (null in production)
+  int tune = 0;                           // measurement switches (BAYENS_SMALL_TUNE)
 };
 
 bool small_fit_supported(int N, int R);

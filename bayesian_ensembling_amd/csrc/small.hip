@@ -353,7 +353,7 @@ __device__ __forceinline__ void diag16(v4d acc, real* T, real* Dk, int lane, int
 struct NoExtra { __device__ __forceinline__ void operator()(int) const {} };
 template <int NT, bool WITH_INV, class Extra = NoExtra>
 __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const Lane& o, int wave, int lane, int bad,
-                                         Extra extra = Extra()) {
+                                         Extra extra = Extra(), bool w4idle = true) {
   // (LDS operands arrive as offsets into the workgroup's dynamic LDS block: pointers handed to a real function call
   //  would be generic pointers and every access a flat one)
   real* A = tiles_base() + a_off;
@@ -402,7 +402,12 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
       // its own positions directly, NW-1 at a time (round 3: scanning the whole sequence with a modulo test per candidate
       // cost more scalar time than the tile updates it found - measured in medium.hip, where this loop was first fixed).
       const int n_trail = (below - 1) * (below + 2) / 2;                      // sum_{i = k+2}^{NT-1} (i - k)
-      int pos = wave - 1;
+      // Wave 4 shares its SIMD with wave 0 (waves are dealt round-robin over the four SIMDs), and a v_fma_f64 of the serial
+      // 16x16 chain waits out every fp64 MFMA its SIMD partner has in the pipe (tools/diag16_bench.py: the chain takes
+      // 8.1 k cycles beside MFMA-issuing partners, 4.0 k alone): wave 4 takes no tile updates in this phase, the other six do.
+      const int NWK = w4idle ? NW - 2 : NW - 1;
+      int pos = (w4idle && wave > 4) ? wave - 2 : wave - 1;
+      if (w4idle && wave == 4) pos = 1 << 20;
       {
         int i = k + 2, j = k + 1 + pos;                                       // row i holds i - k tiles
         while (i < NT && j > i) { j -= i - k; ++i; }
@@ -412,12 +417,12 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
           v4r acc = ld_tile(t, o);
           acc = mma<false, true>(acc, A + lt(i, k) * TS, A + lt(j, k) * TS, o, -1);
           st_tile(t, o, acc);
-          pos += NW - 1;
-          j += NW - 1;
+          pos += NWK;
+          j += NWK;
           while (i < NT && j > i) { j -= i - k; ++i; }
         }
       }
-      if (WITH_INV) {
+      if (WITH_INV && !(w4idle && wave == 4)) {
         const int n_inv_ops = below * (k + 1);
         int q = pos - n_trail;                                                // position inside the inverse's part of the sequence
         int j = k + 1 + q / (k + 1), i = q - (j - (k + 1)) * (k + 1);
@@ -428,8 +433,8 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
           if (k > i) acc = ld_tile(t, o);
           acc = mma<false, false>(acc, A + lt(j, k) * TS, Xb + lt(k, i) * TS, o, -1);
           st_tile(t, o, acc);
-          q += NW - 1;
-          i += NW - 1;
+          q += NWK;
+          i += NWK;
           while (i > k) { i -= k + 1; ++j; }
         }
       }
@@ -557,6 +562,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
   lane_init(o, lane);
   const int N = g.N, R = g.R;
   const double J = g.jitter;
+  const bool w4idle = !(g.tune & 1);
 
 #pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -708,8 +714,8 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           }
         }
       };
-      if (wb) bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, g_rows);  // (nothing in that iteration uses L^-1)
-      else bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, g_rows);  // L in Lb, L^-1 rides along into Wb
+      if (wb) bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, g_rows, w4idle);  // (nothing in that iteration uses L^-1)
+      else bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, g_rows, w4idle);  // L in Lb, L^-1 rides along into Wb
       if (g.loss && it > 0 && (it - 1) % 25 == 0) neg_elbo((it - 1) / 25);  // after the Adam step = at these hypers
       STAMP(2);
       // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G), theta1 <- (1-g) theta1 + g L^T (y / nu)
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           if (p < NTT && i <= k) st[s] = mma<true, false>(st[s], Lb + lt(k, i) * TS, Lb + lt(k, j) * TS, o);
         }
       };
-      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::LB, o, wave, lane, bad, s_rows);      // (L is dead: C^-1 takes its buffer)
+      bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::LB, o, wave, lane, bad, s_rows, w4idle);      // (L is dead: C^-1 takes its buffer)
       STAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     STAMP(11);
     refresh_hypers();
     kmat();
-    bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad);       // Lb = L, Wb = L^-1 (riding along), Cb = S
+    bad = potrf_lds<NT, true>(Y::LB, Y::DL, Y::WB, o, wave, lane, bad, NoExtra(), w4idle);       // Lb = L, Wb = L^-1 (riding along), Cb = S
     SYNC();
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     STAMP(12);
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       SYNC();       // (the factorisation below overwrites the diagonal tiles)
     }
     if (g.chol || g.logdet || g.basis) {
-      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad);   // Distribution.__post_init__ (data.py:38-39)
+      bad = potrf_lds<NT, false>(Y::LB, Y::DL, 0, o, wave, lane, bad, NoExtra(), w4idle);   // Distribution.__post_init__ (data.py:38-39)
       STAMP(16);
       if (g.chol) {
         for (int e = tid; e < NT * NT * 256; e += NTH) {
@@ -1175,9 +1181,12 @@ void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* ou
 
 bool small_fit_supported(int N, int R) { return N >= 1 && N <= SMALL_MAX_N && R >= 1; }
 
-void small_fit(hipStream_t stream, const SmallArgs& g, int n_cus) {
-  if (!small_fit_supported(g.N, g.R)) throw HipError{-1, "small_fit: N out of range"};
-  if (g.B <= 0) return;
+void small_fit(hipStream_t stream, const SmallArgs& g_in, int n_cus) {
+  if (!small_fit_supported(g_in.N, g_in.R)) throw HipError{-1, "small_fit: N out of range"};
+  if (g_in.B <= 0) return;
+  static const int tune = [] { const char* e = std::getenv("BAYENS_SMALL_TUNE"); return e ? std::atoi(e) : 0; }();
+  SmallArgs g = g_in;
+  g.tune = tune;
   if (g.N + 2 <= 32) launch<2>(stream, g, n_cus);
   else if (g.N + 2 <= 64) launch<4>(stream, g, n_cus);
   else launch<6>(stream, g, n_cus);
