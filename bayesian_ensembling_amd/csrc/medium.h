@@ -31,6 +31,7 @@ struct MediumArgs {
   unsigned long long* stamps = nullptr;   // diagnostic: cycle-counter stamps of workgroup 0 (null in production)
   int NT = 0;               // filled in by medium_fit
   long scratch_stride = 0;  // filled in by medium_fit
+  int tune = 0;             // measurement switches (BAYENS_MEDIUM_TUNE), filled in by medium_fit
 };
 
 bool medium_fit_supported(int N, int R);

@@ -132,6 +132,8 @@ struct PotrfArgs {
   long oA, oX, oG;             // offsets of the triangle, of its inverse (WITH_INV) and of the Gram triangle (MODE 1 / 2)
   int NT, NTT;
   int sa_off, rs_off, yd_off, wv_off;   // LDS offsets (doubles): staging tiles, 1 / sqrt(nu), y / nu, wv
+  int w4idle;                  // measurement switch: wave 4 (wave 0's SIMD partner) takes no tile updates beside the serial 16x16
+                               // factorisation - what the small-member kernel does (section 5b); slower here
 };
 // arguments of a real function arrive in vector registers: tell the compiler that these are wave-uniform
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -149,6 +151,7 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
   e.oA = uni(e_in.oA); e.oX = uni(e_in.oX); e.oG = uni(e_in.oG);
   e.NT = uni(e_in.NT); e.NTT = uni(e_in.NTT);
   e.sa_off = uni(e_in.sa_off); e.rs_off = uni(e_in.rs_off); e.yd_off = uni(e_in.yd_off); e.wv_off = uni(e_in.wv_off);
+  const bool w4idle = uni(e_in.w4idle) != 0;
   const int NT = e.NT;
   double* lds = lds_base();
   double* SA = lds + e.sa_off;
@@ -280,7 +283,11 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
         }
       };
       const int n_trail = (below - 1) * (below + 2) / 2;                       // sum_{i = k+2}^{NT-1} (i - k)
-      int pos = wave - 1;
+      // (wave 4 shares its SIMD with wave 0, whose fp64 chain waits out every MFMA the partner has in the pipe - section 5b:
+      //  it takes no tile updates in this phase, the other six do)
+      const int NWK = w4idle ? NW - 2 : NW - 1;
+      int pos = (w4idle && wave > 4) ? wave - 2 : wave - 1;
+      if (w4idle && wave == 4) pos = 1 << 20;
       {
         int i = k + 2, j = k + 1 + pos;                                        // row i holds i - k tiles
         while (i < NT && j > i) { j -= i - k; ++i; }
@@ -289,13 +296,13 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
         while (pos < n_trail) {
           if (!have) { hi = i; hj = j; have = 1; }
           else { trailing2(hi, hj, i, j, true); have = 0; }
-          pos += NW - 1;
-          j += NW - 1;
+          pos += NWK;
+          j += NWK;
           while (i < NT && j > i) { j -= i - k; ++i; }
         }
         if (have) trailing2(hi, hj, hi, hj, false);
       }
-      if (WITH_INV) {
+      if (WITH_INV && !(w4idle && wave == 4)) {
         auto inverse2 = [&](int j0, int i0, int j1, int i1, bool two) {        // T_ji -= L_jk X_ki   (first touched at k == i)
           gdouble* t0 = Xb + lt(j0, i0) * TS;
           gdouble* t1 = Xb + lt(j1, i1) * TS;
@@ -316,8 +323,8 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
         while (q < n_inv_ops) {
           if (!have) { hi = i; hj = j; have = 1; }
           else { inverse2(hj, hi, j, i, true); have = 0; }
-          q += NW - 1;
-          i += NW - 1;
+          q += NWK;
+          i += NWK;
           while (i > k) { i -= k + 1; ++j; }
         }
         if (have) inverse2(hj, hi, hj, hi, false);
@@ -405,6 +412,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     PotrfArgs e;
     e.sc = (gdouble*)sc; e.oA = A_ - sc; e.oX = X_ - sc; e.oG = G_ - sc; e.NT = NT; e.NTT = NTT;
     e.sa_off = (int)(SA - lds); e.rs_off = (int)(rs - lds); e.yd_off = (int)(yd - lds); e.wv_off = (int)(wv - lds);
+    e.w4idle = (g.tune & 1) ? 1 : 0;   // off: here the tile updates (through the scratch), not the chain, bound a step (288 against 279 us at N = 165)
     return e;
   };
   // the "cross" of k in a symmetric triangle: slot0 + i = tile (i, k) for i >= k, tile (k, i) for i < k (the user picks
@@ -973,6 +981,8 @@ void medium_fit(hipStream_t stream, const MediumArgs& g_in, int n_cus) {
   MediumArgs g = g_in;
   g.NT = medium_tiles(g.N);
   g.scratch_stride = (long)medium_scratch_doubles(g.N);
+  static const int tune = [] { const char* e = std::getenv("BAYENS_MEDIUM_TUNE"); return e ? std::atoi(e) : 0; }();
+  g.tune = tune;
   const size_t lds = medium_lds_bytes(g.N);
   static bool configured[64] = {};
   int dev = 0;
