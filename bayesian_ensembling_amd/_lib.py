@@ -122,6 +122,7 @@ def load():
     lib.bayens_bench_diag16.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     lib.bayens_set_medium_min_batch.argtypes = [_vp, C.c_int]
+    lib.bayens_set_fit_route.argtypes = [_vp, C.c_int]
     lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
@@ -260,6 +261,10 @@ class Context:
         """Batch size from which members with 94 < N <= 254 take the fused mid-size kernel (1 = always, huge = never,
         0 = the default choice by size)."""
         self._check(self.lib.bayens_set_medium_min_batch(self.h, int(n)))
+
+    def set_fit_route(self, route):
+        """1: every fp64 fit takes the general path whatever its size; 0: the fused kernels by size (default)."""
+        self._check(self.lib.bayens_set_fit_route(self.h, int(route)))
 
     def profile_enable(self, on=True):
         self._check(self.lib.bayens_profile_enable(self.h, 1 if on else 0))

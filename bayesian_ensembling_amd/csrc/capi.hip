@@ -98,6 +98,7 @@ struct bayens_ctx {
   }
   int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
   int medium_min_batch = 0;        // > 0: batches of at least this many mid-size members take the fused kernel (medium.hip); 0: by size
+  int fit_route = 0;               // 0: fused kernels by size (default); 1: general path whatever the size (bayens_set_fit_route, fp64)
   double* mscratch = nullptr;      // tile scratch of the fused mid-size kernel (medium.hip), grown on demand
   size_t mscratch_cap = 0;
   double* medium_scratch(size_t count) {
@@ -459,6 +460,12 @@ int bayens_set_medium_min_batch(bayens_ctx* c, int min_batch) {
   return 0;
 }
 
+int bayens_set_fit_route(bayens_ctx* c, int route) {
+  if (!c || route < 0 || route > 1) return BAYENS_E_ARG;
+  c->fit_route = route;
+  return 0;
+}
+
 int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
                         const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
                         double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
@@ -469,7 +476,7 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
     // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
     static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
-    const bool small = !no_small && smalln::small_fit_supported(N, R);
+    const bool small = !no_small && c->fit_route == 0 && smalln::small_fit_supported(N, R);
     // mid-size members (94 < N <= 254, the reference's N = 165 series): ONE kernel too, matrices in an L2-resident scratch
     // (medium.hip; BAYENS_NO_MEDIUM=1 forces the general path)
     // Measured (profiles/r03_medium_kernel.txt, us per optimiser iteration): the fused kernel is flat in the batch - one CU per
@@ -478,7 +485,7 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     // per side (N <= 190) the fused kernel always; above that from 128 members on (bayens_set_medium_min_batch overrides).
     static const bool no_medium = getenv("BAYENS_NO_MEDIUM") != nullptr;
     const int medium_from = c->medium_min_batch > 0 ? c->medium_min_batch : ((N + 2 + 15) / 16 <= 12 ? 1 : 128);
-    const bool medium = !small && !no_medium && B >= medium_from && mediumn::medium_fit_supported(N, R);
+    const bool medium = !small && !no_medium && c->fit_route == 0 && B >= medium_from && mediumn::medium_fit_supported(N, R);
     const int Np = pad_to_leaf(N);
     if (!small && !medium) ensure_ws(c, B, Np);
     Stage st(c, loc);

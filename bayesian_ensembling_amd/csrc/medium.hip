@@ -624,17 +624,20 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         }
         GSYNC();
       }
-      // ---- m = S theta1: one staged pass over the crosses of S
+      // ---- m = C^-T (C^-1 theta1) through the inverse FACTOR (Lb), not S theta1: see small.hip - with a variance of ~1e-11 at
+      // one time step the rounding of the explicit S puts 1e-5 into m, which u = G m - L^T (y / nu) multiplies by |G| ~ 1e11.
+      lower_matvec(Lb, th, 0.0, uv);                                        // z = C^-1 theta1 (one pass over the block columns)
       {
         double part[2] = {0.0, 0.0};
 #pragma unroll 1
-        for (int k = 0; k < NT; ++k) {
-          stage_cross(Sb, k, 0);
+        for (int k = 0; k < NT; ++k) {                                      // m_j = sum_{k >= j} X_kj^T z_k: one pass over the block rows
+#pragma unroll 1
+          for (int j = wave; j <= k; j += NW) st_tile(c.slot(j), o, ldn(Lb + lt(k, j) * TS, lane));
           GSYNC();
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int i = wave + u * NW;
-            if (i < NT) part[u] += tile_mv(c.slot(i), i < k, th + 16 * k, o);   // S_ik = tile (i, k), or tile (k, i)^T above the diagonal
+            const int j = wave + u * NW;
+            if (j < NT && j <= k) part[u] += tile_mv(c.slot(j), true, uv + 16 * k, o);
           }
           GSYNC();
         }
@@ -650,8 +653,9 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       // out of the same pass (the crosses of G are in LDS anyway) and, like m, enters Phi only in the epilogue.
       if (it == 0 && g.gamma > 0.0) {
         // First iteration: Lam_old = I exactly, so Lam = I + gamma G, G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma and
-        // G m = (Lam m - m) / gamma = (theta1 - m) / gamma: no product, one pass over the tiles of S.
-        for (int t = tid; t < NP; t += NTH) uv[t] = (th[t] - mv[t]) / g.gamma - wv[t];
+        // u = G m - L^T (y / nu) = (Lam m - m) / gamma - theta1 / gamma = -m / gamma: no product, one pass over the tiles of S.
+        // (not (theta1 - m) / gamma - L^T (y / nu): with |theta1| ~ 1e11 that difference rounds m away)
+        for (int t = tid; t < NP; t += NTH) uv[t] = -mv[t] / g.gamma;
         GSYNC();
         int i = 0, j = 0;
         unpack_step(i, j, wave);

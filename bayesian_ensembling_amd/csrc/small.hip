@@ -757,6 +757,25 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       };
       bad = potrf_lds<NT, true>(Y::CB, Y::DC, Y::LB, o, wave, lane, bad, s_rows, w4idle);      // (L is dead: C^-1 takes its buffer)
       STAMP(4);
+      if (!wb) {
+        // ---- m = C^-T (C^-1 theta1) through the inverse FACTOR (two triangular tile mat-vecs while C^-1 still lies in Lb), not
+        // S theta1: with a variance of ~1e-11 at one time step (two nearly coincident realisations) |theta1| ~ |G| ~ 1e11, the
+        // rounding of the explicit S alone (1e-16) puts 1e-5 into m, and u = G m - L^T (y / nu) below multiplies that by
+        // |G| again - the fit came out O(1) wrong (profiles/r03_fuzz_seed32.log case 21; tests/golden/illcond_*.npz hold
+        // the 50-digit answer).  Through the factor the error of m stays in the directions S damps: cond(Lam) eps overall.
+#pragma unroll 1
+        for (int i = wave; i < NT; i += NW) {
+          const double s = mv_lower<NT>(Lb, th, i, o);
+          if (o.lk == 0) uv[16 * i + o.lr] = (vecr)s;                      // z = C^-1 theta1 (uv is free until u is formed)
+        }
+        SYNC();
+#pragma unroll 1
+        for (int i = wave; i < NT; i += NW) {
+          const double s = mv_lower_t<NT>(Lb, uv, i, o);
+          if (o.lk == 0) mv[16 * i + o.lr] = (vecr)s;
+        }
+        // (mv is read after the barriers of the tile moves below)
+      }
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
         for (int t = tid; t < N; t += NTH) s += log((double)Cb[lt(t >> 4, t >> 4) * TS + swz(t & 15, t & 15)]);
@@ -786,13 +805,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         }
         SYNC();
       } else {
-      // ---- m = S theta1 ; u = L^T D (L m - y) = G m - L^T (y / nu)
-#pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        const double s = mv_sym<NT>(Cb, th, i, o);
-        if (o.lk == 0) mv[16 * i + o.lr] = (vecr)s;
-      }
-      SYNC();
+      // ---- u = L^T D (L m - y) = G m - L^T (y / nu)   (m: above, from the inverse factor)
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_sym<NT>(Lb, mv, i, o);

@@ -232,7 +232,7 @@ class FieldWorkload:
     fused small-member kernel over the B = M * G fits (reduced export: mu, diag(cov), basis, logdet; or the full
     covariance) -> per-gridpoint LogLikelihoodWeight rows -> normalisation over the members -> barycentre per point."""
 
-    def __init__(self, ctx, M, G, N, R, T, export, R_obs=3, seed=0xC5, f32=False):
+    def __init__(self, ctx, M, G, N, R, T, export, R_obs=3, seed=0xC5, f32=False, keep_host=False):
         self.ctx, self.M, self.G, self.N, self.R, self.T, self.export, self.R_obs = ctx, M, G, N, R, T, export, R_obs
         self.f32 = f32
         if f32:
@@ -249,6 +249,8 @@ class FieldWorkload:
         dt = np.float32 if f32 else np.float64
         self.dX, self.dy, self.dnu = ctx.to_device(X, dt), ctx.to_device(data.mean(axis=1), dt), ctx.to_device(data.var(axis=1), dt)
         self.dobs = ctx.to_device(obs)
+        # (tests/test_gpu_small.py holds THIS launch against the oracle: it asks for the host copies of the inputs)
+        self.host = (X, data.mean(axis=1), data.var(axis=1), obs) if keep_host else None
         self.dmu, self.dvar, self.dld, self.dhyp = ctx.empty((B, N), dt), ctx.empty((B, N)), ctx.empty((B,)), ctx.empty((B, 2))
         self.dbasis, self.dll, self.dw = ctx.empty((B, 2, N), dt), ctx.empty((B, N)), ctx.empty((B, N))
         self.dcov = ctx.empty((B, N, N), dt) if export == "full" else None

@@ -61,6 +61,10 @@ int bayens_test_trsm(bayens_ctx* ctx, int nb, int m, int n, const double* L, dou
  * min_batch members on (1 = always, a huge value = never - what the parity tests use to hold the two routes against each
  * other); 0 restores the default. */
 int bayens_set_medium_min_batch(bayens_ctx* ctx, int min_batch);
+/* route = 1 sends EVERY fp64 fit of this context through the general path (csrc/driver.cpp) whatever its size, 0 restores the
+ * choice by size (fused kernels for N <= 254).  The parity tests use it to hold all routes to the same fixtures in one
+ * process (the environment switches BAYENS_NO_SMALL / BAYENS_NO_MEDIUM are read once per process). */
+int bayens_set_fit_route(bayens_ctx* ctx, int route);
 
 /* Diagnostic: the pack -> [ncclAllGather image] -> unpack index arithmetic of bayens_allgather_member_rows without a
  * communicator: the host tables ll / mean / var [M][P] are split over `nranks` fictitious ranks exactly as

@@ -15,7 +15,7 @@ Per selected member the fixture holds
     hyp (2,)              (variance, lengthscale) the oracle reaches with that y_mean after T=2500
     n_iters               2500 (experiments/pre_fitting_cmip6models.py:76-77)
 
-Usage:  OPENBLAS_NUM_THREADS=1 python oracle/extract_golden.py [--only TAG]
+Usage:  python oracle/extract_golden.py [--only TAG] [--missing] [--jobs 6]
 """
 from __future__ import annotations
 
@@ -32,13 +32,11 @@ from oracle import gp_oracle as go  # noqa: E402
 REF = "/root/reference/experiments/pre_fit_models"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
-# (tag, pickle, member index) : a spread of N in {86,165} and R in {3,5,9,25}
-SELECTION = [
-    ("ssp434_m0", "ssp434_1D_models.pkl", 0),       # N=86  R=5
-    ("ssp119_m0", "ssp119_1D_models.pkl", 0),       # N=86  R=25 (first member of ssp119)
-    ("ssp119_m4", "ssp119_1D_models.pkl", 4),       # N=86  small R
-    ("histssp434_m1", "histssp434_1D_models.pkl", 1),  # N=165
-]
+# (tag, pickle, member index): ALL 18 pickled members (round 4; rounds 1-3 carried four of them).
+#   histssp434 / histssp460: N=165, R in {25, 9, 16} / {25, 9, 10};  ssp119: N=86, R in {25, 25, 5, 6, 3, 5};
+#   ssp434: N=86, R = 5, 5, 5;  ssp460: N=86, R in {5, 5, 4}
+MEMBERS_PER_PICKLE = {"histssp434": 3, "histssp460": 3, "ssp119": 6, "ssp434": 3, "ssp460": 3}
+SELECTION = [(f"{stem}_m{i}", f"{stem}_1D_models.pkl", i) for stem, n in MEMBERS_PER_PICKLE.items() for i in range(n)]
 
 
 class _Stub:
@@ -150,32 +148,50 @@ def recover_y_mean(data, mu_gold, n_iters=2500, steps=8, tol=2e-10, log=print):
     return y, mu, cov, hyp
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None)
-    ap.add_argument("--steps", type=int, default=8)
-    args = ap.parse_args()
-    os.makedirs(OUT, exist_ok=True)
-    for tag, pkl, idx in SELECTION:
-        if args.only and args.only != tag:
-            continue
+def extract_one(job):
+    tag, pkl, idx, steps = job
+    from threadpoolctl import threadpool_limits
+    lines = []
+    log = lambda s: (lines.append(s), print(f"[{tag}] {s}", flush=True))
+    with threadpool_limits(1):
         mem = load_members(os.path.join(REF, pkl))[idx]
         R, N = mem["data"].shape
-        print(f"[{tag}] {mem['name']}  R={R} N={N} logdet={mem['logdet']}", flush=True)
+        log(f"{mem['name']}  R={R} N={N} logdet={mem['logdet']}")
         # sanity: the pickled Cholesky/logdet are those of the pickled covariance
         Lc, ld = go.mvn_factor(mem["cov"])
-        print(f"   chol check {np.max(np.abs(Lc - mem['chol'])):.2e}  logdet check "
-              f"{abs(ld - (mem['logdet'] if mem['logdet'] is not None else ld)):.2e}", flush=True)
-        y, mu, cov, hyp = recover_y_mean(mem["data"], mem["mu"], steps=args.steps,
-                                         log=lambda s: print(s, flush=True))
-        print(f"   final max|cov-cov_gold|={np.max(np.abs(cov - mem['cov'])):.3e} "
-              f"(cov scale {np.max(np.abs(mem['cov'])):.3e})", flush=True)
+        log(f"   chol check {np.max(np.abs(Lc - mem['chol'])):.2e}  logdet check "
+            f"{abs(ld - (mem['logdet'] if mem['logdet'] is not None else ld)):.2e}")
+        y, mu, cov, hyp = recover_y_mean(mem["data"], mem["mu"], steps=steps, log=log)
+        log(f"   final max|cov-cov_gold|={np.max(np.abs(cov - mem['cov'])):.3e} "
+            f"(cov scale {np.max(np.abs(mem['cov'])):.3e})")
         np.savez_compressed(
             os.path.join(OUT, f"gpfit_{tag}.npz"),
             name=mem["name"], data=mem["data"], mu_gold=mem["mu"], cov_gold=mem["cov"],
             chol_gold=mem["chol"], logdet_gold=np.float64(mem["logdet"] if mem["logdet"] is not None else ld),
             y_mean=y, hyp=hyp, n_iters=np.int64(2500),
         )
+    return tag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--jobs", type=int, default=1, help="members extracted side by side (one BLAS thread each)")
+    ap.add_argument("--missing", action="store_true", help="only members whose fixture does not exist yet")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [(tag, pkl, idx, args.steps) for tag, pkl, idx in SELECTION
+            if (not args.only or args.only == tag)
+            and not (args.missing and os.path.exists(os.path.join(OUT, f"gpfit_{tag}.npz")))]
+    if args.jobs > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(args.jobs) as pool:
+            for tag in pool.imap_unordered(extract_one, jobs):
+                print(f"[{tag}] written", flush=True)
+    else:
+        for job in jobs:
+            extract_one(job)
 
 
 if __name__ == "__main__":

@@ -50,3 +50,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def golden_files():
     return sorted(f for f in os.listdir(GOLDEN) if f.startswith("gpfit_") and f.endswith(".npz"))
+
+
+def golden_tolerances(g):
+    """(cov relative, mu absolute, hyp relative) bounds for one gpfit_* fixture.  The members with R >= 6 realisations are held
+    to 1e-6 / 1e-5 / 1e-5; the members with R <= 5 are chaotic over 2500 optimiser iterations - a ONE-ulp change of the target
+    moves their fit by the `chaos_*` figures the fixture carries (oracle/measure_chaos.py: up to 7e-5 on cov, 1.6e-3 on mu) - so
+    for them the bound is ten times that envelope: no fp64 evaluation, the reference's own on another BLAS included, is
+    reproducible beyond it."""
+    c, m, h = float(g["chaos_cov"]), float(g["chaos_mu"]), float(g["chaos_hyp"])
+    return max(1e-6, 10 * c), max(1e-5, 10 * m), max(1e-5, 10 * h)

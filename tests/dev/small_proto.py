@@ -179,10 +179,12 @@ def fit(X, y_in, nu_in, T, kernel=0, gamma=0.5, lr=0.01, jitter=1e-6):
                 for k in range(i, NT):
                     acc += Lb[k, i].T @ Lb[k, j]
                 S[i, j] = acc
+        # P6: m = C^-T (C^-1 theta1) through the inverse FACTOR while it still lies in Lb (round 4; m = S theta1 through the
+        # explicit S loses cond(Lam) eps |theta1| in m, which u = G m - L^T (y / nu) multiplies by |G| again: tests/golden/illcond_*)
+        m = matvec_lower(Lb, matvec_lower(Lb, th), trans=True)
         Cb.t[:] = S.t
         have_S = True
         Lb.t[:] = G.t                                                      # G -> Lb (C^-1 dead)
-        m = matvec_sym(Cb, th)                                             # P6
         uvec = matvec_sym(Lb, m) - ly                                      # u = L^T D (L m - y) = G m - L^T (y / nu)
         Phi = Buf(NT)                                                      # P7
         for i in range(NT):

@@ -8,7 +8,7 @@ import pytest
 from threadpoolctl import threadpool_limits
 
 from bayesian_ensembling_amd import _lib as L
-from conftest import GOLDEN, golden_files, member_inputs, relerr
+from conftest import GOLDEN, golden_files, golden_tolerances, member_inputs, relerr
 from oracle import gp_oracle as go
 
 pytestmark = pytest.mark.gpu
@@ -18,13 +18,17 @@ REL_TOL = 1e-5
 @pytest.mark.parametrize("M,N,R,T,kernel", [
     (8, 200, 8, 2, 0),      # BASELINE config 1: 8-member x 200-step, test-scale T (tests/test_weights.py:90)
     (2, 86, 5, 3, 0), (3, 24, 3, 2, 0),   # the reference test's own N=24, R=3
-    (1, 65, 3, 1, 0), (1, 64, 2, 2, 0), (2, 130, 4, 2, 1), (1, 100, 8, 2, 2), (2, 7, 3, 2, 0), (1, 200, 8, 0, 0)])
+    (1, 65, 3, 1, 0), (1, 64, 2, 2, 0), (2, 130, 4, 2, 1), (1, 100, 8, 2, 2), (2, 7, 3, 2, 0), (1, 200, 8, 0, 0),
+    # the extension kernels (Matern-5/2 = 1, RBF = 2; BASELINE configs 1-2 say "RBF GP") through the GENERAL path (N > 254):
+    # one iteration (general form), three (symmetric first iteration with its gradient weights from P, then general ones)
+    (2, 320, 6, 1, 1), (2, 320, 6, 3, 1), (2, 320, 6, 1, 2), (2, 320, 6, 3, 2), (1, 1000, 8, 2, 1), (1, 1000, 8, 2, 2)])
 def test_fit_matches_oracle(ctx, M, N, R, T, kernel):
     data, _ = go.synthetic_ensemble(M, N, R=R)
     X, y, nu = member_inputs(data)
     out = ctx.gp_fit_batch(X, y, nu, T, kernel=kernel)
     assert not out["info"].any()
-    tight = 1e-10 if kernel == 0 else 1e-6       # smoother kernels: K + 1e-6 I is far worse conditioned
+    # smoother kernels: K + 1e-6 I is far worse conditioned (1e-6 asserted up to N = 320; BASELINE's 1e-5 at N = 1000)
+    tight = 1e-10 if kernel == 0 else (1e-6 if N <= 320 else REL_TOL)
     for m in range(M):
         mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T, kernel=kernel)
         Lc, ld = go.mvn_factor(co)
@@ -54,13 +58,23 @@ def test_fit_reproduces_the_references_pickled_posteriors(ctx, fname):
     g = np.load(os.path.join(GOLDEN, fname))
     X, _, nu = go.prologue(g["data"])
     out = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], int(g["n_iters"]))
-    assert relerr(out["cov"][0], g["cov_gold"]) < 1e-6
-    # (the recovered DBA target pins mu_gold to ~5e-6 - the oracle itself sits at 4.9e-6 on one member - and 2500
-    #  chaotic optimiser steps turn a different summation order into a few 1e-7: BASELINE's 1e-5, |mu| ~ 1)
-    assert np.max(np.abs(out["mu"][0] - g["mu_gold"])) < 1e-5
-    # the hypers are compared with the ORACLE's (the pickles do not hold them); over 2500 Adam steps the
-    # small-R members amplify rounding differences by ~1e10, hence BASELINE's 1e-5 rather than 1e-6 here
-    assert relerr(out["hyp"][0], g["hyp"]) < 1e-5
+    # Bounds per fixture (conftest.golden_tolerances): cov 1e-6, mu 1e-5, hypers 1e-5 for the nine members with R >= 6
+    # realisations; the nine members with R <= 5 are chaotic over 2500 iterations (a one-ulp change of the target moves the
+    # ORACLE's fit by up to 7e-5 on cov / 1.6e-3 on mu, tests/golden `chaos_*`), and a device that sums in another order is
+    # such a change: they are held to ten times their measured envelope here - and TIGHTLY below, at a horizon where rounding
+    # has not been amplified yet.  (The hypers are compared with the oracle's: the pickles do not hold them.)
+    tol_cov, tol_mu, tol_hyp = golden_tolerances(g)
+    e_cov, e_mu, e_hyp = relerr(out["cov"][0], g["cov_gold"]), np.max(np.abs(out["mu"][0] - g["mu_gold"])), relerr(out["hyp"][0], g["hyp"])
+    print(f"{fname}: R={g['data'].shape[0]} cov {e_cov:.2e} (< {tol_cov:.1e}) mu {e_mu:.2e} (< {tol_mu:.1e}) hyp {e_hyp:.2e} (< {tol_hyp:.1e})")
+    assert e_cov < tol_cov and e_mu < tol_mu and e_hyp < tol_hyp
+    if float(g["chaos_cov"]) > 1e-12:
+        # chaotic member: the same inputs for 100 iterations - one e-folding of the amplification - against the oracle
+        short = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], 100)
+        with threadpool_limits(1):
+            mo, co, ho = go.gp_fit(X, g["y_mean"], nu, 100)
+        s_cov, s_mu, s_hyp = relerr(short["cov"][0], co), relerr(short["mu"][0], mo), relerr(short["hyp"][0], ho)
+        print(f"    T=100 vs oracle: cov {s_cov:.2e} mu {s_mu:.2e} hyp {s_hyp:.2e}")
+        assert s_cov < 1e-8 and s_mu < 1e-8 and s_hyp < 1e-8
     # Distribution.__post_init__ (distrax): Cholesky + logdet of the reference's covariance
     chol, logdet = ctx.mvn_factor_batch(g["cov_gold"][None])
     assert np.max(np.abs(chol[0] - g["chol_gold"])) < 1e-11
@@ -303,10 +317,76 @@ def test_benchmarked_configuration_full_size(ctx, M):
         assert np.isfinite(w_ref).all() and bad == rbad == 0
         assert relerr(w_dev, w_ref) < REL_TOL and relerr(bmu_dev, rm) < REL_TOL and relerr(bvar_dev, rv) < REL_TOL
         assert relerr(w_dev, w_ref) < 1e-9 and relerr(bmu_dev, rm) < 1e-9 and relerr(bvar_dev, rv) < 1e-9     # (measured)
+        # ... and element by element: every weight above underflow to 1e-5 RELATIVE to itself (norm-wise bounds say nothing
+        # about the small entries of a weight table)
+        big = w_ref > 1e-300
+        assert big.all() and np.max(np.abs(w_dev[big] / w_ref[big] - 1.0)) < REL_TOL
+        assert np.max(np.abs(w_dev[big] / w_ref[big] - 1.0)) < 1e-8                                             # (measured)
         assert np.allclose(w_dev.sum(axis=0), 1.0, rtol=1e-12)
     finally:
         for b in bufs:
             b.free()
+
+
+def test_rbf_bench_leg_full_size_against_the_oracle(ctx):
+    """bench.py's `rbf_f64` leg (BASELINE.json configs[1] as worded: "32-member x 2000-timestep synthetic, RBF GP fp64") exactly as
+    bench.py runs it - Workload(ctx, 32, 2000, 8, T = 2, "rbf"): bench's seed, resident buffers, one batched fit - with members 0
+    and 31 against the oracle at BASELINE's 1e-5.  RBF has no reference call site (SURVEY App. A "extension kernels"): the pin is
+    the oracle's restatement of GPflow 2.1.5's SquaredExponential."""
+    M, N, R, T = 32, 2000, 8, 2
+    data, obs = go.synthetic_ensemble(M, N, R=R, seed=0xB4E5)
+    X, y, nu = member_inputs(data)
+    dX, dy, dnu = ctx.to_device(X), ctx.to_device(y), ctx.to_device(nu)
+    dmu, dcov, dchol = ctx.empty((M, N)), ctx.empty((M, N, N)), ctx.empty((M, N, N))
+    dld, dhyp, dbasis = ctx.empty((M,)), ctx.empty((M, 2)), ctx.empty((M, 2, N))
+    bufs = [dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis]
+    try:
+        info = ctx.gp_fit_batch_dev(M, N, R, dX, dy, dnu, T, dmu, dcov, dchol, dld, dhyp, basis=dbasis, kernel=go.KERNEL_RBF)
+        assert not info.any()
+        mu, hyp, ld = dmu.download(), dhyp.download(), dld.download()
+        assert np.isfinite(mu).all() and np.isfinite(ld).all()
+        for m in (0, M - 1):
+            cov = np.empty((N, N)); ch = np.empty((N, N))
+            ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, cov.ctypes.data, dcov.offset(m * N * N * 8), cov.nbytes))
+            ctx._check(ctx.lib.bayens_memcpy_d2h(ctx.h, ch.ctypes.data, dchol.offset(m * N * N * 8), ch.nbytes))
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T, kernel=go.KERNEL_RBF)
+            Lc, ldo = go.mvn_factor(co)
+            assert relerr(mu[m], mo) < REL_TOL and relerr(cov, co) < REL_TOL and relerr(hyp[m], ho) < REL_TOL, m
+            assert relerr(ch, Lc) < REL_TOL and abs(ld[m] - ldo) < REL_TOL * abs(ldo), m
+            assert np.array_equal(cov, cov.T)
+    finally:
+        for b in bufs:
+            b.free()
+
+
+def test_ill_conditioned_members_against_extended_precision(ctx):
+    """Members with a variance of ~1e-11 across realisations at one time step (two realisations 6e-6 apart): cond(Lam) ~ 1e11, so
+    an fp64 evaluation of the fit is determined to cond * eps ~ 1e-5 at best - and "device vs oracle" then compares two fp64
+    answers.  The arbiter is the 50-digit twin of the oracle (oracle/gp_oracle_mp.py -> tests/golden/illcond_*.npz, which also
+    records that the fp64 oracle itself is <= 1e-6 from it).  Round 3's sweep (profiles/r03_fuzz_seed32.log, case 21 = illcond_s32c21)
+    had the fused kernels 2.3 (relative) off on the mean: m = S theta1 through the explicit S, then u = G m - L^T (y / nu).  Every
+    route is held to BASELINE's 1e-5 against the 50-digit answer: the fused small-member kernel (N = 24), the general path
+    (the same member, bayens_set_fit_route), the fused mid-size kernel (N = 96), with and without loss samples (the sample of
+    iteration 0 keeps the first iteration in its general form)."""
+    for tag, routes in (("illcond_s32c21", (0, 1)), ("illcond_n96", (0, 1))):
+        g = np.load(os.path.join(GOLDEN, tag + ".npz"))
+        X, y, nu = go.prologue(g["data"])
+        assert nu.min() < 1e-9 * nu.max()
+        for T in g["T"]:
+            T = int(T)
+            assert np.all(g[f"oracle_err_T{T}"] < 1e-5) and g[f"cond_lam_T{T}"] > 1e10
+            for route in routes:
+                for want_loss in (False, True):
+                    ctx.set_fit_route(route)
+                    try:
+                        out = ctx.gp_fit_batch(X[None], y[None], nu[None], T, want_loss=want_loss)
+                    finally:
+                        ctx.set_fit_route(0)
+                    where = (tag, T, "general" if route else "fused", want_loss)
+                    assert not out["info"].any(), where
+                    assert relerr(out["mu"][0], g[f"mu_T{T}"]) < REL_TOL, (where, relerr(out["mu"][0], g[f"mu_T{T}"]))
+                    assert relerr(out["cov"][0], g[f"cov_T{T}"]) < REL_TOL, (where, relerr(out["cov"][0], g[f"cov_T{T}"]))
+                    assert relerr(out["hyp"][0], g[f"hyp_T{T}"]) < 1e-8, (where, relerr(out["hyp"][0], g[f"hyp_T{T}"]))
 
 
 def test_config3_full_size_against_the_fp64_oracle(ctx):

@@ -163,3 +163,49 @@ def test_config5_weighting_step_over_the_chunk_boundary(ctx):
             assert relerr(w.reshape(M, G, N)[:, g], w_ref) < 1e-9, g
             rm, rv, _ = go.barycentre(w_ref, mus, vars_)
             assert relerr(bmu.reshape(G, N)[g], rm) < 1e-9 and relerr(bvar.reshape(G, N)[g], rv) < 1e-9, g
+
+
+def test_config5_at_the_benchmarked_launch_shape(ctx):
+    """bench.py's own config-5 launch (FieldWorkload(ctx, 32, 1728, 86, 8, T = 2, "reduced"), built by bench.py's class on
+    bench.py's seed): B = 55 296 fits of N = 86 in ONE launch of the fused kernel with the reduced export on resident buffers.
+    info == 0 for every fit; 13 members spread over the launch (first / last workgroup round included) against the oracle; the
+    per-gridpoint weights and barycentre of the step at three grid points against weights.py:88-123 / ensemble_scheme.py:52-78."""
+    import bench
+    M, G, N, R, T = 32, 1728, 86, 8, 2
+    fw = bench.FieldWorkload(ctx, M, G, N, R, T, "reduced", keep_host=True)
+    try:
+        X, y, nu, obs = fw.host
+        B = fw.B
+        assert B == 55296
+        info = fw.fit()
+        assert info.shape == (B,) and not info.any()
+        bad = fw.weighted_posterior()
+        mu, var, ld, hyp = fw.dmu.download(), fw.dvar.download(), fw.dld.download(), fw.dhyp.download()
+        basis, w = fw.dbasis.download(), fw.dw.download().reshape(M, G, N)
+        bmu, bvar = fw.dbmu.download().reshape(G, N), fw.dbvar.download().reshape(G, N)
+    finally:
+        fw.free()
+    assert bad == 0 and np.isfinite(mu).all() and np.isfinite(var).all() and np.isfinite(ld).all() and np.isfinite(basis).all()
+    import scipy.linalg as sla
+    with threadpool_limits(1):
+        for b in list(range(0, B, 4608)) + [B - 1]:                 # 13 members
+            mo, co, ho = go.gp_fit(X[b], y[b], nu[b], T)
+            Lc, ldo = go.mvn_factor(co)
+            assert relerr(mu[b], mo) < 1e-10 and relerr(var[b], np.diag(co)) < 1e-10 and relerr(hyp[b], ho) < 1e-10, b
+            assert abs(ld[b] - ldo) < 1e-9 * abs(ldo), b
+            assert relerr(basis[b, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 1e-9, b
+            assert relerr(basis[b, 1], sla.solve_triangular(Lc, mo, lower=True)) < 1e-9, b
+        for g in (0, 1000, G - 1):
+            lls, mus, vars_ = [], [], []
+            for m in range(M):
+                b = m * G + g
+                mo, co, _ = go.gp_fit(X[b], y[b], nu[b], T)
+                Lc, ldo = go.mvn_factor(co)
+                lls.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, Lc, ldo, obs[g])))
+                mus.append(mo); vars_.append(np.diag(co))
+            w_ref, _ = go.loglik_weights(np.stack(lls), 1e-3)
+            assert np.isfinite(w_ref).all()
+            big = w_ref > 1e-300
+            assert np.max(np.abs(w[:, g][big] / w_ref[big] - 1.0)) < 1e-5, g          # element-wise (north_star: weights to 1e-5)
+            rm, rv, _ = go.barycentre(w_ref, np.stack(mus), np.stack(vars_))
+            assert relerr(bmu[g], rm) < 1e-9 and relerr(bvar[g], rv) < 1e-9, g
