@@ -123,6 +123,7 @@ def load():
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     lib.bayens_set_medium_min_batch.argtypes = [_vp, C.c_int]
     lib.bayens_set_fit_route.argtypes = [_vp, C.c_int]
+    lib.bayens_small_wave_stamps.argtypes = [_vp, _vp]
     lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
@@ -699,6 +700,12 @@ class Context:
         out = np.zeros(32, dtype=np.uint64) if read else None
         self._check(self.lib.bayens_small_stamps(self.h, 1 if enable else 0, _ptr(out)))
         return out
+
+    def small_wave_stamps(self):
+        """Per-wave stamps of the last recorded small fit: (8, 16) uint64 (zeros where a build places no stamp)."""
+        out = np.zeros(128, dtype=np.uint64)
+        self._check(self.lib.bayens_small_wave_stamps(self.h, _ptr(out)))
+        return out.reshape(8, 16)
 
     def test_potrf(self, A):
         A = np.array(A, dtype=np.float64, order="C", copy=True)

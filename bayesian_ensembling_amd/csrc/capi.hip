@@ -1658,14 +1658,23 @@ int bayens_bench_diag16(bayens_ctx* c, int variant, int waves, int reps, double*
 int bayens_small_stamps(bayens_ctx* c, int enable, unsigned long long* stamps32) {
   return guarded(c, [&]() {
     if (enable && !c->small_stamps) {
-      BAYENS_HIP(hipMalloc((void**)&c->small_stamps, 32 * sizeof(unsigned long long)));
-      BAYENS_HIP(hipMemset(c->small_stamps, 0, 32 * sizeof(unsigned long long)));
+      BAYENS_HIP(hipMalloc((void**)&c->small_stamps, 160 * sizeof(unsigned long long)));
+      BAYENS_HIP(hipMemset(c->small_stamps, 0, 160 * sizeof(unsigned long long)));
     }
     if (stamps32 && c->small_stamps) {
       BAYENS_HIP(hipStreamSynchronize(c->stream));
       BAYENS_HIP(hipMemcpy(stamps32, c->small_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     if (!enable && c->small_stamps) { (void)hipFree(c->small_stamps); c->small_stamps = nullptr; }
+    return 0;
+  });
+}
+
+int bayens_small_wave_stamps(bayens_ctx* c, unsigned long long* stamps128) {
+  return guarded(c, [&]() {
+    if (!stamps128 || !c->small_stamps) return fail(c, BAYENS_E_ARG, "small_wave_stamps: recording is off (bayens_small_stamps(ctx, 1, NULL) first)");
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    BAYENS_HIP(hipMemcpy(stamps128, c->small_stamps + 32, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
   });
 }

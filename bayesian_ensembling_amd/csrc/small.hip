@@ -21,6 +21,7 @@
 // full covariance, 2.8 KB with the reduced export).  tests/dev/small_proto.py is the NumPy model of these phases.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "hip_prims.h"
 #include "small.h"
@@ -93,6 +94,8 @@ __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
 #define SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // diagnostic: wave 0 / lane 0 of workgroup 0 stamps the phase boundaries of its member (g.stamps null in production)
 #define STAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[k] = __builtin_readcyclecounter(); } while (0)
+// ... and every wave of workgroup 0 its own (g.stamps[32 + 16 wave + k]; bayens_small_wave_stamps)
+#define WSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && lane == 0) g.stamps[32 + 16 * wave + (k)] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ v4r ld_tile(const real* t, const Lane& o) {
   v4r a;
@@ -557,7 +560,9 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
   vecr* av = mv + NP;                   // loss samples: L m - y; prediction: the posterior mean
   vecr* wv = av + NP;                   // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
   vecr* uv = wv + NP;                   // u = L^T D (L m - y) = G m - L^T (y / nu)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index is made visibly wave-uniform: everything derived from it - tile indices, LDS tile addresses, the branches of
+  //  the tile-to-wave tables - stays in scalar registers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   Lane o;
   lane_init(o, lane);
   const int N = g.N, R = g.R;
@@ -595,6 +600,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 
     // hyper-parameters of the coming kernel matrix -> misc[8..10]
     auto refresh_hypers = [&]() {
+      WSTAMP(8);
       if (tid == 0) {
         const double ls = softplus_d(misc[1]);
         misc[8] = softplus_d(misc[0]); misc[9] = ls; misc[10] = 1.0 / (ls * ls);
@@ -605,11 +611,13 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     // (with_m: also Cb <- tril(gamma (K0 + J I) + diag(nu)), the matrix whose inverse the first iteration's gradient needs)
     auto kmat = [&](bool with_m = false) {
       const double var = misc[8], inv_ls2 = misc[10];
+      WSTAMP(9);
 #pragma unroll 1
       for (int p = wave; p < NTT; p += NW) {
         int i, j;
         unpack_lower(p, i, j);
         const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+        if (p == wave) WSTAMP(10);
         v4r kt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -622,6 +630,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           kt[r] = (real)K;
         }
         st_tile(Lb + p * TS, o, kt);
+        if (p == wave) WSTAMP(11);
         if (with_m) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -631,7 +640,9 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           st_tile(Cb + p * TS, o, kt);
         }
       }
+      WSTAMP(12);
       SYNC();
+      WSTAMP(13);
     };
 
     // -ELBO (the training loss the reference samples after iterations 0, 25, 50, ..., models.py:211-215; GPflow VGP.elbo with
@@ -649,7 +660,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         for (int j = 0; j <= i; ++j) {
           v4r acc = {0, 0, 0, 0};
           acc = acc_run(acc, 0, i + 1, [&](int k, int q) { return Lb[lt(i, k) * TS + o.rc[q]]; },
-                        [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
+                        [&](int k, int q) { return Cb[k >= j ? lt(k, j) * TS + o.cr[q] : lt(j, k) * TS + o.rc[q]]; });
           const v4r lt_ = ld_tile(Lb + lt(i, j) * TS, o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) fr[r] = fma((double)acc[r], (double)lt_[r], fr[r]);
@@ -829,8 +840,10 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
               acc[r] = (real)((((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0) - (double)st[s][r]) / g.gamma);
           } else {
             acc = acc_run(acc, 0, NT,
-                          [&](int k, int q) { return k <= i ? Lb[lt(i, k) * TS + o.rc[q]] : Lb[lt(k, i) * TS + o.cr[q]]; },
-                          [&](int k, int q) { return k >= j ? Cb[lt(k, j) * TS + o.cr[q]] : Cb[lt(j, k) * TS + o.rc[q]]; });
+                          // (ONE load per operand with a selected address: a choice between two loads is a branch, and operand loads
+                          //  in separate basic blocks cannot be issued together - every one of them then exposes its LDS latency)
+                          [&](int k, int q) { return Lb[k <= i ? lt(i, k) * TS + o.rc[q] : lt(k, i) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return Cb[k >= j ? lt(k, j) * TS + o.cr[q] : lt(j, k) * TS + o.rc[q]]; });
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -939,101 +952,147 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
     STAMP(12);
     STAMP(13);
-    // mu = A^T m with A^T = K0 L^-T = L - J L^-T
+    // A^T = K0 L^-T = L - J L^-T enters every product below as an MFMA operand.  Forming its elements on the fly (a read of L, a
+    // read of L^-1, an fma - rounds 2-3) put fp64 VECTOR instructions into the operand path, and those share the matrix pipe: each
+    // waits out the MFMAs of the SIMD's other wave (tools/diag16_bench.py: 7.5 cycles per dependent fma alone, 71 beside MFMAs) -
+    // the products ran at a fifth of the pipe rate.  Round 4: L^-1 is scaled by -J in place once (Wb' = -J L^-1: nothing after
+    // this needs the unscaled inverse: A^T = L + Wb'^T, J^2 L^-T L^-1 = Wb'^T Wb'), the six diagonal tiles of A^T are formed
+    // explicitly in DLi, and every operand is a plain LDS read again.
+#pragma unroll 1
+    for (int p = wave; p < NTT; p += NW) {
+      v4r t = ld_tile(Wb + p * TS, o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = (real)(-J * (double)t[r]);
+      st_tile(Wb + p * TS, o, t);
+    }
+    SYNC();
+    for (int i = wave; i < NT; i += NW) {              // D_i = L_ii + (Wb'_ii)^T (L_ii is zero above its diagonal, L^-1_ii too)
+      v4r t = ld_tile(Lb + lt(i, i) * TS, o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = t[r] + Wb[lt(i, i) * TS + o.rc[r]];       // element (kq[r], lr) of the transpose
+      st_tile(DLi + i * TS, o, t);
+    }
+    // mu = A^T m = L m + Wb'^T m
 #pragma unroll 1
     for (int i = wave; i < NT; i += NW) {
       const double s1 = mv_lower<NT>(Lb, mv, i, o);
       const double s2 = mv_lower_t<NT>(Wb, mv, i, o);
-      if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s1 - J * s2);               // av = mu (padded part 0)
+      if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s1 + s2);                   // av = mu (padded part 0)
     }
-    // (av is read after the barriers of the covariance loop)
+    SYNC();                                                                 // (D tiles; av is read after the barriers below)
     STAMP(14);
-    // cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T S) A, one tile row at a time.  E_i* = A^T_i* S is staged in LDS,
-    // alternately in DCi and DLi (both dead here), so that the tile row i of cov and the staging of row i+1 share a
-    // phase: E tile l of the next row is dealt to wave NW-1-l, cov tile (i, j) to wave j.
-    // A-operand element [lr][4q + lk] of A^T(i, k) = L_ik (k < i), -J (L^-1)_ki^T (k > i), L_ii - J (L^-1)_ii^T (k = i),
-    // without branches: one read from the tile that applies (L normal or L^-1 transposed) plus the diagonal L^-1 tile
-    // scaled by -J or 0, so that the operand loads of the next step can be issued ahead
+    // cov = diag(nu + J) - J^2 L^-T L^-1 + A^T S A as ONE product phase (round 4; rounds 2-3 staged E = A^T S row by row through
+    // LDS: six phases with at most i + 1 of the eight waves on a row's tiles - 83 k of the prediction's 192 k cycles).
+    // A^T S A = At F with F = S At^T (At = A^T = L - J L^-T).  A unit of work is half a block column of F: wave (j, h) forms
+    // F(l, j) for l in its half of the contraction range in REGISTERS (an accumulator tile is a B operand as it stands), then its
+    // partial sums  cov(i, j) += sum_{l in half} At(i, l) F(l, j),  i = j .. NT-1,  with B from registers; the L^-T L^-1 terms are
+    // dealt over the two halves by parity (with Wb' = -J L^-1 they are plain Gram products).  The h = 1 partials meet the h = 0 ones through Cb (S is dead by then).  NT = 6:
+    // twelve units on eight waves - columns 0, 1 alone, (2, 5) and (3, 4) paired: 46 ... 57 tile steps per wave.
+    // A-operand element [lr][kq[q]] of A^T(i, k): L_ik (k < i), D_i (k = i), Wb'_ki^T (k > i) - which tile is a scalar choice
     auto at_a = [&](int i, int k, int q) -> real {
-      const bool low = k <= i;
-      const real* t1 = low ? Lb + lt(i, k) * TS : Wb + lt(k, i) * TS;
-      const real v1 = t1[low ? o.rc[q] : o.cr[q]];
-      const real v2 = Wb[lt(i, i) * TS + o.cr[q]];
-      return (real)fma(k == i ? -J : 0.0, (double)v2, (low ? 1.0 : -J) * (double)v1);
+      const int base = k < i ? Y::LB + lt(i, k) * TS : (k == i ? Y::DL + i * TS : Y::WB + lt(k, i) * TS);
+      return tiles_base()[base + (k <= i ? o.rc[q] : o.cr[q])];
     };
-    auto stage_row = [&](int i, real* Eb) {
-#pragma unroll 1
-      for (int l = NW - 1 - wave; l < NT; l += NW) {
-        v4r acc = {0, 0, 0, 0};
-        acc = acc_run(acc, 0, NT, [&](int k, int q) { return at_a(i, k, q); },
-                      [&](int k, int q) { return k >= l ? Cb[lt(k, l) * TS + o.cr[q]] : Cb[lt(l, k) * TS + o.rc[q]]; });
-        st_tile(Eb + l * TS, o, acc);
+    constexpr int HL = NT / 2;                       // NT is 2, 4 or 6
+    constexpr int T1 = NT == 6 ? 2 : 1;              // tiles of a wave's second unit (NT = 6 only: columns 4 and 5)
+    const int ch = wave & 1, cj0 = wave >> 1, cj1 = NT + 1 - cj0;
+    const bool on0 = cj0 < NT, on1 = NT == 6 && wave >= 4;
+    v4r pc0[NT], pc1[T1];
+    auto cov_unit = [&](auto& pc, auto maxt, int j, bool on) {
+      constexpr int MAXT = decltype(maxt)::value;
+      const int l0 = ch * HL;
+      v4r f[HL];
+#pragma unroll
+      for (int ll = 0; ll < HL; ++ll) {
+        const int l = l0 + ll;
+        f[ll] = v4r{0, 0, 0, 0};
+        if (on)
+          f[ll] = acc_run(f[ll], 0, NT,
+                          [&](int k, int q) { return Cb[k <= l ? lt(l, k) * TS + o.rc[q] : lt(k, l) * TS + o.cr[q]]; },
+                          [&](int k, int q) { return at_a(j, k, q); });
       }
-    };
-    stage_row(0, DCi);
-    SYNC();
-    constexpr int CPW = (NT + NW - 1) / NW;        // cov tiles of one tile row per wave
-    v4r covt[NT][CPW];
+      if (MAXT == NT) WSTAMP(1);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      real* Eb = (i & 1) ? DLi : DCi;
+      for (int t = 0; t < MAXT; ++t) {
+        const int i = j + t;
+        pc[t] = v4r{0, 0, 0, 0};
+        if (on && i < NT) {
+          v4r acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
 #pragma unroll
-      for (int u = 0; u < CPW; ++u) {
-      const int j = wave + u * NW;
-      covt[i][u] = v4r{0, 0, 0, 0};
-      if (j <= i) {
-        v4r acc = {0, 0, 0, 0};
-        acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
-                      [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+          for (int ll = 0; ll < HL; ++ll) {
+            real a[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (real)(acc[r] * (-J * J));
-        // B[kq][col] = A^T(j, l)[col][kq]: the same element function with the roles of the tile indices as for A
-        acc = acc_run(acc, 0, NT, [&](int l, int q) { return Eb[l * TS + o.rc[q]]; },
-                      [&](int l, int q) { return at_a(j, l, q); });
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-          if (row == col) acc[r] = (real)(acc[r] + (1.0 / (double)dv[row] + J));
-          if (row < N && col < N) {
-            // (a diagonal tile is a full 16x16 accumulation: only its lower half is exported here, the upper half is
-            //  mirrored from it below, so that cov is exactly symmetric like the general path's extraction)
-            if (g.cov && (i != j || col <= row)) {
-              g.cov[((long)b * N + row) * N + col] = acc[r];
-              if (i != j) g.cov[((long)b * N + col) * N + row] = acc[r];
-            }
-            if (g.var && row == col) g.var[(long)b * N + row] = acc[r];
+            for (int q = 0; q < 4; ++q) a[q] = at_a(i, l0 + ll, q);
+            acc = MFMAR(a[0], f[ll][0], acc);
+            acc2 = MFMAR(a[1], f[ll][1], acc2);
+            acc = MFMAR(a[2], f[ll][2], acc);
+            acc2 = MFMAR(a[3], f[ll][3], acc2);
           }
+          if (((i + j) & 1) == ch) {                 // - J^2 (L^-T L^-1)_ij = - sum_{k >= i} Wb'_ki^T Wb'_kj
+            v4r qa = {0, 0, 0, 0};
+            qa = acc_run(qa, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
+                         [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] - qa[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pc[t][r] = acc[r] + acc2[r];
         }
-        covt[i][u] = acc;
       }
-      }
-      if (i + 1 < NT) stage_row(i + 1, (i & 1) ? DCi : DLi);
-      SYNC();
+    };
+    WSTAMP(0);
+    cov_unit(pc0, std::integral_constant<int, NT>(), cj0, on0);
+    WSTAMP(2);
+    cov_unit(pc1, std::integral_constant<int, T1>(), on1 ? cj1 : 0, on1);
+    WSTAMP(3);
+    SYNC();                                          // every product has read S (Cb), L (Lb) and L^-1 (Wb)
+    WSTAMP(4);
+    if (ch == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (on0 && cj0 + t < NT) st_tile(Cb + lt(cj0 + t, cj0) * TS, o, pc0[t]);
+#pragma unroll
+      for (int t = 0; t < T1; ++t)
+        if (on1 && cj1 + t < NT) st_tile(Cb + lt(cj1 + t, cj1) * TS, o, pc1[t]);
     }
+    SYNC();
+    // the h = 0 wave of a column completes its tiles, exports them and leaves the bordered matrix of chol(cov) in Lb: rows N
+    // (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
+    auto cov_finish = [&](v4r acc, int i, int j) {
+      const v4r other = ld_tile(Cb + lt(i, j) * TS, o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+        acc[r] = acc[r] + other[r];
+        if (row == col) acc[r] = (real)(acc[r] + (1.0 / (double)dv[row] + J));
+        if (row < N && col < N) {
+          // (a diagonal tile is a full 16x16 accumulation: only its lower half is exported here, the upper half is
+          //  mirrored from it below, so that cov is exactly symmetric like the general path's extraction)
+          if (g.cov && (i != j || col <= row)) {
+            g.cov[((long)b * N + row) * N + col] = acc[r];
+            if (i != j) g.cov[((long)b * N + col) * N + row] = acc[r];
+          }
+          if (g.var && row == col) g.var[(long)b * N + row] = acc[r];
+        } else {
+          double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
+          if (col < N && row == N) v = 1.0;
+          if (col < N && row == N + 1) v = (double)av[col];
+          acc[r] = (real)v;
+        }
+      }
+      st_tile(Lb + lt(i, j) * TS, o, acc);
+    };
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (on0 && cj0 + t < NT) cov_finish(pc0[t], cj0 + t, cj0);
+#pragma unroll
+      for (int t = 0; t < T1; ++t)
+        if (on1 && cj1 + t < NT) cov_finish(pc1[t], cj1 + t, cj1);
+    }
+    WSTAMP(5);
     if (g.mu)
       for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = (real)av[t];
-    // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) {
-      const int j = wave + u * NW;
-      if (j <= i) {
-        v4r t = covt[i][u];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-          if (row >= N || col >= N) {
-            double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
-            if (col < N && row == N) v = 1.0;
-            if (col < N && row == N + 1) v = (double)av[col];
-            t[r] = (real)v;
-          }
-        }
-        st_tile(Lb + lt(i, j) * TS, o, t);
-      }
-      }
-    }
     SYNC();
     STAMP(15);
     if (g.cov) {      // exact symmetry inside the diagonal tiles: upper element = lower element

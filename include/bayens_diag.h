@@ -49,6 +49,9 @@ int bayens_bench_diag16(bayens_ctx* ctx, int variant, int waves, int reps, doubl
  * makes every later small fit record the phase boundaries of workgroup 0's last member / iteration; stamps32 (nullable)
  * receives the 32 recorded values; enable = 0 switches the recording off again. */
 int bayens_small_stamps(bayens_ctx* ctx, int enable, unsigned long long* stamps32);
+/* ... and the per-wave stamps of the same recording: stamps128[wave * 16 + k], k-th WSTAMP of wave `wave` (0..7) of workgroup 0
+ * (which phases carry them is a property of the build; tools/small_phases.py prints what it finds). */
+int bayens_small_wave_stamps(bayens_ctx* ctx, unsigned long long* stamps128);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */

@@ -242,15 +242,17 @@ def fit(X, y_in, nu_in, T, kernel=0, gamma=0.5, lr=0.01, jitter=1e-6):
 
     mu = matvec_lower(Lb, m) - jitter * matvec_lower(Wb, m, trans=True)
     covt = Buf(NT)
-    for i in range(NT):
-        E = [sum(At(i, k) @ Cb.sym(k, l) for k in range(NT)) for l in range(NT)]
-        for j in range(i + 1):
-            acc = np.zeros((16, 16))
+    # one product phase (round 4): F = S At^T column by column (registers of the column's two waves, each half of the
+    # contraction range), cov(i, j) = sum_l At(i, l) F(l, j) - J^2 (L^-T L^-1)_ij + diag
+    for j in range(NT):
+        F = [sum(Cb.sym(l, k) @ At(j, k).T for k in range(NT)) for l in range(NT)]
+        for i in range(j, NT):
+            halves = [sum(At(i, l) @ F[l] for l in range(h * NT // 2, (h + 1) * NT // 2)) for h in (0, 1)]
+            q = np.zeros((16, 16))
             for k in range(i, NT):
-                acc += Wb[k, i].T @ Wb[k, j]
-            acc = -jitter * jitter * acc
-            for l in range(NT):
-                acc += E[l] @ At(j, l).T
+                q += Wb[k, i].T @ Wb[k, j]
+            halves[(i + j) & 1] = halves[(i + j) & 1] - jitter * jitter * q
+            acc = halves[0] + halves[1]
             if i == j:
                 acc += np.diag(nu[16 * i:16 * i + 16] + jitter)
             covt[i, j] = acc

@@ -23,8 +23,17 @@ for T in (2, 50):
         ms = ctx.timer_stop()
     print(f"B={B} N={N} R={R} T={T}: {ms:.2f} ms -> {B / (ms * 1e-3):.0f} fits/s; {ms * 1e3 / (B / 256):.1f} us per fit per CU; info max {int(info.max())}", flush=True)
 ctx.small_stamps(True)
-ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, 2, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
+if len(sys.argv) > 4 and sys.argv[4] == "reduced":
+    dvar = ctx.empty((B, N))
+    for rep in range(3):
+        ctx.timer_start()
+        ctx.gp_fit_batch_reduced_dev(B, N, R, dX, dy, dnu, 2, dmu, dvar, dld, dhyp, dbasis)
+        ms = ctx.timer_stop()
+    print(f"reduced export, T=2: {ms:.2f} ms -> {B / (ms * 1e-3):.0f} fits/s", flush=True)
+else:
+    ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, 2, dmu, dcov, dchol, dld, dhyp, basis=dbasis)
 st = ctx.small_stamps(True, read=True).astype(np.int64)
+ws = ctx.small_wave_stamps().astype(np.int64)
 ctx.small_stamps(False)
 names = ["hypers+kmat", "potrf L (+L^-1, G)", "Lam, theta1", "potrf C (+C^-1, S)", "S, G -> LDS", "m, u", "G S -> Phi", "-", "W = Phi Linv", "Kbar, grad, Adam",
          "(to predict)", "P: kmat+potrf (+L^-1)", "-", "P: mu", "P: cov rows", "P: potrf cov", "P: outputs", "-"]
@@ -39,3 +48,10 @@ print("iteration total", tot_it, "predict total", st[17] - st[11])
 
 
 
+
+if ws.any():
+    print("per-wave stamps (cycles since the wave's first stamp; 0 = not placed):")
+    for w in range(8):
+        base = ws[w, 0]
+        print(f"  wave {w}: " + " ".join(f"{(v - base) if v else 0:7d}" for v in ws[w, :8]) + "  |  " +
+              " ".join(f"{(v - ws[w, 8]) if v else 0:7d}" for v in ws[w, 8:16]))
