@@ -111,6 +111,17 @@ struct bayens_ctx {
     return mscratch;
   }
   unsigned long long* small_stamps = nullptr;   // diagnostic phase stamps of the fused kernel (bayens_small_stamps)
+  double* kpark = nullptr;         // kernel-value park of the fused small-member kernel (small.hip), grown on demand
+  size_t kpark_cap = 0;
+  double* small_park(size_t count) {
+    if (count > kpark_cap) {
+      if (kpark) (void)hipFree(kpark);
+      kpark = nullptr;
+      if (hipMalloc((void**)&kpark, count * sizeof(double)) != hipSuccess) throw HipError{BAYENS_E_ALLOC, "hipMalloc"};
+      kpark_cap = count;
+    }
+    return kpark;
+  }
   RcclApi rccl;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -287,6 +298,7 @@ int bayens_ctx_destroy(bayens_ctx* c) {
   if (c->mscratch) (void)hipFree(c->mscratch);
   if (c->xbuf) (void)hipFree(c->xbuf);
   if (c->small_stamps) (void)hipFree(c->small_stamps);
+  if (c->kpark) (void)hipFree(c->kpark);
   for (auto* p : c->gprims) delete p;
   for (auto s : c->gstreams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   delete c->prims;
@@ -502,6 +514,7 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
       int* dinfo = st.scratch<int>((size_t)B);
       smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo};
       a.stamps = c->small_stamps;
+      a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
       a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
       a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
       smalln::small_fit(c->stream, a, c->n_cus);
@@ -593,6 +606,7 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, con
     int* dinfo = st.scratch<int>((size_t)B);
     smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo};
     a.stamps = c->small_stamps;
+    a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
     smalln::small_fit(c->stream, a, c->n_cus);
     std::vector<int> hinfo(B, 0);
     BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -22,13 +22,15 @@ struct State {
   DeviceWs dws;
   int* small_info = nullptr;       // device info[] of the fused small-member path
   int small_info_cap = 0, n_cus = 256;
+  double* kpark = nullptr;         // kernel-value park of the fused small-member kernel
+  size_t kpark_cap = 0;
   explicit State(hipStream_t s) : stream(s), prims(s) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       n_cus = prop.multiProcessorCount;
   }
-  ~State() { if (small_info) (void)hipFree(small_info); }
+  ~State() { if (small_info) (void)hipFree(small_info); if (kpark) (void)hipFree(kpark); }
 };
 }  // namespace bayens_f32
 
@@ -61,6 +63,14 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
                           nullptr, a.chol, a.logdet, a.hyp, a.basis, st->small_info};
       g.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
       g.loss = g.loss_stride > 0 ? a.loss_trace : nullptr;
+      const size_t need = smalln::small_park_doubles(a.B, a.N, st->n_cus);
+      if (need > st->kpark_cap) {
+        if (st->kpark) (void)hipFree(st->kpark);
+        st->kpark = nullptr;
+        BAYENS_HIP(hipMalloc((void**)&st->kpark, need * sizeof(double)));
+        st->kpark_cap = need;
+      }
+      g.kpark = st->kpark;
       smalln::small_fit(st->stream, g, st->n_cus);
       BAYENS_HIP(hipMemcpyAsync(a.info_host, st->small_info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
       BAYENS_HIP(hipStreamSynchronize(st->stream));

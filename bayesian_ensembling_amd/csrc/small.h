@@ -29,7 +29,13 @@ struct SmallArgs {
   int loss_stride = 0;
   unsigned long long* stamps = nullptr;   // diagnostic: 32 cycle-counter stamps of workgroup 0 (null in production)
   int tune = 0;                           // measurement switches (BAYENS_SMALL_TUNE)
+  // per-workgroup park of the unit-variance kernel values (k1, k2) of an iteration's kernel matrix, so that its hyper-gradient
+  // does not evaluate sqrt / exp a second time: small_park_doubles() doubles, device memory (L2-resident: 86 KB per workgroup)
+  double* kpark = nullptr;
 };
+
+// size of SmallArgs::kpark for a batch of B members of N time points on a device with n_cus compute units
+size_t small_park_doubles(int B, int N, int n_cus);
 
 bool small_fit_supported(int N, int R);
 // queues the fit of all B members on `stream` (grid = resident workgroups, members dealt round-robin)

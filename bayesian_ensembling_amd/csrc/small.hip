@@ -454,7 +454,7 @@ __device__ __forceinline__ int potrf_lds(int a_off, int d_off, int x_off, const 
 template <int NT>
 __device__ __forceinline__ double mv_lower(const real* Lb, const vecr* x, int i, const Lane& o) {     // (L x)[16 i + lr]
   double s = 0.0;
-#pragma unroll 1
+#pragma unroll 2
   for (int k = 0; k <= i; ++k) {
     const real* t = Lb + lt(i, k) * TS;
 #pragma unroll
@@ -467,7 +467,7 @@ __device__ __forceinline__ double mv_lower(const real* Lb, const vecr* x, int i,
 template <int NT>
 __device__ __forceinline__ double mv_lower_t(const real* Lb, const vecr* x, int j, const Lane& o) {   // (L^T x)[16 j + lr]
   double s = 0.0;
-#pragma unroll 1
+#pragma unroll 2
   for (int k = j; k < NT; ++k) {
     const real* t = Lb + lt(k, j) * TS;
 #pragma unroll
@@ -502,16 +502,21 @@ __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_l
   const real* xb = X + (long)(rb < N ? rb : 0) * R;
   if (R <= 8) {                 // the common case: both operand pairs requested before the first MFMA
     const int c0 = o.lk, c1 = 4 + o.lk;
-    const double a0 = (ra < N && c0 < R) ? (double)xa[c0] : 0.0, b0 = (rb < N && c0 < R) ? (double)xb[c0] : 0.0;
-    const double a1 = (ra < N && c1 < R) ? (double)xa[c1] : 0.0, b1 = (rb < N && c1 < R) ? (double)xb[c1] : 0.0;
+    // (unconditional loads from clamped addresses, zeroed afterwards: a load under a condition is a branch whose value is
+    //  awaited at the join - four serial round trips instead of one)
+    const double la0 = (double)xa[c0 < R ? c0 : 0], lb0 = (double)xb[c0 < R ? c0 : 0];
+    const double la1 = (double)xa[c1 < R ? c1 : 0], lb1 = (double)xb[c1 < R ? c1 : 0];
+    const double a0 = (ra < N && c0 < R) ? la0 : 0.0, b0 = (rb < N && c0 < R) ? lb0 : 0.0;
+    const double a1 = (ra < N && c1 < R) ? la1 : 0.0, b1 = (rb < N && c1 < R) ? lb1 : 0.0;
     acc = MFMA(a0, b0, acc);
     if (R > 4) acc = MFMA(a1, b1, acc);
   } else {
 #pragma unroll 2
     for (int k0 = 0; k0 < R; k0 += 4) {
       const int c = k0 + o.lk;
-      const double a = (ra < N && c < R) ? (double)xa[c] : 0.0;
-      const double b = (rb < N && c < R) ? (double)xb[c] : 0.0;
+      const double la = (double)xa[c < R ? c : 0], lb = (double)xb[c < R ? c : 0];
+      const double a = (ra < N && c < R) ? la : 0.0;
+      const double b = (rb < N && c < R) ? lb : 0.0;
       acc = MFMA(a, b, acc);
     }
   }
@@ -609,7 +614,13 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     };
     // Lb <- tril(K0) + J I (identity in the padding)
     // (with_m: also Cb <- tril(gamma (K0 + J I) + diag(nu)), the matrix whose inverse the first iteration's gradient needs)
-    auto kmat = [&](bool with_m = false) {
+    // `park`: the unit-variance kernel values (k1, k2) of every tile go to the workgroup's park in device memory (accumulator
+    // order, one coalesced 512-byte row per register) for this iteration's hyper-gradient, which then evaluates no sqrt / exp
+    // (round 4: the five kernel-function passes of a T = 2 fit were 17 % of it, and they are bound by the fp64 vector rate -
+    //  tools/valu64_bench.py: 125 cycles per exp, 74 per sqrt and wave, 6.5 per v_fma_f64 and SIMD - not by their operand loads:
+    //  requesting the X operands of all tiles ahead of the hypers, or evaluating the hypers in every lane, moved nothing / cost more)
+    double* kpark = g.kpark + (size_t)blockIdx.x * (2 * NTT * TS);
+    auto kmat = [&](bool with_m = false, bool park = false) {
       const double var = misc[8], inv_ls2 = misc[10];
       WSTAMP(9);
 #pragma unroll 1
@@ -619,15 +630,26 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
         if (p == wave) WSTAMP(10);
         v4r kt;
+        double k1m[4], k2m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
           double k1, k2;
-          kern_unit<false>(g.kernel, r2[r], k1, k2);
+          if (park) kern_unit<true>(g.kernel, r2[r], k1, k2);
+          else kern_unit<false>(g.kernel, r2[r], k1, k2);
           double K = var * k1;
           if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
           else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
           kt[r] = (real)K;
+          k1m[r] = (row < N && col < N) ? k1 : 0.0;            // (the padding contributes no gradient)
+          k2m[r] = (row < N && col < N) ? k2 : 0.0;
+        }
+        if (park) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            kpark[(size_t)(2 * p) * TS + r * 64 + lane] = k1m[r];
+            kpark[(size_t)(2 * p + 1) * TS + r * 64 + lane] = k2m[r];
+          }
         }
         st_tile(Lb + p * TS, o, kt);
         if (p == wave) WSTAMP(11);
@@ -702,7 +724,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       const bool wb = it == 0 && g.gamma > 0.0 && g.n_iters >= 2 && !g.loss;
       const bool first = it == 0 && g.gamma > 0.0 && sizeof(real) == sizeof(double);
       refresh_hypers();
-      kmat(wb);                                                            // K0 + J I at the current hypers  (models.py:209)
+      kmat(wb, true);                                                      // K0 + J I at the current hypers  (models.py:209)
       STAMP(1);
       // L = chol(K0 + J I); G = L^T D L = sum_k (D^1/2 L)_k*^T (D^1/2 L)_k* is accumulated block row by block row behind
       // the factorisation (registers gt[], tiles dealt over waves 1..7)
@@ -889,12 +911,19 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       // the tiles (i, j) and (j, i) of Kbar meet the same kernel values: Kbar_ij and Kbar_ji^T = sum_k W_ki^T Linv_kj
       // are accumulated together and the kernel function is evaluated once per unordered pair.
       {
-        const double var = misc[8], ls = misc[9], inv_ls2 = misc[10];
+        const double var = misc[8], ls = misc[9];
         double gv = 0.0, gl = 0.0;
 #pragma unroll 1
         for (int p = wave; p < NTT; p += NW) {
           int i, j;
           unpack_lower(p, i, j);
+          // this wave parked the tile's kernel values itself (same tile-to-wave map as kmat): requested ahead of the products
+          double k1t[4], k2t[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            k1t[r] = kpark[(size_t)(2 * p) * TS + r * 64 + lane];
+            k2t[r] = kpark[(size_t)(2 * p + 1) * TS + r * 64 + lane];
+          }
           v4r acc = {0, 0, 0, 0};
           if (wb) {                    // the symmetric weights: (P - gamma p p^T) / 2 for the tile and its mirror image together
             acc = ld_tile(Cb + p * TS, o);
@@ -909,14 +938,8 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
               acc = acc_run(acc, i, NT, [&](int k, int q) { return Lb[lt(k, i) * TS + o.cr[q]]; },
                             [&](int k, int q) { return Wb[lt(k, j) * TS + o.cr[q]]; });
           }
-          const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-            double k1, k2;
-            kern_unit<true>(g.kernel, r2[r], k1, k2);
-            if (row < N && col < N) { gv = fma((double)acc[r], k1, gv); gl = fma((double)acc[r], k2, gl); }
-          }
+          for (int r = 0; r < 4; ++r) { gv = fma((double)acc[r], k1t[r], gv); gl = fma((double)acc[r], k2t[r], gl); }
         }
         gv = wave_sum(gv);
         gl = wave_sum(gl);
@@ -1141,6 +1164,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
   }
 }
 
+static int launch_grid(int B, int NT, int n_cus);
 template <int NT>
 static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
   const size_t lds = Layout<NT>::BYTES;
@@ -1154,9 +1178,7 @@ static void launch(hipStream_t stream, const SmallArgs& g, int n_cus) {
                                    (int)lds));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  const int per_cu = (int)(163840 / lds) > 0 ? (int)(163840 / lds) : 1;
-  int grid = n_cus * per_cu;
-  if (grid > g.B) grid = g.B;
+  const int grid = launch_grid(g.B, NT, n_cus);
   hipLaunchKernelGGL((small_fit_kernel<NT>), dim3(grid), dim3(NTH), lds, stream, g);
   BAYENS_HIP(hipGetLastError());
 }
@@ -1177,6 +1199,35 @@ __global__ void diag_bench_kernel(int variant, int reps, double* out, double see
     }
   __syncthreads();
   const int kind = variant & 255;
+  if (kind == 9 || kind == 10 || kind == 11) {   // every wave: throughput of independent fp64 vector work (9: 8 chains of v_fma_f64, 10: exp_neg, 11: sqrt_pos)
+    double x[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = 1.0 + seed + 1e-9 * lane + 0.01 * c;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int rep = 0; rep < reps; ++rep) {
+      if (kind == 9) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = fma(x[c], 0.999, 1e-3);
+      } else if (kind == 10) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = exp_neg(-x[c]) + 0.5;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = sqrt_pos(x[c]) + 0.5;
+      }
+    }
+    __syncthreads();
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum += x[c];
+    if (tid == 0) { out[0] = (double)(t1 - t0) / reps; out[1] = sum; }
+    if (sum == 12345.678) out[2] = sum;
+    return;
+  }
   if (kind == 7 || kind == 8) {           // every wave: `reps` tile products of 6 steps each from LDS tiles (the GS pattern)
     __shared__ double Tl[8 * TS];
     for (int e = tid; e < 8 * TS; e += blockDim.x) Tl[e] = 1.0 + 1e-6 * e;
@@ -1253,14 +1304,31 @@ void diag_bench(hipStream_t stream, int variant, int waves, int reps, double* ou
 
 bool small_fit_supported(int N, int R) { return N >= 1 && N <= SMALL_MAX_N && R >= 1; }
 
+static int tiles_per_side(int N) { return N + 2 <= 32 ? 2 : (N + 2 <= 64 ? 4 : 6); }
+static size_t lds_bytes(int NT) { return NT == 2 ? Layout<2>::BYTES : (NT == 4 ? Layout<4>::BYTES : Layout<6>::BYTES); }
+// workgroups of a launch: as many as are resident at once (LDS-bound: 5 / 2 / 1 per compute unit at 2 / 4 / 6 tiles per side)
+static int launch_grid(int B, int NT, int n_cus) {
+  const int per_cu = (int)(163840 / lds_bytes(NT)) > 0 ? (int)(163840 / lds_bytes(NT)) : 1;
+  const int grid = n_cus * per_cu;
+  return grid < B ? grid : B;
+}
+
+size_t small_park_doubles(int B, int N, int n_cus) {
+  const int NT = tiles_per_side(N);
+  const int grid = launch_grid(B > 0 ? B : 1, NT, n_cus);
+  return (size_t)grid * (2 * (NT * (NT + 1) / 2) * TS);
+}
+
 void small_fit(hipStream_t stream, const SmallArgs& g_in, int n_cus) {
   if (!small_fit_supported(g_in.N, g_in.R)) throw HipError{-1, "small_fit: N out of range"};
   if (g_in.B <= 0) return;
+  if (g_in.n_iters > 0 && !g_in.kpark) throw HipError{-1, "small_fit: no kernel-value park (SmallArgs::kpark)"};
   static const int tune = [] { const char* e = std::getenv("BAYENS_SMALL_TUNE"); return e ? std::atoi(e) : 0; }();
   SmallArgs g = g_in;
   g.tune = tune;
-  if (g.N + 2 <= 32) launch<2>(stream, g, n_cus);
-  else if (g.N + 2 <= 64) launch<4>(stream, g, n_cus);
+  const int NT = tiles_per_side(g.N);
+  if (NT == 2) launch<2>(stream, g, n_cus);
+  else if (NT == 4) launch<4>(stream, g, n_cus);
   else launch<6>(stream, g, n_cus);
 }
 
