@@ -96,7 +96,7 @@ __device__ __forceinline__ v4d mma_rt(v4d acc, const double* A, bool ta, const d
 __device__ __forceinline__ double tile_mv(const double* T, bool ta, const double* x, const Lane& o) {
   double s = 0.0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) s = fma(T[ta ? o.cr[q] : o.rc[q]], x[o.kq[q]], s);
+  for (int q = 0; q < 4; ++q) s = fma(T[ta ? o.cr[q] : o.rc[q]], x[o.kq(q)], s);
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
   return s;
@@ -180,7 +180,7 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
         const double* tb = slot(NT + j);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double scl = rs[16 * k + o.kq[q]];
+          const double scl = rs[16 * k + o.kq(q)];
           acc = MFMA(ta[o.cr[q]] * scl, tb[o.cr[q]] * scl, acc);
         }
         return acc;
@@ -212,7 +212,7 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
 #pragma unroll 1
       for (int jj = wave - 1; jj <= k; jj += NW - 1) {
         const double s = tile_mv(slot(NT + jj), true, yd + 16 * k, o);
-        if (o.lk == 0) wv[16 * jj + o.lr] += s;
+        if (o.lk() == 0) wv[16 * jj + o.lr()] += s;
       }
     }
   };
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       for (int p = wave; p < NTT; p += NW) {
         v4d id;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) id[r] = (i == j && o.kq[r] == o.lr) ? 1.0 : 0.0;
+        for (int r = 0; r < 4; ++r) id[r] = (i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0;
         stn(LamB + (size_t)p * TS, lane, id);            // Lam = I: q_sqrt = I
         stn(Sb + (size_t)p * TS, lane, id);              // S = I until the first natural-gradient step (n_iters = 0)
         unpack_step(i, j, NW);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         v4d kt, k1t, k2t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+          const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
           double k1, k2;
           kern_unit<true>(g.kernel, r2[r], k1, k2);
           double K = var * k1;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = wave + u * NW;
-        if (i < NT && o.lk == 0) out[16 * i + o.lr] = part[u] + beta * yv[16 * i + o.lr];
+        if (i < NT && o.lk() == 0) out[16 * i + o.lr()] = part[u] + beta * yv[16 * i + o.lr()];
       }
       GSYNC();
     };
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           for (int r = 0; r < 4; ++r) {
             double v = acc[r] * lt_[r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (o.lr == 0) Cb[(size_t)p * 16 + o.kq[r]] = v;
+            if (o.lr() == 0) Cb[(size_t)p * 16 + o.kq(r)] = v;
           }
         });
       GSYNC();
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           const v4d gt = ldn(Gb + (size_t)p * TS, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            lam[r] = (1.0 - g.gamma) * lam[r] + g.gamma * (gt[r] + ((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0));
+            lam[r] = (1.0 - g.gamma) * lam[r] + g.gamma * (gt[r] + ((i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0));
           stn(LamB + (size_t)p * TS, lane, lam);
           stn(Cb + (size_t)p * TS, lane, lam);
           unpack_step(i, j, NW);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int i = wave + u * NW;
-          if (i < NT && o.lk == 0) mv[16 * i + o.lr] = part[u];
+          if (i < NT && o.lk() == 0) mv[16 * i + o.lr()] = part[u];
         }
         GSYNC();
       }
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           v4d a = ldn(Sb + (size_t)p * TS, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int rl = o.kq[r];
-            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], (((i == j && rl == o.lr) ? 1.0 : 0.0) - a[r]) / g.gamma);
-            if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
+            const int rl = o.kq(r);
+            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], (((i == j && rl == o.lr()) ? 1.0 : 0.0) - a[r]) / g.gamma);
+            if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
             a[r] = v;
           }
           stn(Cb + (size_t)p * TS, lane, a);
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int i = wave + u * NW;
-              if (i < NT && o.lk == 0) uv[16 * i + o.lr] = gm[u] - wv[16 * i + o.lr];
+              if (i < NT && o.lk() == 0) uv[16 * i + o.lr()] = gm[u] - wv[16 * i + o.lr()];
             }
             GSYNC();
           }
@@ -721,9 +721,9 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
               v4d a = acc[s];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int rl = o.kq[r];
-                double v = fma(uv[16 * i + rl], mv[16 * j + o.lr], a[r]);
-                if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
+                const int rl = o.kq(r);
+                double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], a[r]);
+                if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
                 a[r] = v;
               }
               stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, a);
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = wave + u * NW;
-        if (i < NT && o.lk == 0) av[16 * i + o.lr] = part[u];              // av = mu (padded part 0)
+        if (i < NT && o.lk() == 0) av[16 * i + o.lr()] = part[u];              // av = mu (padded part 0)
       }
       GSYNC();
     }
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           v4d a = acc[s], t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+            const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
             if (row == col) a[r] = a[r] + (1.0 / dv[row] + J);
             t[r] = a[r];
             if (row < N && col < N) {

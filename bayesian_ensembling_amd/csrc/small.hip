@@ -56,12 +56,32 @@ __device__ __forceinline__ real* tiles_base() { return reinterpret_cast<real*>(l
 // column lr.  Step q of a tile product contracts over the index set kq[q] = {4q + lk} (fp64) / {4lk + q} (fp32) - the
 // order of a sum is free - so that in BOTH precisions accumulator register q is element (kq[q], lr): an accumulator
 // tile is a B operand as it stands, and one table of offsets serves operand reads and accumulator stores.
+#ifndef BAYENS_SMALL_HELPERS_ONLY
 struct Lane {
-  int rc[4];   // rc[q] = swizzled offset of element (lr, kq[q])
-  int cr[4];   // cr[q] = swizzled offset of element (kq[q], lr)   (= accumulator register q of this lane)
-  int kq[4];
-  int lr, lk;
+  int rc[4];   // rc[q] = swizzled offset of element (lr, kq(q))
+  int cr[4];   // cr[q] = swizzled offset of element (kq(q), lr)   (= accumulator register q of this lane)
+  int lane;
+  // lr, lk and kq(q) are two or three integer instructions away from the lane id and are NOT kept in registers (round 4): as
+  // struct members they were what the register allocator spilled to scratch - and reloaded from memory, a ~500-cycle round
+  // trip, in front of every tile epilogue that needed a row / column index
+  __device__ __forceinline__ int lr() const { return lane & 15; }
+  __device__ __forceinline__ int lk() const { return lane >> 4; }
+  __device__ __forceinline__ int kq(int q) const;
 };
+#else
+// (medium.hip keeps the members stored: its kernel is built from the same helpers, and with the computed form above it FAULTED
+//  on a 20-member batch - a memory access fault in a build whose source differs in nothing but where these integers live - while
+//  single members passed; the stored form is the build that passed every test of rounds 3 and 4.  Until that sensitivity is
+//  understood the mid-size kernel stays on the tested form.)
+struct Lane {
+  int rc[4], cr[4];
+  int kq_[4];
+  int lr_, lk_;
+  __device__ __forceinline__ int lr() const { return lr_; }
+  __device__ __forceinline__ int lk() const { return lk_; }
+  __device__ __forceinline__ int kq(int q) const { return kq_[q]; }
+};
+#endif
 
 #ifdef BAYENS_F32
 #define MFMAR(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
@@ -77,11 +97,20 @@ __device__ __forceinline__ int kq_of(int lk, int q) { return 4 * q + lk; }
 __device__ __forceinline__ int swz(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
 __device__ __forceinline__ int dist_row(int lr) { return lr; }
 #endif
+#ifndef BAYENS_SMALL_HELPERS_ONLY
+__device__ __forceinline__ int Lane::kq(int q) const { return kq_of(lane >> 4, q); }
 __device__ __forceinline__ void lane_init(Lane& o, int lane) {
-  o.lr = lane & 15; o.lk = lane >> 4;
+  o.lane = lane;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { o.kq[q] = kq_of(o.lk, q); o.rc[q] = swz(o.lr, o.kq[q]); o.cr[q] = swz(o.kq[q], o.lr); }
+  for (int q = 0; q < 4; ++q) { o.rc[q] = swz(o.lr(), o.kq(q)); o.cr[q] = swz(o.kq(q), o.lr()); }
 }
+#else
+__device__ __forceinline__ void lane_init(Lane& o, int lane) {
+  o.lr_ = lane & 15; o.lk_ = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { o.kq_[q] = kq_of(o.lk_, q); o.rc[q] = swz(o.lr_, o.kq_[q]); o.cr[q] = swz(o.kq_[q], o.lr_); }
+}
+#endif
 __device__ __forceinline__ int lt(int i, int j) { return ((i * (i + 1)) >> 1) + j; }     // j <= i
 __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
   i = 0;
@@ -133,16 +162,31 @@ template <class LoadA, class LoadB>
 __device__ __forceinline__ v4r acc_run(v4r acc, int k0, int k1, LoadA la, LoadB lb) {
   v4r acc2 = {0, 0, 0, 0};
   int k = k0;
-#pragma unroll 1
-  for (; k + 1 < k1; k += 2) {
+  if (k + 1 < k1) {
+    // software pipeline (round 4): the operands of the NEXT pair of steps are requested before the eight MFMAs of the current
+    // pair are issued, so a trip no longer starts by waiting out an LDS round trip
     real a[8], b[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); a[4 + q] = la(k + 1, q); b[4 + q] = lb(k + 1, q); }
+#pragma unroll 1
+    for (; k + 3 < k1; k += 2) {
+      real na[8], nb[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { na[q] = la(k + 2, q); nb[q] = lb(k + 2, q); na[4 + q] = la(k + 3, q); nb[4 + q] = lb(k + 3, q); }
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        acc = MFMAR(a[q], b[q], acc);
+        acc2 = MFMAR(a[q + 1], b[q + 1], acc2);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[q] = na[q]; b[q] = nb[q]; }
+    }
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
       acc = MFMAR(a[q], b[q], acc);
       acc2 = MFMAR(a[q + 1], b[q + 1], acc2);
     }
+    k += 2;
   }
   if (k < k1) {
     real a[4], b[4];
@@ -256,7 +300,7 @@ __device__ __forceinline__ v4r ld_tile_sym(const real* T, const Lane& o) {
   v4r acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = o.kq[r], col = o.lr;
+    const int row = o.kq(r), col = o.lr();
     acc[r] = T[row >= col ? swz(row, col) : swz(col, row)];
   }
   return acc;
@@ -265,7 +309,7 @@ __device__ __forceinline__ v4d ld_tile_sym64(const real* T, const Lane& o) {
   v4d acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = o.lk + 4 * r, col = o.lr;
+    const int row = o.lk() + 4 * r, col = o.lr();
     acc[r] = (double)T[row >= col ? swz(row, col) : swz(col, row)];
   }
   return acc;
@@ -276,13 +320,13 @@ __device__ __forceinline__ void diag16(v4d acc, real* T, real* Dk, int lane, int
   __builtin_amdgcn_s_setprio(3);        // the serial chain of the workgroup: win issue arbitration on its SIMD
   v4d fac;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) fac[r] = o.lk + 4 * r == o.lr ? 1.0 : 0.0;
+  for (int r = 0; r < 4; ++r) fac[r] = o.lk() + 4 * r == o.lr() ? 1.0 : 0.0;
   double lcol[4], xrow[4];
   // sel[e] = 1 in the one lane (lr < 4, lk <= lr) that holds entry e of the lower 4x4 block, in the order
   // (0,0) (1,1) (1,0) (2,2) (2,1) (2,0) (3,3) (3,2) (3,1) (3,0)
   double sel[10];
   {
-    const int code = o.lr < 4 ? 4 * o.lr + o.lk : -1;
+    const int code = o.lr() < 4 ? 4 * o.lr() + o.lk() : -1;
     const int at[10] = {0, 5, 4, 10, 9, 8, 15, 14, 13, 12};
 #pragma unroll
     for (int e = 0; e < 10; ++e) sel[e] = code == at[e] ? 1.0 : 0.0;
@@ -324,7 +368,7 @@ __device__ __forceinline__ void diag16(v4d acc, real* T, real* Dk, int lane, int
                       fma(sel[5], m20, fma(sel[4], m21, fma(sel[3], r2, fma(sel[2], m10, fma(sel[1], r1, sel[0] * r0)))))))));
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
     const v4d pt = MFMA(ia, v, zero);                          // register 0 at lane (lr, lk): P[lr][lk] = L[lr][4s+lk]
-    const double pm = o.lr >= 4 * s + o.lk ? pt[0] : 0.0;      // rows above the diagonal (and finished rows) are zero
+    const double pm = o.lr() >= 4 * s + o.lk() ? pt[0] : 0.0;      // rows above the diagonal (and finished rows) are zero
     lcol[s] = pm;
     const v4d qt = MFMA(ia, fac[s], zero);                     // register 0: Q[lk][lr] = Linv[4s+lk][lr]
     xrow[s] = qt[0];
@@ -336,8 +380,8 @@ __device__ __forceinline__ void diag16(v4d acc, real* T, real* Dk, int lane, int
   // every lane holds 4 entries of the factor (operand layout) and 4 of the inverse (accumulator layout)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    T[swz(o.lr, 4 * s + o.lk)] = (real)lcol[s];
-    Dk[swz(4 * s + o.lk, o.lr)] = (real)xrow[s];
+    T[swz(o.lr(), 4 * s + o.lk())] = (real)lcol[s];
+    Dk[swz(4 * s + o.lk(), o.lr())] = (real)xrow[s];
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -458,7 +502,7 @@ __device__ __forceinline__ double mv_lower(const real* Lb, const vecr* x, int i,
   for (int k = 0; k <= i; ++k) {
     const real* t = Lb + lt(i, k) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma((double)t[o.rc[q]], (double)x[16 * k + o.kq[q]], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[o.rc[q]], (double)x[16 * k + o.kq(q)], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -471,7 +515,7 @@ __device__ __forceinline__ double mv_lower_t(const real* Lb, const vecr* x, int 
   for (int k = j; k < NT; ++k) {
     const real* t = Lb + lt(k, j) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma((double)t[o.cr[q]], (double)x[16 * k + o.kq[q]], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[o.cr[q]], (double)x[16 * k + o.kq(q)], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -484,7 +528,7 @@ __device__ __forceinline__ double mv_sym(const real* Sb, const vecr* x, int i, c
   for (int k = 0; k < NT; ++k) {
     const real* t = Sb + (k <= i ? lt(i, k) : lt(k, i)) * TS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s = fma((double)t[k <= i ? o.rc[q] : o.cr[q]], (double)x[16 * k + o.kq[q]], s);
+    for (int q = 0; q < 4; ++q) s = fma((double)t[k <= i ? o.rc[q] : o.cr[q]], (double)x[16 * k + o.kq(q)], s);
   }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -497,11 +541,11 @@ __device__ __forceinline__ double mv_sym(const real* Sb, const vecr* x, int i, c
 // (always an fp64 product; result register r is the pair (row kq[r], column lr) of the tile in either precision)
 __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_ls2, const double* ssq, int i, int j, const Lane& o) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  const int ra = 16 * i + dist_row(o.lr), rb = 16 * j + o.lr;
+  const int ra = 16 * i + dist_row(o.lr()), rb = 16 * j + o.lr();
   const real* xa = X + (long)(ra < N ? ra : 0) * R;
   const real* xb = X + (long)(rb < N ? rb : 0) * R;
   if (R <= 8) {                 // the common case: both operand pairs requested before the first MFMA
-    const int c0 = o.lk, c1 = 4 + o.lk;
+    const int c0 = o.lk(), c1 = 4 + o.lk();
     // (unconditional loads from clamped addresses, zeroed afterwards: a load under a condition is a branch whose value is
     //  awaited at the join - four serial round trips instead of one)
     const double la0 = (double)xa[c0 < R ? c0 : 0], lb0 = (double)xb[c0 < R ? c0 : 0];
@@ -513,16 +557,16 @@ __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_l
   } else {
 #pragma unroll 2
     for (int k0 = 0; k0 < R; k0 += 4) {
-      const int c = k0 + o.lk;
+      const int c = k0 + o.lk();
       const double la = (double)xa[c < R ? c : 0], lb = (double)xb[c < R ? c : 0];
       const double a = (ra < N && c < R) ? la : 0.0;
       const double b = (rb < N && c < R) ? lb : 0.0;
       acc = MFMA(a, b, acc);
     }
   }
-  const double sj = ssq[16 * j + o.lr];
+  const double sj = ssq[16 * j + o.lr()];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = ((-2.0 * acc[r] + ssq[16 * i + o.kq[r]]) + sj) * inv_ls2;
+  for (int r = 0; r < 4; ++r) acc[r] = ((-2.0 * acc[r] + ssq[16 * i + o.kq(r)]) + sj) * inv_ls2;
   return acc;
 }
 
@@ -597,7 +641,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
       int i = 0, j = 0;
       unpack_lower(p < NTT ? p : 0, i, j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lam[s][r] = (i == j && o.kq[r] == o.lr) ? 1 : 0;
+      for (int r = 0; r < 4; ++r) lam[s][r] = (i == j && o.kq(r) == o.lr()) ? 1 : 0;
       gt[s] = v4r{0, 0, 0, 0};
       if (p < NTT) st_tile(Cb + p * TS, o, lam[s]);        // S = I until the first natural-gradient step (n_iters = 0)
     }
@@ -633,7 +677,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         double k1m[4], k2m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+          const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
           double k1, k2;
           if (park) kern_unit<true>(g.kernel, r2[r], k1, k2);
           else kern_unit<false>(g.kernel, r2[r], k1, k2);
@@ -656,7 +700,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         if (with_m) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
+            const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
             kt[r] = (real)(g.gamma * (double)kt[r] + (row == col ? 1.0 / (double)dv[row] : 0.0));
           }
           st_tile(Cb + p * TS, o, kt);
@@ -676,7 +720,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower<NT>(Lb, mv, i, o);
-        if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s - (double)yv[16 * i + o.lr]);
+        if (o.lk() == 0) av[16 * i + o.lr()] = (vecr)(s - (double)yv[16 * i + o.lr()]);
         double fr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int j = 0; j <= i; ++j) {
@@ -691,7 +735,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
         for (int r = 0; r < 4; ++r) {
           double v = fr[r];
           v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-          if (o.lr == 0) wv[16 * i + o.kq[r]] = (vecr)v;                   // f_t
+          if (o.lr() == 0) wv[16 * i + o.kq(r)] = (vecr)v;                   // f_t
         }
       }
       SYNC();
@@ -741,7 +785,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
             const real* tb = Lb + lt(k, j) * TS;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const real sc = (real)rs[16 * k + o.kq[q]];
+              const real sc = (real)rs[16 * k + o.kq(q)];
               gt[s] = MFMAR(ta[o.cr[q]] * sc, tb[o.cr[q]] * sc, gt[s]);
             }
           }
@@ -760,16 +804,16 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           unpack_lower(p, i, j);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            lam[s][r] = (real)((1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0)));
+            lam[s][r] = (real)((1.0 - g.gamma) * lam[s][r] + g.gamma * (gt[s][r] + ((i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0)));
           if (!wb) st_tile(Cb + p * TS, o, lam[s]);
         }
       }
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_lower_t<NT>(Lb, yd, i, o);
-        if (o.lk == 0) {
-          th[16 * i + o.lr] = (vecr)((1.0 - g.gamma) * (double)th[16 * i + o.lr] + g.gamma * s);
-          wv[16 * i + o.lr] = (vecr)s;         // L^T (y / nu): u = L^T D (L m - y) = G m - L^T (y / nu) needs it, and L dies here
+        if (o.lk() == 0) {
+          th[16 * i + o.lr()] = (vecr)((1.0 - g.gamma) * (double)th[16 * i + o.lr()] + g.gamma * s);
+          wv[16 * i + o.lr()] = (vecr)s;         // L^T (y / nu): u = L^T D (L m - y) = G m - L^T (y / nu) needs it, and L dies here
         }
       }
       SYNC();
@@ -799,13 +843,13 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll 1
         for (int i = wave; i < NT; i += NW) {
           const double s = mv_lower<NT>(Lb, th, i, o);
-          if (o.lk == 0) uv[16 * i + o.lr] = (vecr)s;                      // z = C^-1 theta1 (uv is free until u is formed)
+          if (o.lk() == 0) uv[16 * i + o.lr()] = (vecr)s;                      // z = C^-1 theta1 (uv is free until u is formed)
         }
         SYNC();
 #pragma unroll 1
         for (int i = wave; i < NT; i += NW) {
           const double s = mv_lower_t<NT>(Lb, uv, i, o);
-          if (o.lk == 0) mv[16 * i + o.lr] = (vecr)s;
+          if (o.lk() == 0) mv[16 * i + o.lr()] = (vecr)s;
         }
         // (mv is read after the barriers of the tile moves below)
       }
@@ -834,7 +878,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll 1
         for (int i = wave; i < NT; i += NW) {
           const double s = mv_sym<NT>(Cb, yv, i, o);
-          if (o.lk == 0) uv[16 * i + o.lr] = (vecr)s;
+          if (o.lk() == 0) uv[16 * i + o.lr()] = (vecr)s;
         }
         SYNC();
       } else {
@@ -842,7 +886,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
 #pragma unroll 1
       for (int i = wave; i < NT; i += NW) {
         const double s = mv_sym<NT>(Lb, mv, i, o);
-        if (o.lk == 0) uv[16 * i + o.lr] = (vecr)(s - (double)wv[16 * i + o.lr]);
+        if (o.lk() == 0) uv[16 * i + o.lr()] = (vecr)(s - (double)wv[16 * i + o.lr()]);
       }
       SYNC();
       STAMP(6);
@@ -859,7 +903,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
             // this wave still holds its S tile in st[s] (same element layout) - no product
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              acc[r] = (real)((((i == j && o.kq[r] == o.lr) ? 1.0 : 0.0) - (double)st[s][r]) / g.gamma);
+              acc[r] = (real)((((i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0) - (double)st[s][r]) / g.gamma);
           } else {
             acc = acc_run(acc, 0, NT,
                           // (ONE load per operand with a selected address: a choice between two loads is a branch, and operand loads
@@ -869,9 +913,9 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int rl = o.kq[r];
-            double v = fma((double)uv[16 * i + rl], (double)mv[16 * j + o.lr], (double)acc[r]);
-            if (i == j) v = rl < o.lr ? 0.0 : (rl == o.lr ? 0.5 * v : v);
+            const int rl = o.kq(r);
+            double v = fma((double)uv[16 * i + rl], (double)mv[16 * j + o.lr()], (double)acc[r]);
+            if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
             acc[r] = (real)v;
           }
           st[s] = acc;
@@ -930,7 +974,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
             const double f = i == j ? 0.5 : 1.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              acc[r] = (real)(f * ((double)acc[r] - g.gamma * (double)uv[16 * i + o.kq[r]] * (double)uv[16 * j + o.lr]));
+              acc[r] = (real)(f * ((double)acc[r] - g.gamma * (double)uv[16 * i + o.kq(r)] * (double)uv[16 * j + o.lr()]));
           } else {
             acc = acc_run(acc, i, NT, [&](int k, int q) { return Wb[lt(k, i) * TS + o.cr[q]]; },
                           [&](int k, int q) { return Lb[lt(k, j) * TS + o.cr[q]]; });
@@ -1000,7 +1044,7 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     for (int i = wave; i < NT; i += NW) {
       const double s1 = mv_lower<NT>(Lb, mv, i, o);
       const double s2 = mv_lower_t<NT>(Wb, mv, i, o);
-      if (o.lk == 0) av[16 * i + o.lr] = (vecr)(s1 + s2);                   // av = mu (padded part 0)
+      if (o.lk() == 0) av[16 * i + o.lr()] = (vecr)(s1 + s2);                   // av = mu (padded part 0)
     }
     SYNC();                                                                 // (D tiles; av is read after the barriers below)
     STAMP(14);
@@ -1070,25 +1114,44 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
     WSTAMP(3);
     SYNC();                                          // every product has read S (Cb), L (Lb) and L^-1 (Wb)
     WSTAMP(4);
-    if (ch == 1) {
+    // tile (i, j) is completed by the half with h = (i + j) & 1 (the one that added its L^-T L^-1 term); the other half hands
+    // its partial sum over through Cb
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (on0 && cj0 + t < NT) st_tile(Cb + lt(cj0 + t, cj0) * TS, o, pc0[t]);
+    for (int t = 0; t < NT; ++t)
+      if (on0 && cj0 + t < NT && ((t & 1) != ch)) st_tile(Cb + lt(cj0 + t, cj0) * TS, o, pc0[t]);
 #pragma unroll
-      for (int t = 0; t < T1; ++t)
-        if (on1 && cj1 + t < NT) st_tile(Cb + lt(cj1 + t, cj1) * TS, o, pc1[t]);
-    }
+    for (int t = 0; t < T1; ++t)
+      if (on1 && cj1 + t < NT && ((t & 1) != ch)) st_tile(Cb + lt(cj1 + t, cj1) * TS, o, pc1[t]);
+    WSTAMP(6);
     SYNC();
-    // the h = 0 wave of a column completes its tiles, exports them and leaves the bordered matrix of chol(cov) in Lb: rows N
+    WSTAMP(7);
+    // completion: export, and the bordered matrix of chol(cov) into Lb: rows N
     // (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
     auto cov_finish = [&](v4r acc, int i, int j) {
+      // (branch-free up to the exports: every operand - the other half's partial, mu for the bordered row, nu for the diagonal -
+      //  is requested up front; LDS reads under per-element conditions cost a round trip each, 2.3 k cycles per tile)
       const v4r other = ld_tile(Cb + lt(i, j) * TS, o);
+      const int col = 16 * j + o.lr();
+      const double mu_c = (double)av[col];
+      double nur[4] = {0.0, 0.0, 0.0, 0.0};
+      if (i == j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * i + o.kq(r);
+          nur[r] = (double)g.nu[(long)b * N + (row < N ? row : 0)];          // cov += diag(y_var)   (models.py:220)
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * i + o.kq[r], col = 16 * j + o.lr;
-        acc[r] = acc[r] + other[r];
-        if (row == col) acc[r] = (real)(acc[r] + (1.0 / (double)dv[row] + J));
-        if (row < N && col < N) {
+        const int row = 16 * i + o.kq(r);
+        double v = (double)acc[r] + (double)other[r];
+        if (row == col) v += nur[r] + J;
+        const bool inside = row < N && col < N;
+        double bv = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
+        bv = (col < N && row == N) ? 1.0 : bv;
+        bv = (col < N && row == N + 1) ? mu_c : bv;
+        acc[r] = (real)(inside ? v : bv);
+        if (inside) {
           // (a diagonal tile is a full 16x16 accumulation: only its lower half is exported here, the upper half is
           //  mirrored from it below, so that cov is exactly symmetric like the general path's extraction)
           if (g.cov && (i != j || col <= row)) {
@@ -1096,23 +1159,16 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
             if (i != j) g.cov[((long)b * N + col) * N + row] = acc[r];
           }
           if (g.var && row == col) g.var[(long)b * N + row] = acc[r];
-        } else {
-          double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
-          if (col < N && row == N) v = 1.0;
-          if (col < N && row == N + 1) v = (double)av[col];
-          acc[r] = (real)v;
         }
       }
       st_tile(Lb + lt(i, j) * TS, o, acc);
     };
-    if (ch == 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (on0 && cj0 + t < NT) cov_finish(pc0[t], cj0 + t, cj0);
+    for (int t = 0; t < NT; ++t)
+      if (on0 && cj0 + t < NT && ((t & 1) == ch)) cov_finish(pc0[t], cj0 + t, cj0);
 #pragma unroll
-      for (int t = 0; t < T1; ++t)
-        if (on1 && cj1 + t < NT) cov_finish(pc1[t], cj1 + t, cj1);
-    }
+    for (int t = 0; t < T1; ++t)
+      if (on1 && cj1 + t < NT && ((t & 1) == ch)) cov_finish(pc1[t], cj1 + t, cj1);
     WSTAMP(5);
     if (g.mu)
       for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = (real)av[t];
