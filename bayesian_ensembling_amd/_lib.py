@@ -151,9 +151,11 @@ class DeviceBuffer:
         self.nbytes = int(nbytes)
         self.shape = shape
         self.dtype = np.dtype(dtype)
-        p = _vp()
-        ctx._check(ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p)))
-        self.ptr = p.value
+        self.ptr = ctx._take_cached(self.nbytes)        # a block of exactly this size freed earlier, if there is one
+        if self.ptr is None:
+            p = _vp()
+            ctx._check(ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p)))
+            self.ptr = p.value
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr, dtype=self.dtype)
@@ -187,7 +189,8 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            self.ctx.lib.bayens_free(self.ctx.h, self.ptr)
+            if not self.ctx._give_cached(self.nbytes, self.ptr):
+                self.ctx.lib.bayens_free(self.ctx.h, self.ptr)
             self.ptr = None
 
 
@@ -211,9 +214,49 @@ class Context:
                                   "there is no CPU fallback)")
         self.h = h
         self.device = device
+        # Freed blocks are kept for re-use by size (every operation of a context is ordered on its one stream, so a block
+        # may be handed out again the moment its owner lets go of it).  hipMalloc / hipFree cost a millisecond or more each and
+        # hipFree waits for the device: through the plug-in classes a weighting step allocated and freed half a dozen tables
+        # around 0.2 ms of kernels.  Bounded: at most CACHE_BYTES in all, nothing above CACHE_MAX_BLOCK.
+        self._cache = {}
+        self._cache_bytes = 0
+
+    CACHE_BYTES = 3 << 30
+    CACHE_MAX_BLOCK = 1 << 30
+
+    def _take_cached(self, nbytes):
+        blocks = self._cache.get(nbytes)
+        if blocks:
+            self._cache_bytes -= nbytes
+            return blocks.pop()
+        return None
+
+    def _give_cached(self, nbytes, ptr):
+        if getattr(self, "h", None) is None or nbytes > self.CACHE_MAX_BLOCK:
+            return False
+        while self._cache_bytes + nbytes > self.CACHE_BYTES and self._cache:       # make room: largest size class first
+            size = max(self._cache)
+            blocks = self._cache[size]
+            self.lib.bayens_free(self.h, blocks.pop())
+            self._cache_bytes -= size
+            if not blocks:
+                del self._cache[size]
+        if self._cache_bytes + nbytes > self.CACHE_BYTES:
+            return False
+        self._cache.setdefault(nbytes, []).append(ptr)
+        self._cache_bytes += nbytes
+        return True
+
+    def trim_cache(self):
+        """Returns every cached block to the device."""
+        for size, blocks in self._cache.items():
+            for ptr in blocks:
+                self.lib.bayens_free(self.h, ptr)
+        self._cache, self._cache_bytes = {}, 0
 
     def close(self):
         if getattr(self, "h", None):
+            self.trim_cache()
             self.lib.bayens_ctx_destroy(self.h)
             self.h = None
 

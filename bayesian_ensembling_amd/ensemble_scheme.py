@@ -43,11 +43,32 @@ class Barycentre(AbstractEnsembleScheme):
             if not process_model.distribution:
                 raise AttributeError(f"No posterior for model {t_idx}. Please run model.fit() first.")
         n_points = int(process_models[0].model_data.size / process_models[0].model_data.shape[0])
+        ds = [pm.distribution._dist for pm in process_models.models]
+        field = field_of(ds)
+        res = getattr(weights, "resident", None)
+        if field is not None and res is not None and res[1] is field and res[2] == "member-gridpoint-time" \
+                and tuple(weights.shape) == (M,) + tuple(process_models[0].model_data.shape[1:]):
+            # the weight table is still where LogLikelihoodWeight left it, in the field's own [member][grid point][time]
+            # layout: no download, no upload, no change of layout (ensemble_scheme.py:52 reshapes the same table on the host)
+            ctx, G, N = field.ctx, field.G, field.N
+            dmu, dv, dout = ctx.empty((G * N,)), ctx.empty((G * N,)), ctx.empty((2, N * G))
+            try:
+                bad = ctx.barycentre_dev(M, G * N, res[0].buf, field.mu, field.var, dmu, dv)
+                ctx.transpose_rows_dev(1, G, N, dmu, dout)
+                ctx.transpose_rows_dev(1, G, N, dv, dout.offset(N * G * 8))
+                both = dout.download()
+                mu, v = both[0], both[1]
+            finally:
+                for d in (dmu, dv, dout):
+                    d.free()
+            if bad:
+                import warnings
+                warnings.warn(f"Barycentre not converged for {bad} time step(s)")
+            return Distribution(mu=mu, covariance=v, dim_array=_blank(process_models.models[-1]),
+                                dist_type=dx.MultivariateNormalDiag)
         w = np.asarray(getattr(weights, "values", weights), dtype=np.float64).reshape(M, -1)
         if w.shape[1] != n_points:
             raise ValueError(f"weights have {w.shape[1]} points per model, the posteriors {n_points}")
-        ds = [pm.distribution._dist for pm in process_models.models]
-        field = field_of(ds)
         if field is not None:
             # per-gridpoint posteriors: the marginals of all M x G fits are resident as [M][G*N]; the weights arrive in
             # the data's (time, *space) order and are turned into that layout, the result back (ensemble_scheme.py:51-52

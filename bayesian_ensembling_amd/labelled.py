@@ -256,6 +256,62 @@ class DataArray:
     __hash__ = None
 
 
+class ResidentDataArray(DataArray):
+    """A DataArray whose values live in HBM until somebody reads them (round 4: the [model, time, *space] weight table of a
+    per-gridpoint field is 38 MB at BASELINE config 5; the reference hands xr.DataArray objects from a weight to a scheme -
+    weights.py:118-123 -> ensemble_scheme.py:52 - and here the scheme reads the device table where it lies).  `values` /
+    `data` / np.asarray() download on first use and keep the host copy; shape, dims and coords never touch the device.
+    `resident` = (owner, device table in the DEVICE's layout, layout tag): what a consumer that knows the layout uses."""
+
+    def __init__(self, fetch, shape, dims, coords, name, resident):
+        self._fetch, self._shape, self._host = fetch, tuple(int(x) for x in shape), None
+        self.resident = resident
+        self.dims = tuple(dims)
+        assert len(self.dims) == len(self._shape), "dims do not match data rank"
+        self.coords, self.scalar_coords = {}, {}
+        for k, v in (coords or {}).items():
+            v = np.asarray(v)
+            if v.ndim == 0 or k not in self.dims:
+                self.scalar_coords[k] = v
+            else:
+                assert v.shape[0] == self._shape[self.dims.index(k)], f"coord {k} has the wrong length"
+                self.coords[k] = v
+        self.name = name
+
+    @property
+    def values(self):
+        if self._host is None:
+            self._host = np.asarray(self._fetch()).reshape(self._shape)
+        return self._host
+
+    @values.setter
+    def values(self, v):
+        self._host = np.asarray(v)
+        self.resident = None                       # somebody replaced the data: the device table no longer describes it
+
+    @property
+    def shape(self):
+        return self._shape if self._host is None else self._host.shape
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        where = "resident in HBM" if self._host is None else "host copy fetched"
+        return f"<DataArray {self.name or ''} dims={self.dims} shape={self.shape} ({where})>"
+
+    def __deepcopy__(self, memo):
+        return DataArray(np.array(self.values, copy=True), self.dims, dict(self.coords), self.name)
+
+
 def concat(arrays, dim):
     """xr.concat along a NEW dimension whose coordinate comes from the scalar coord `dim` of each item
     (weights.py:110-118 assigns `model=<name>` to every member's row and concatenates over 'model')."""

@@ -97,8 +97,14 @@ class GPDTW1D:
             # realisations cross PCIe on a second stream (its own context, driven by a helper thread - ctypes releases
             # the GIL inside the blocking calls), so the upload (304 MB at config 5) hides behind the fits.
             row = R * N * G * 8
+            # (stage sizes grow 1, 2, 4, ... up to M / FIELD_STAGES members: only the FIRST stage's upload is exposed, so it is
+            #  the smallest; every later one hides behind the fits of the stage before it)
             per_stage = max(1, -(-M // self.FIELD_STAGES))
-            stages = [(m0, min(M, m0 + per_stage)) for m0 in range(0, M, per_stage)]
+            stages, m0, size = [], 0, 1
+            while m0 < M:
+                m1 = min(M, m0 + min(size, per_stage))
+                stages.append((m0, m1))
+                m0, size = m1, size * 2
             up = _lib.upload_context(ctx)
             failure = []
 
@@ -143,8 +149,9 @@ class GPDTW1D:
             for d in (dX, dy, dnu, draw):
                 d.free()
         dists = []
+        blank = _blank_array(process_models[0])         # (every member has the same shape and coordinates: one template)
         for m, pm in enumerate(process_models):
-            d = Distribution(dim_array=_blank_array(pm), dist_type=dx.GridMultivariateNormalFullCovariance,
+            d = Distribution(dim_array=blank, dist_type=dx.GridMultivariateNormalFullCovariance,
                              _resident=(field, m))
             d.losses = None
             dists.append(d)

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from . import distributions as dx
 from .data import ModelCollection, ProcessModel
-from .labelled import DataArray, concat
+from .labelled import DataArray, ResidentDataArray, concat
 from .resident import field_of, resident_tables
 
 __all__ = ["AbstractWeight", "LogLikelihoodWeight", "ModelSimilarityWeight", "InverseSquareWeight", "UniformWeight",
@@ -37,6 +37,19 @@ class AbstractWeight:
         for process_model in process_models.models:
             assert hasattr(process_model.distribution, "_dist"), "Distribution not defined - fit models first"
         return self._compute(process_models=process_models, observations=observations, **kwargs)
+
+
+class _ResidentTable:
+    """Owner of a device table behind a ResidentDataArray: the block goes back to the context when the array is dropped."""
+
+    def __init__(self, ctx, buf):
+        self.ctx, self.buf = ctx, buf
+
+    def __del__(self):
+        try:
+            self.buf.free()
+        except Exception:
+            pass
 
 
 def _row_template(model):
@@ -107,35 +120,64 @@ class LogLikelihoodWeight(AbstractWeight):
         """Per-gridpoint posteriors (GPDTW1D(per_gridpoint=True), BASELINE config 5): weights.py:88-123 at EVERY grid
         point - rows log N(x_{r,t,g} 1; mu_{m,g}, cov_{m,g}) from the resident basis of fit (m, g), mean over the
         observation realisations, exp(c .), normalisation over the models - in three launches over the whole field
-        (bayens_loglik_rows_basis_grouped -> bayens_weights_normalise).  Only the observations go up and the
-        [M, time, *space] weight table comes down."""
-        if not (scheme is None or scheme == "exp" or scheme is np.exp):
-            raise NotImplementedError("per-gridpoint fields: only the default exp standardisation runs on the device")
+        (bayens_loglik_rows_basis_grouped -> bayens_weights_normalise).  Only the observations go up; the
+        [model, time, *space] weight table STAYS in HBM (round 4: labelled.ResidentDataArray - `Barycentre` reads it where it
+        lies; `.values`, arithmetic or a reduction download it once).  A standardisation scheme other than exp is a host
+        callable (weights.py:66-73,107 takes any): the mean log-likelihood table comes down and the callable is applied to
+        it as the 1-D path does."""
         ctx = field.ctx
         M, G, N = field.M, field.G, field.N
         R_obs = observations.n_realisations
+        on_device = scheme is None or scheme == "exp" or scheme is np.exp
         # observations go up as they lie in memory [R_obs][N][G] and are re-laid on the device to [G][R_obs][N] (one
         # observation set per grid point): [R_obs * N][G] -> [G][R_obs * N] is that, since rows of one point stay together
         dobs_raw = ctx.to_device(np.asarray(observations.model_data.values, dtype=np.float64).reshape(R_obs * N, G))
         dobs, dll, dw = ctx.empty((G, R_obs, N)), ctx.empty((M * G, N)), ctx.empty((M, G * N))
-        draw = ctx.empty((M, G * N)) if return_lls else None
-        dout = ctx.empty((M, N * G))
+        draw = ctx.empty((M, G * N)) if return_lls and on_device else None
+        keep = []
         try:
             ctx.transpose_rows_dev(1, R_obs * N, G, dobs_raw, dobs)
             ctx.loglik_rows_basis_grouped(field.basis, field.logdet, dobs, loc=_lib.DEVICE, out=dll)
+            if not on_device:
+                dout = ctx.empty((M, N * G))
+                try:
+                    ctx.transpose_rows_dev(M, G, N, dll, dout)              # device order [M][G][N] -> (model, time, *space)
+                    ll_mean = dout.download()
+                finally:
+                    dout.free()
+                raw = np.asarray(scheme(c_std * ll_mean), dtype=np.float64)
+                with np.errstate(all="ignore"):
+                    w = raw / raw.sum(axis=0, keepdims=True)
+                return self._finish(process_models, observations, models, w, raw, return_lls)
             ctx.weights_normalise_dev(M, G * N, dll, c_std, dw, draw)
-            # device order [M][G][N] -> the data's (model, time, *space)
-            ctx.transpose_rows_dev(M, G, N, dw, dout)
-            w = dout.download()
-            raw = None
-            if return_lls:
-                ctx.transpose_rows_dev(M, G, N, draw, dout)
-                raw = dout.download()
+            keep = [dw] + ([draw] if draw is not None else [])
         finally:
-            for d in (dobs_raw, dobs, dll, dw, draw, dout):
-                if d is not None:
+            for d in (dobs_raw, dobs, dll, dw, draw):
+                if d is not None and not any(d is k for k in keep):
                     d.free()
-        return self._finish(process_models, observations, models, w, raw, return_lls)
+        template = models[0].model_data
+        dims = ("model",) + tuple(template.dims[1:])
+        coords = {k: v for k, v in template.coords.items() if k in dims}
+        coords["model"] = np.asarray([m.model_name for m in models])
+        shape = (M,) + tuple(template.shape[1:])
+
+        def lazy(table, name):
+            owner = _ResidentTable(ctx, table)
+
+            def fetch():
+                dout = ctx.empty((M, N * G))
+                try:
+                    ctx.transpose_rows_dev(M, G, N, owner.buf, dout)        # device order [M][G][N] -> the data's (time, *space)
+                    return dout.download()
+                finally:
+                    dout.free()
+            return ResidentDataArray(fetch, shape, dims, coords, name, resident=(owner, field, "member-gridpoint-time"))
+
+        weights = lazy(dw, "Log-likelihood weights")
+        assert weights.shape == (len(process_models),) + tuple(observations.model_data.shape[1:])
+        if return_lls:
+            return weights, lazy(draw, "Log-likelihoods")
+        return weights
 
     @staticmethod
     def _finish(process_models, observations, models, w, raw, return_lls):

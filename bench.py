@@ -411,13 +411,18 @@ def api_path_c5(ctx, M, n_lat, n_lon, N, R, T, reps=3):
             t3 = time.perf_counter()
         if best is None or t3 - t0 < best:
             best, parts = t3 - t0, (t1 - t0, t2 - t1, t3 - t2)
-    assert np.isfinite(post.mu).all() and w.shape == (M, N, n_lat, n_lon)
+    t4 = time.perf_counter()
+    wv = np.asarray(w.values)                 # the [M, time, lat, lon] table stays in HBM until somebody reads it: timed apart
+    w_dl = time.perf_counter() - t4
+    assert np.isfinite(post.mu).all() and w.shape == (M, N, n_lat, n_lon) and np.isfinite(wv).all()
     return {"api_path_c5_fits_per_s": round(M * G / best, 1), "api_path_c5_ms_per_step": round(best * 1e3, 2),
             "api_path_c5_ms_fit_weights_barycentre": [round(p * 1e3, 2) for p in parts],
+            "api_path_c5_weight_table_download_ms": round(w_dl * 1e3, 2),
             "api_path_c5_note": f"{M} members x {n_lat}x{n_lon} grid points, N={N}, R={R}: ModelCollection.fit(GPDTW1D("
                                 "per_gridpoint=True)) + LogLikelihoodWeight + Barycentre through the Python classes, host "
-                                f"realisations in ({M * R * N * G * 8 / 1e6:.0f} MB over PCIe), weight table and barycentre "
-                                "field out; best of %d" % reps}
+                                f"realisations in ({M * R * N * G * 8 / 1e6:.0f} MB over PCIe), barycentre field out; the "
+                                f"{M * N * G * 8 / 1e6:.0f} MB weight table stays resident for the scheme and is downloaded when a "
+                                "caller reads it (timed apart); best of %d" % reps}
 
 
 def mid_size_line(ctx, M=20, N=165, R=9, T=2500):

@@ -68,6 +68,35 @@ def test_config5_through_the_plugin_classes(ctx):
     assert np.allclose(clone.variance.values, mc.models[1].distribution.variance.values, rtol=1e-14)
 
 
+def test_field_weight_table_stays_resident_and_host_schemes_work(ctx):
+    """LogLikelihoodWeight on a per-gridpoint field returns a table that is still in HBM (labelled.ResidentDataArray);
+    Barycentre reads it there - same numbers, bit for bit, as through a host copy of the table - and a standardisation scheme
+    that is an arbitrary host callable (weights.py:66-73,107 accepts any) gives what the reference's arithmetic gives."""
+    from bayesian_ensembling_amd.labelled import ResidentDataArray
+    M, R, T, n_lat, n_lon = 3, 4, 20, 4, 5
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=9)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=2, progress_bar=False)
+    w, raw = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2, return_lls=True)
+    assert isinstance(w, ResidentDataArray) and w._host is None and w.shape == (M, T, n_lat, n_lon)       # nothing fetched yet
+    assert w.dims == ("model", "time", "latitude", "longitude") and list(w.coords["model"]) == [m.model_name for m in mc.models]
+    post_resident = es.Barycentre()(mc, w)
+    assert w._host is None                                                                                # ... nor by the scheme
+    host = DataArray(np.array(w.values), w.dims, dict(w.coords), w.name)
+    post_host = es.Barycentre()(mc, host)
+    assert np.array_equal(post_resident.mu, post_host.mu) and np.array_equal(post_resident.covariance, post_host.covariance)
+    assert np.allclose(np.asarray(raw.values) / np.asarray(raw.values).sum(axis=0, keepdims=True), w.values, rtol=1e-13)
+    # an arbitrary host callable: the same table through exp written as a lambda, and a genuinely different scheme
+    w_lambda = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2, standardisation_scheme=lambda x: np.exp(x))
+    assert relerr(w_lambda.values, w.values) < 1e-13
+    soft = lambda x: 1.0 / (1.0 + np.exp(-x))                                      # noqa: E731
+    w_soft, raw_soft = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2, standardisation_scheme=soft, return_lls=True)
+    ll = np.log(np.asarray(raw.values)) / 1e-2                                      # the mean log-likelihood the device computed
+    ref = soft(1e-2 * ll)
+    assert relerr(raw_soft.values, ref) < 1e-10 and relerr(w_soft.values, ref / ref.sum(axis=0, keepdims=True)) < 1e-10
+    # arithmetic / reductions on the resident table behave like any DataArray (PerfectModelTest takes weights.mean('time'))
+    assert np.allclose(w.mean("time").values, np.asarray(w.values).mean(axis=1))
+
+
 def test_field_fit_in_several_launches_equals_one(ctx):
     """FIELD_CHUNK splits a field over several launches of the fused kernel: same posteriors, bit for bit."""
     mc, _ = _field_collection(3, 3, 20, 5, 7, seed=3)
