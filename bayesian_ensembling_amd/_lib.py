@@ -377,7 +377,7 @@ class Context:
         return info
 
     def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
-        """Small members (N <= 94), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance)."""
+        """Members with N <= 254 (fused kernels), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance)."""
         X = _f64(X)
         B, N, R = X.shape
         y_mean, y_var = _f64(y_mean).reshape(B, N), _f64(y_var).reshape(B, N)

@@ -592,8 +592,9 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, con
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !var || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: unknown kernel id");
-    if (!smalln::small_fit_supported(N, R))
-      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: N must be at most 94 (larger members: bayens_gp_fit_batch + bayens_extract_diag)");
+    const bool medium = !smalln::small_fit_supported(N, R) && mediumn::medium_fit_supported(N, R);
+    if (!smalln::small_fit_supported(N, R) && !medium)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: N must be at most 254 (larger members: bayens_gp_fit_batch + bayens_extract_diag)");
     Stage st(c, loc);
     const double* dX = st.in(X, (size_t)B * N * R);
     const double* dy = st.in(y_mean, (size_t)B * N);
@@ -604,10 +605,19 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, con
     double* dhyp = st.out(hyp, (size_t)B * 2);
     double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
     int* dinfo = st.scratch<int>((size_t)B);
-    smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo};
-    a.stamps = c->small_stamps;
-    a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
-    smalln::small_fit(c->stream, a, c->n_cus);
+    if (medium) {
+      // 94 < N <= 254 (the reference's historical annual horizon, N = 165: experiments/full_experiment_script.py:57): the fused
+      // mid-size kernel with the same reduced export - no covariance, no factor leaves the kernel
+      mediumn::MediumArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo,
+                            c->medium_scratch((size_t)mediumn::medium_grid(B, N, c->n_cus) * mediumn::medium_scratch_doubles(N))};
+      a.stamps = c->small_stamps;
+      mediumn::medium_fit(c->stream, a, c->n_cus);
+    } else {
+      smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo};
+      a.stamps = c->small_stamps;
+      a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
+      smalln::small_fit(c->stream, a, c->n_cus);
+    }
     std::vector<int> hinfo(B, 0);
     BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st.finish();

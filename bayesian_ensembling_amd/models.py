@@ -69,7 +69,8 @@ class GPDTW1D:
     def fit_field(self, process_models, n_optim_nits: int = 500):
         """Every (member, grid point) of a collection of (realisation, time, *space) models as an independent GP over
         time - models.py:175-220 applied to `model_data[:, :, lat, lon]` - in batched launches of the fused small-member
-        kernel (reduced export), resident in HBM as ONE ResidentField [M][G].  Members must share (R, T, space)."""
+        kernel (N <= 94; 94 < N <= 254, the reference's historical horizon N = 165, through the fused mid-size kernel) with
+        the reduced export, resident in HBM as ONE ResidentField [M][G].  Members must share (R, T, space)."""
         ctx = _lib.default_context()
         shapes = {tuple(pm.model_data.shape) for pm in process_models}
         if len(shapes) != 1:
@@ -81,9 +82,9 @@ class GPDTW1D:
         R, N = next(iter(shapes))[:2]
         G = int(np.prod(next(iter(shapes))[2:]))
         M = len(process_models)
-        if N > 94:
-            raise NotImplementedError(f"per_gridpoint: {N} time steps; the fused small-member kernel holds N <= 94 (the "
-                                      "reference's annual horizons are 86 steps)")
+        if N > 254:
+            raise NotImplementedError(f"per_gridpoint: {N} time steps; the fused one-kernel-per-fit paths hold N <= 254 (the "
+                                      "reference's annual horizons are 86 and 165 steps)")
         field = ResidentField(ctx, M, G, N)
         kid = _lib.KERNEL_IDS[self.kernel]
         B = M * G

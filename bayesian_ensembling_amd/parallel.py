@@ -394,28 +394,63 @@ def weighted_posterior_sharded(n_members, local_ll, local_mean, local_var, excha
     return w, mu, v
 
 
-def w2_single_sharded(ctx, n_members, mu_local, chol_local):
-    """ModelSimilarityWeight(mode='single') over member-sharded posteriors.
+def gather_member_blocks(ctx, n_members, rank, world, local, row_shape):
+    """All-gather of per-rank blocks of leading-axis rows that need NOT have the same length: rank r contributes the rows
+    shard_bounds(n_members, r, world) of a [n_members, *row_shape] table.  The collective itself is fixed-size
+    (bayens_allgather_rows = one ncclAllGather): every rank sends ceil(n_members / world) rows - its own, then padding - and
+    the gathered image [world][rows][...] is compacted on the device, block by block, into the [n_members][...] table
+    (device-to-device copies; with even shards the image IS the table and nothing is copied).  Returns the device table;
+    the caller frees it."""
+    row_shape = tuple(int(x) for x in row_shape)
+    width = int(np.prod(row_shape, dtype=np.int64)) if row_shape else 1
+    rows = -(-n_members // world)
+    lo, hi = shard_bounds(n_members, rank, world)
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape((hi - lo,) + row_shape)
+    d_loc = ctx.empty((rows,) + row_shape)
+    d_img = ctx.empty((world * rows,) + row_shape)
+    try:
+        d_loc.upload(local)                                  # (rows beyond this rank's share stay unwritten: never copied below)
+        ctx.allgather_rows(d_loc, d_img, rows, width)
+        if n_members == world * rows:
+            out, d_img = d_img, None
+            return out
+        out = ctx.empty((n_members,) + row_shape)
+        for r in range(world):
+            lo_r, hi_r = shard_bounds(n_members, r, world)
+            if hi_r > lo_r:
+                out.copy_rows_from(lo_r, d_img, r * rows, hi_r - lo_r)
+        return out
+    finally:
+        d_loc.free()
+        if d_img is not None:
+            d_img.free()
 
-    mu_local [M_loc, N] / chol_local [M_loc, N, N]: this rank's members - the SAME M_loc on every rank (contiguous
-    blocks in rank order), i.e. n_members == nranks * M_loc; pad the ensemble or use the single-GPU entry otherwise.
-    The factors are all-gathered over RCCL (M_loc * N^2 doubles per rank), every rank runs the polar iterations of its
-    share of the pairs and an all-reduce completes the distance table.  Returns (w [M], D [M, M])."""
+
+def w2_single_sharded(ctx, n_members, mu_local, chol_local):
+    """ModelSimilarityWeight(mode='single') over member-sharded posteriors (weights.py:240-265 has no restriction
+    on the member count).
+
+    mu_local [M_loc, N] / chol_local [M_loc, N, N]: this rank's members - the block shard_bounds(n_members, rank, world) of the
+    ensemble, so the shards may be uneven (the first n_members % world ranks hold one member more), exactly as the member
+    exchange of the weighted posterior deals them.  The factors are all-gathered over RCCL (ceil(M / world) * N^2 doubles per
+    rank, padded blocks compacted on the device), every rank runs the polar iterations of its share of the pairs and an
+    all-reduce completes the distance table.  Returns (w [M], D [M, M])."""
     M_loc, N = mu_local.shape
-    _, world = ctx.comm_info()[:2]
+    rank, world = ctx.comm_info()[:2]
     if world <= 0:
         raise ValueError("w2_single_sharded: the context has no communicator (RcclExchange / comm_init first)")
-    if n_members != world * M_loc:
-        raise ValueError(f"w2_single_sharded: n_members={n_members} must equal nranks*M_loc={world}*{M_loc} "
-                         "(the fixed-size all-gather of the factors cannot carry uneven shards)")
-    d_mu_loc, d_ch_loc = ctx.to_device(mu_local), ctx.to_device(chol_local)
-    d_mu, d_ch = ctx.empty((n_members, N)), ctx.empty((n_members, N, N))
-    d_w, d_D = ctx.empty((n_members,)), ctx.empty((n_members, n_members))
+    lo, hi = shard_bounds(n_members, rank, world)
+    if M_loc != hi - lo:
+        raise ValueError(f"w2_single_sharded: rank {rank} of {world} holds {M_loc} members, its block of n_members={n_members} "
+                         f"has {hi - lo} (members are dealt in contiguous blocks, parallel.shard_bounds)")
+    d_mu = d_ch = d_w = d_D = None
     try:
-        ctx.allgather_rows(d_mu_loc, d_mu, M_loc, N)
-        ctx.allgather_rows(d_ch_loc, d_ch, M_loc, N * N)
+        d_mu = gather_member_blocks(ctx, n_members, rank, world, mu_local, (N,))
+        d_ch = gather_member_blocks(ctx, n_members, rank, world, chol_local, (N, N))
+        d_w, d_D = ctx.empty((n_members,)), ctx.empty((n_members, n_members))
         ctx.w2_single_sharded_dev(n_members, N, d_mu, d_ch, d_w, d_D)
         return d_w.download(), d_D.download()
     finally:
-        for d in (d_mu_loc, d_ch_loc, d_mu, d_ch, d_w, d_D):
-            d.free()
+        for d in (d_mu, d_ch, d_w, d_D):
+            if d is not None:
+                d.free()

@@ -122,7 +122,9 @@ int bayens_field_prologue(bayens_ctx* ctx, int loc, int M, int R, int N, int G, 
  * member with every matrix resident in LDS (csrc/small.hip; BAYENS_NO_SMALL=1 forces the general path).  This entry is
  * the same fit with the REDUCED export the weighting path needs and nothing else: mu [B][N], var [B][N] = diag(cov)
  * (_dist.variance(), ensemble_scheme.py:64-65), logdet [B], hyp [B][2], ll_basis [B][2][N] (weights.py:98-100) - 2.8 KB
- * per member instead of the 59.9 KB of a full covariance.  N <= 94 only. */
+ * per member instead of the 59.9 KB of a full covariance.  Members with 94 < N <= 254 (the
+ * reference's historical annual horizon N = 165, full_experiment_script.py:57) take the fused mid-size kernel (csrc/medium.hip)
+ * with the same export; N > 254: BAYENS_E_ARG (bayens_gp_fit_batch + bayens_extract_diag serve those). */
 int bayens_gp_fit_batch_reduced(bayens_ctx* ctx, int loc, int B, int N, int R,
                                 const double* X, const double* y_mean, const double* y_var,
                                 int kernel, int n_iters, double gamma, double lr, double jitter,

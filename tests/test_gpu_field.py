@@ -97,6 +97,36 @@ def test_field_weight_table_stays_resident_and_host_schemes_work(ctx):
     assert np.allclose(w.mean("time").values, np.asarray(w.values).mean(axis=1))
 
 
+def test_field_at_the_references_historical_horizon(ctx):
+    """N = 165 time steps per grid point (the reference's historical annual horizon, experiments/full_experiment_script.py:57 -
+    the fused small-member kernel stops at 94): GPDTW1D(per_gridpoint=True) takes the fused mid-size kernel with the reduced
+    export; posterior marginals, per-gridpoint weights and barycentre against the oracle at every sampled grid point."""
+    M, R, T, n_lat, n_lon, nits = 3, 5, 165, 2, 3, 2
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=165)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=nits, progress_bar=False)
+    w = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-3)
+    post = es.Barycentre()(mc, w)
+    wv = np.asarray(w.values)
+    bm, bv = np.asarray(post.mu).reshape(T, n_lat, n_lon), np.asarray(post.covariance).reshape(T, n_lat, n_lon)
+    ov = np.asarray(obs.model_data.values)
+    assert np.isfinite(wv).all() and np.allclose(wv.sum(axis=0), 1.0, rtol=1e-12)
+    with threadpool_limits(2):
+        for (i, j) in [(0, 0), (1, 2)]:
+            mus, vs, lls = [], [], []
+            for m in range(M):
+                X, y, nu = go.prologue(np.asarray(mc[m].model_data.values)[:, :, i, j])
+                mo, co, _ = go.gp_fit(X, y, nu, nits)
+                Lc, ld = go.mvn_factor(co)
+                lls.append(go.loglik_mean_rows(go.mvn_constvec_loglik(mo, Lc, ld, ov[:, :, i, j])))
+                mus.append(mo); vs.append(np.diag(co))
+                assert relerr(mc[m].distribution.mean.values[:, i, j], mo) < 1e-10
+                assert relerr(mc[m].distribution.variance.values[:, i, j], vs[-1]) < 1e-10
+            w_ref, _ = go.loglik_weights(np.stack(lls), 1e-3)
+            assert relerr(wv[:, :, i, j], w_ref) < 1e-9
+            rm, rv, _ = go.barycentre(w_ref, np.stack(mus), np.stack(vs))
+            assert relerr(bm[:, i, j], rm) < 1e-9 and relerr(bv[:, i, j], rv) < 1e-9
+
+
 def test_field_fit_in_several_launches_equals_one(ctx):
     """FIELD_CHUNK splits a field over several launches of the fused kernel: same posteriors, bit for bit."""
     mc, _ = _field_collection(3, 3, 20, 5, 7, seed=3)

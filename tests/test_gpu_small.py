@@ -98,10 +98,36 @@ def test_failed_pivot_is_reported_per_member(ctx):
 
 
 def test_reduced_export_rejects_large_members(ctx):
-    X = np.zeros((1, 95, 2))
+    X = np.zeros((1, 255, 2))
     with pytest.raises(L.BayensError) as e:
-        ctx.gp_fit_batch_reduced(X, np.zeros((1, 95)), np.ones((1, 95)), 1)
+        ctx.gp_fit_batch_reduced(X, np.zeros((1, 255)), np.ones((1, 255)), 1)
     assert e.value.code == -1
+
+
+def test_reduced_export_of_mid_size_members_through_the_fused_mid_size_kernel(ctx):
+    """94 < N <= 254 (the reference's historical annual horizon N = 165, experiments/full_experiment_script.py:57): the
+    reduced export comes from csrc/medium.hip - bit-identical to the full export's mu / diag(cov) / logdet / hypers / basis
+    of the same fit, and on the oracle."""
+    import scipy.linalg as sla
+    for (M, N, R, T) in [(3, 165, 9, 2), (2, 95, 4, 1), (2, 254, 5, 2)]:
+        data, _ = go.synthetic_ensemble(M, N, R=R, seed=N)
+        X, y, nu = member_inputs(data)
+        red = ctx.gp_fit_batch_reduced(X, y, nu, T)
+        ctx.set_medium_min_batch(1)
+        try:
+            full = ctx.gp_fit_batch(X, y, nu, T)
+        finally:
+            ctx.set_medium_min_batch(0)
+        assert not red["info"].any()
+        assert np.array_equal(red["mu"], full["mu"]) and np.array_equal(red["var"], np.einsum("bii->bi", full["cov"]))
+        assert np.array_equal(red["logdet"], full["logdet"]) and np.array_equal(red["hyp"], full["hyp"])
+        assert np.array_equal(red["basis"], full["basis"])
+        with threadpool_limits(2):
+            mo, co, ho = go.gp_fit(X[0], y[0], nu[0], T)
+        Lc, ld = go.mvn_factor(co)
+        assert relerr(red["mu"][0], mo) < 1e-10 and relerr(red["var"][0], np.diag(co)) < 1e-10 and relerr(red["hyp"][0], ho) < 1e-10
+        assert abs(red["logdet"][0] - ld) < 1e-9 * abs(ld)
+        assert relerr(red["basis"][0, 1], sla.solve_triangular(Lc, mo, lower=True)) < 1e-9
 
 
 def test_fp32_instance_at_batch_scale(ctx):

@@ -103,13 +103,69 @@ def test_file_rendezvous_gather_matches_single_process(tmp_path, M, world):
     assert not rdzv.exists()                      # rank 0 removed the rendezvous directory after the last round
 
 
-def test_w2_single_sharded_rejects_uneven_shards():
-    class FakeCtx:
-        def comm_info(self):
-            return 0, 2, "librccl"
-    with pytest.raises(ValueError, match="n_members=5"):
-        parallel.w2_single_sharded(FakeCtx(), 5, np.zeros((3, 4)), np.zeros((3, 4, 4)))
+def test_w2_single_sharded_carries_uneven_shards():
+    """ModelSimilarityWeight(mode='single') sharded over ranks whose shards differ in length (weights.py:240-265 puts no
+    condition on the member count): the per-rank blocks go through the fixed-size all-gather padded to ceil(M / world) rows
+    and are compacted into the [M][...] table - here with NumPy-backed stand-ins for the device buffers and the collective,
+    for 7 members over 3 ranks (blocks 3, 2, 2), 5 over 2, 4 over 4 and the even case 6 over 3."""
+    class Buf:
+        def __init__(self, shape):
+            self.a = np.full(shape, np.nan)
+            self.shape = tuple(shape)
 
+        def upload(self, arr):
+            flat = np.asarray(arr).reshape(-1)
+            self.a.reshape(-1)[:flat.size] = flat
+            return self
+
+        def download(self):
+            return self.a.copy()
+
+        def copy_rows_from(self, dst_first, src, src_first, count=1):
+            self.a[dst_first:dst_first + count] = src.a[src_first:src_first + count]
+
+        def free(self):
+            self.a = None
+
+    class FakeCtx:
+        """One rank's context; `peers[r]` = what rank r uploads (filled in below, as the collective would see it)."""
+        def __init__(self, rank, world, tables):
+            self.rank, self.world, self.tables, self.calls = rank, world, tables, 0
+
+        def comm_info(self):
+            return self.rank, self.world, "fake"
+
+        def empty(self, shape):
+            return Buf(shape)
+
+        def allgather_rows(self, local, all_, rows, width):
+            M = sum(len(t[self.calls]) for t in self.tables)
+            for r in range(self.world):
+                blk = np.full((rows, width), np.nan)
+                mine = np.asarray(self.tables[r][self.calls]).reshape(len(self.tables[r][self.calls]), width)
+                blk[:len(mine)] = mine
+                all_.a.reshape(self.world * rows, width)[r * rows:(r + 1) * rows] = blk
+            assert np.array_equal(np.nan_to_num(local.a.reshape(rows, width)[:len(self.tables[self.rank][self.calls])]),
+                                  np.nan_to_num(np.asarray(self.tables[self.rank][self.calls]).reshape(-1, width)))
+            self.calls += 1
+
+        def w2_single_sharded_dev(self, M, N, mu, chol, w, D):
+            self.seen = (mu.a.copy(), chol.a.copy())
+            w.a[:] = 1.0 / M
+            D.a[:] = 0.0
+
+    rng = np.random.default_rng(3)
+    for M, world in ((7, 3), (5, 2), (4, 4), (6, 3), (2, 3)):
+        N = 4
+        mu, ch = rng.standard_normal((M, N)), rng.standard_normal((M, N, N))
+        tables = [(mu[slice(*parallel.shard_bounds(M, r, world))], ch[slice(*parallel.shard_bounds(M, r, world))]) for r in range(world)]
+        for r in range(world):
+            ctx = FakeCtx(r, world, tables)
+            w, D = parallel.w2_single_sharded(ctx, M, tables[r][0], tables[r][1])
+            assert np.array_equal(ctx.seen[0], mu) and np.array_equal(ctx.seen[1], ch), (M, world, r)
+            assert w.shape == (M,) and D.shape == (M, M)
+    with pytest.raises(ValueError, match="holds 3 members"):                 # a rank that holds the wrong block is told so
+        parallel.w2_single_sharded(FakeCtx(1, 2, tables), 5, np.zeros((3, 4)), np.zeros((3, 4, 4)))
 
 class _FakeCommCtx:
     """Stands in for _lib.Context in make_exchange: `fail_at` = None | 'load' | 'init' picks where this rank's RCCL breaks;
