@@ -123,6 +123,7 @@ def load():
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     lib.bayens_set_medium_min_batch.argtypes = [_vp, C.c_int]
     lib.bayens_set_fit_route.argtypes = [_vp, C.c_int]
+    lib.bayens_chain_stalls.argtypes = [_vp, C.POINTER(C.c_long)]
     lib.bayens_small_wave_stamps.argtypes = [_vp, _vp]
     lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
@@ -305,6 +306,12 @@ class Context:
         """Batch size from which members with 94 < N <= 254 take the fused mid-size kernel (1 = always, huge = never,
         0 = the default choice by size)."""
         self._check(self.lib.bayens_set_medium_min_batch(self.h, int(n)))
+
+    def chain_stalls(self):
+        """bayens_loglik_rows calls of this context that fell back from the chained substitution to the blocked solve."""
+        n = C.c_long()
+        self._check(self.lib.bayens_chain_stalls(self.h, C.byref(n)))
+        return int(n.value)
 
     def set_fit_route(self, route):
         """1: every fp64 fit takes the general path whatever its size; 0: the fused kernels by size (default)."""

@@ -99,6 +99,7 @@ struct bayens_ctx {
   int n_cus = 256;                 // compute units of the device (grid sizing of the fused small-member kernel)
   int medium_min_batch = 0;        // > 0: batches of at least this many mid-size members take the fused kernel (medium.hip); 0: by size
   int fit_route = 0;               // 0: fused kernels by size (default); 1: general path whatever the size (bayens_set_fit_route, fp64)
+  long chain_stalls = 0;           // bayens_loglik_rows calls whose chained substitution gave up and took the blocked solve
   double* mscratch = nullptr;      // tile scratch of the fused mid-size kernel (medium.hip), grown on demand
   size_t mscratch_cap = 0;
   double* medium_scratch(size_t count) {
@@ -469,6 +470,12 @@ int bayens_set_groups(bayens_ctx* c, int n_groups) {
 int bayens_set_medium_min_batch(bayens_ctx* c, int min_batch) {
   if (!c || min_batch < 0) return BAYENS_E_ARG;
   c->medium_min_batch = min_batch;
+  return 0;
+}
+
+int bayens_chain_stalls(bayens_ctx* c, long* count) {
+  if (!c || !count) return BAYENS_E_ARG;
+  *count = c->chain_stalls;
   return 0;
 }
 
@@ -987,6 +994,16 @@ int bayens_loglik_rows(bayens_ctx* c, int loc, int B, int N, int R_obs, const do
     BAYENS_HIP(hipStreamSynchronize(c->stream));
     static const bool force_stall = getenv("BAYENS_FORCE_CHAIN_STALL") != nullptr;     // (test hook for the fallback)
     if (herr || force_stall) {
+      // (the event leaves a trace: a per-context counter - bayens_chain_stalls - and, once per process, a line on stderr; a
+      //  timing of this entry that took the fallback is a timing of the blocked solve, and bench.py says so)
+      c->chain_stalls += 1;
+      static bool told = false;
+      if (!told && !force_stall) {
+        told = true;
+        fprintf(stderr, "libbayens: bayens_loglik_rows: the chained substitution ran out of polls (a consumer workgroup waited "
+                        "for a block that was not published within 2^21 tries) - recomputed through the blocked solve; "
+                        "bayens_chain_stalls() counts these events\n");
+      }
       // The chain's liveness rests on producer workgroups being dispatched before their consumers and is bounded by a
       // poll count, not by progress: on a GPU shared with other streams / processes a consumer can run out of polls
       // for perfectly valid input.  That is a scheduling accident, not an error of the caller: recompute the basis

@@ -400,8 +400,14 @@ double fit_flops(int N, int R, int n_iters) {
   // first iteration (Lam_old = I: G S = (I - S) / gamma): C^-1 1/3 + C^-T C^-1 1/3 replace the two solves => 3 N^3
   // prediction: chol K 1/3, L^-1 1/3, A^T C^-T 1, L^-T L^-1 1/3, rank-N update 1 => 3 N^3, chol(cov) 1/3
   // ... and when another iteration follows, the symmetric form: chol K, G, chol(nu + gamma K), its inverse, P => 5/3 N^3
+  // Scope of the count (round 4): the fit as THIS precision runs it WITHOUT loss samples.  fp32 keeps a lone first iteration in
+  // its general form (the (I - S) / gamma shortcut cancels in fp32: `first` in gp_fit needs sizeof(real) == sizeof(double)), so
+  // it saves nothing at n_iters == 1; with loss samples the sample of iteration 0 refactors Lam (general path: + 2/3 N^3 + a
+  // solve per sample) and the fused kernels (small.hip, medium.hip) keep the first iteration in its general / (I - S) / gamma
+  // form - those runs execute MORE than this figure, and no bench line that quotes a flop rate requests samples.
   double n3 = (double)N * N * N, n2r = 2.0 * N * (double)N * R;
-  const double first_saves = n_iters >= 2 ? 8.0 / 3.0 * n3 : (n_iters == 1 ? 4.0 / 3.0 * n3 : 0.0);
+  const bool f64 = sizeof(real) == sizeof(double);
+  const double first_saves = n_iters >= 2 ? 8.0 / 3.0 * n3 : (n_iters == 1 && f64 ? 4.0 / 3.0 * n3 : 0.0);
   return n_iters * (13.0 / 3.0 * n3 + n2r) - first_saves + (3.0 * n3 + n2r) + n3 / 3.0;
 }
 

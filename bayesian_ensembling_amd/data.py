@@ -83,9 +83,23 @@ class Distribution:
                 f"dim_array={getattr(self.dim_array, 'shape', None)}, dist_type={getattr(self.dist_type, '__name__', None)}) [{where}]")
 
     def __eq__(self, other):
+        """Equality of two posteriors.  Two views of the SAME resident posterior (a deep copy shares the HBM buffers) are equal
+        without touching the device; per-gridpoint fields - which keep marginals only, `covariance` raises - compare by mean
+        and marginal variance; everything else by mean and covariance like the reference's dataclass.  (A field pickles as the
+        marginal pair MultivariateNormalDiag(mean, stddev) - see __getstate__ - so a save / load round trip changes its
+        dist_type and the reloaded object does NOT compare equal to the resident original: what survives is what the
+        reference's consumers read, mean() and variance().)"""
         if not isinstance(other, Distribution):
             return NotImplemented
-        return (self.dist_type is other.dist_type and np.array_equal(np.asarray(self.mu), np.asarray(other.mu))
+        if self.dist_type is not other.dist_type:
+            return False
+        if self._resident is not None and other._resident is not None and self._resident[0] is other._resident[0] \
+                and self._resident[1] == other._resident[1]:
+            return True
+        if self.dist_type is dx.GridMultivariateNormalFullCovariance:
+            return (np.array_equal(np.asarray(self._dist.mean()), np.asarray(other._dist.mean()))
+                    and np.array_equal(np.asarray(self._dist.variance()), np.asarray(other._dist.variance())))
+        return (np.array_equal(np.asarray(self.mu), np.asarray(other.mu))
                 and np.array_equal(np.asarray(self.covariance), np.asarray(other.covariance)))
 
     __hash__ = None

@@ -134,10 +134,11 @@ class FileRendezvous(_HostRows):
 
     Safety of the directory (it may sit under a shared /tmp): it is created with mode 0700, and one that already
     exists is accepted only if this user owns it and nobody else can write to it.  Payloads travel in fixed formats
-    (raw bytes / .npy without pickle / JSON), never pickle.  Every attempt has its own SESSION token - rank 0 draws it
-    and publishes it in `session.<restart count>` together with its pid; the other ranks take a session file only from
-    a LIVE rank 0 - so the round files of an earlier attempt in the same directory (a worker restart under the same
-    launcher) are never read."""
+    (raw bytes / .npy without pickle / JSON), never pickle.  Every attempt has its own SESSION token - rank 0 clears the
+    directory, draws the token and publishes it in `session.<restart count>` together with the attempt's NONCE (what the
+    launcher gave every rank of this attempt and of no other: `attempt_nonce`); the other ranks take a session file only
+    if it carries their own nonce - so neither the round files nor the session of an earlier attempt in the same
+    directory (a worker restart under the same launcher, a recycled pid) are ever read."""
 
     def __init__(self, directory: str, rank: int, world: int, timeout_s: float = 300.0):
         self.dir, self.rank, self.world, self.timeout_s = directory, int(rank), int(world), timeout_s
@@ -146,32 +147,53 @@ class FileRendezvous(_HostRows):
             os.makedirs(directory, mode=0o700)
         except FileExistsError:
             pass
-        st = os.stat(directory)
-        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o022):
-            raise PermissionError(f"rendezvous directory {directory} is not a directory owned by this user that only "
-                                  "this user can write to: refusing to exchange through it")
+        st = os.lstat(directory)                         # lstat: a symlink planted under a shared /tmp is not a directory
+        if stat.S_ISLNK(st.st_mode) or not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o022):
+            raise PermissionError(f"rendezvous directory {directory} is not a directory (no symlink) owned by this user that "
+                                  "only this user can write to: refusing to exchange through it")
         self.session = self._open_session()
 
+    @staticmethod
+    def attempt_nonce() -> str:
+        """What every rank of ONE launch attempt shares and no other attempt does: BAYENS_RDZV_NONCE when the launcher set one
+        (bench.py's spawn_ranks draws a random one per run), else the launcher's run id, restart count, port and pid."""
+        n = os.environ.get("BAYENS_RDZV_NONCE")
+        if n:
+            return n
+        return ":".join([os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
+                         os.environ.get("MASTER_PORT", "0"), str(os.getppid())])
+
     def _open_session(self) -> str:
+        """The session token of THIS attempt.  Rank 0 clears what earlier attempts left in the directory, draws a token and
+        publishes it with the attempt's nonce; the others accept a session file only if it carries the SAME nonce (round 4:
+        the file used to be tied to rank 0's pid being alive, which a recycled pid, a zombie or a still-running earlier
+        rank 0 all satisfy - a peer then adopted the old token, read the old attempt's ncclUniqueId and sat in
+        ncclCommInitRank until the watchdog fired)."""
         restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
         path = os.path.join(self.dir, f"session.{restart}")
+        nonce = self.attempt_nonce()
         if self.rank == 0:
+            for name in os.listdir(self.dir):            # stale session / round / done files of earlier attempts
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
             token = f"{restart}-{os.urandom(8).hex()}"
             with open(path + ".tmp", "wb") as f:
-                f.write(_encode({"token": token, "pid": os.getpid()}))
-            os.replace(path + ".tmp", path)              # replaces whatever an earlier attempt left behind
+                f.write(_encode({"token": token, "pid": os.getpid(), "nonce": nonce}))
+            os.replace(path + ".tmp", path)
             return token
         deadline = time.time() + self.timeout_s
         while True:
             try:
                 with open(path, "rb") as f:
                     info = _decode(f.read())
-                os.kill(int(info["pid"]), 0)             # the rank 0 that wrote it is still alive: this attempt's session
-                return str(info["token"])
+                if str(info["nonce"]) == nonce:          # this attempt's rank 0 wrote it
+                    return str(info["token"])
             except (OSError, ValueError, KeyError, TypeError):
-                pass                                     # no file yet, a torn read, or a dead attempt's file: wait
+                pass                                     # no file yet, a torn read, or another attempt's file: wait
             if time.time() > deadline:
-                raise TimeoutError(f"rank {self.rank}: rank 0 never opened a rendezvous session in {self.dir}")
+                raise TimeoutError(f"rank {self.rank}: rank 0 never opened a rendezvous session of this attempt in {self.dir}")
             time.sleep(0.002)
 
     @staticmethod
@@ -184,14 +206,14 @@ class FileRendezvous(_HostRows):
         key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
         return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bayens_rdzv_{os.geteuid()}_{key}")
 
-    def allgather_obj(self, obj):
+    def allgather_obj(self, obj, timeout_s=None):
         tag = f"{self.session}.{self.round:06d}"
         self.round += 1
         mine = os.path.join(self.dir, f"{tag}.{self.rank}")
         with open(mine + ".tmp", "wb") as f:
             f.write(_encode(obj))
         os.replace(mine + ".tmp", mine)
-        out, deadline = [], time.time() + self.timeout_s
+        out, deadline = [], time.time() + (self.timeout_s if timeout_s is None else timeout_s)
         for r in range(self.world):
             path = os.path.join(self.dir, f"{tag}.{r}")
             while not os.path.exists(path):
@@ -297,6 +319,15 @@ class RcclExchange:
         self.ctx.comm_destroy()
 
 
+def _allgather_with_timeout(rdzv, obj, timeout_s):
+    """rdzv.allgather_obj with a bound of its own where the rendezvous supports one (FileRendezvous); HostGather (gloo) has the
+    process group's timeout."""
+    try:
+        return rdzv.allgather_obj(obj, timeout_s=timeout_s)
+    except TypeError:
+        return rdzv.allgather_obj(obj)
+
+
 class ExchangeUnavailable(RuntimeError):
     """RCCL could not be loaded / the communicator did not come up and the host-staged exchange was not allowed."""
 
@@ -329,9 +360,16 @@ def make_exchange(ctx, rdzv, prefer="rccl", allow_host_exchange=False, init_time
             mine = [True, ""]
         except Exception as e:             # noqa: BLE001
             ex, mine = None, [False, f"rank {rdzv.rank}: {e}"]
-        # (a peer stuck inside ncclCommInitRank never reaches this round: this rank then times out in the rendezvous
-        #  or is terminated by the parent when the stuck rank's watchdog fires - either way the run ends non-zero)
-        flags = rdzv.allgather_obj(mine)
+        # A peer stuck inside ncclCommInitRank never reaches this round; its watchdog ends it after init_timeout_s.  A rank
+        # that is waiting here for such a peer therefore gives up shortly after that - not after the rendezvous' own, longer
+        # timeout - and leaves the documented way (ExchangeUnavailable -> exit code 3), with its own failure if it had one.
+        try:
+            flags = _allgather_with_timeout(rdzv, mine, init_timeout_s + 30.0)
+        except TimeoutError as e:
+            if ex is not None:
+                ex.close()
+            raise ExchangeUnavailable("RCCL exchange unavailable (" + (mine[1] or f"rank {rdzv.rank}: a peer never reported "
+                                      "back from ncclCommInitRank") + f"; {e})") from e
         if all(f[0] for f in flags):
             return ex, "rccl", None
         if ex is not None:

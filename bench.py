@@ -39,12 +39,14 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # fp32 matrix peak (MI355X_MICROARCH.md: 16x16x4 f
 METRIC = "GP-member-fits/sec + weighted-posterior latency, 32-member x 2000-step ensemble"
 
 
-def fit_flops(N, R, T):
+def fit_flops(N, R, T, f32=False):
     """Algorithmic flop of one member fit (= fit_flops in csrc/driver.cpp): 13/3 N^3 per iteration, 3 N^3 in
-    a lone first one (Lam_old = I: G S = (I - S) / gamma needs S only) and 5/3 N^3 in a first one that another follows (its
-    hyper-gradient from P = (diag(nu) + gamma K)^-1 alone), 3 N^3 for the prediction, N^3/3 for chol(cov)."""
+    a lone first one (Lam_old = I: G S = (I - S) / gamma needs S only; fp64 only - fp32 keeps the general form there) and
+    5/3 N^3 in a first one that another follows (its hyper-gradient from P = (diag(nu) + gamma K)^-1 alone), 3 N^3 for the
+    prediction, N^3/3 for chol(cov).  The count is the fit WITHOUT loss samples (a sampled run executes more; no line that
+    quotes a flop rate requests samples)."""
     n3, n2r = float(N) ** 3, 2.0 * N * N * R
-    first_saves = 8.0 / 3.0 * n3 if T >= 2 else (4.0 / 3.0 * n3 if T == 1 else 0.0)
+    first_saves = 8.0 / 3.0 * n3 if T >= 2 else (4.0 / 3.0 * n3 if T == 1 and not f32 else 0.0)
     return T * (13.0 / 3.0 * n3 + n2r) - first_saves + (3.0 * n3 + n2r) + n3 / 3.0
 
 
@@ -305,7 +307,7 @@ class FieldWorkload:
         in_b = es * (N * R + 2 * N)
         out_b = es * (N * N + N) if self.export == "full" else 8.0 * (4 * N + 3)
         gbs = self.B * (in_b + out_b) / (fit_ms * 1e-3) / 1e9
-        tfl = self.B * fit_flops(N, R, self.T) / (fit_ms * 1e-3) / 1e12
+        tfl = self.B * fit_flops(N, R, self.T, self.f32) / (fit_ms * 1e-3) / 1e12
         peak_tfl = F32_MFMA_PEAK_TFLOPS if self.f32 else F64_MFMA_PEAK_TFLOPS
         return {"value": round(self.B * steps / elapsed, 1), "unit": "member-fits/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "fits_per_step": self.B, "export": self.export, "fit_kernel_ms": round(fit_ms, 3),
@@ -463,9 +465,10 @@ def mid_size_line(ctx, M=20, N=165, R=9, T=2500):
 def spawn_ranks(args):
     """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
     rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
+    nonce = os.urandom(8).hex()          # what the ranks of THIS run share: a rendezvous session of any other run is not theirs
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), BAYENS_RDZV=rdzv,
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), BAYENS_RDZV=rdzv, BAYENS_RDZV_NONCE=nonce,
                    MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -587,8 +590,9 @@ def main():
         try:
             exchange, args.exchange, args.exchange_note = parallel.make_exchange(
                 ctx, rdzv, args.exchange, allow_host_exchange=args.allow_host_exchange, init_timeout_s=args.comm_init_timeout)
-        except parallel.ExchangeUnavailable as e:
+        except (parallel.ExchangeUnavailable, TimeoutError) as e:
             # strict by default: a multi-rank line measured through /tmp files must never pass for an RCCL measurement
+            # (TimeoutError: a peer never reached a rendezvous round at all - the same outcome, the same exit code)
             print(f"rank {rank}: {e}", file=sys.stderr, flush=True)
             raise SystemExit(3)
         if args.exchange == "rccl":
@@ -627,15 +631,18 @@ def main():
         ctx.timer_start(); ctx.loglik_rows_dev(M, N, wl.R_obs, wl.dmu, wl.dchol, wl.dld, wl.dobs, wl.dll_loc); ll_chol_ms = ctx.timer_stop()
     roof = wl.roofline()
     ctx.set_groups(args.groups)
-    fit_tfl = M * fit_flops(N, R, T) / (fit_ms * 1e-3) / 1e12
+    fit_tfl = M * fit_flops(N, R, T, f32) / (fit_ms * 1e-3) / 1e12
     extra = {"fit_batch_ms": round(fit_ms, 3), "weighted_posterior_latency_ms": round(wp_ms, 4),
              "fit_algorithmic_tflops": round(fit_tfl, 3), "fit_frac_of_mfma_peak": round(fit_tfl / peak, 4),
-             "fit_algorithmic_flop_per_member": fit_flops(N, R, T),
+             "fit_algorithmic_flop_per_member": fit_flops(N, R, T, f32),
              "fit_flop_note": "flop the device path executes by construction (fit_flops; DESIGN section 4): 13/3 N^3 per general "
                               "iteration, 5/3 N^3 in a first iteration that another follows (symmetric form), 10/3 N^3 for the "
                               "prediction + chol(cov); round 2 counted 9.6e10 for this workload, round 3 executes 7.5e10",
              "barycentre_not_converged": int(bad),
-             "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4)}
+             "loglik_rows_from_chol_ms": None if ll_chol_ms is None else round(ll_chol_ms, 4),
+             # > 0: the timed bayens_loglik_rows call(s) took the blocked-solve fallback of the chained launch, and the figure
+             # above is the fallback's time (include/bayens.h, bayens_chain_stalls)
+             "loglik_rows_chain_stalls": ctx.chain_stalls()}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(N, R, T, args.cpu_members)

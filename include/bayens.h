@@ -37,7 +37,7 @@ enum {
   BAYENS_E_COMM = -4,     /* RCCL not initialised or not loadable */
   BAYENS_E_ALLOC = -5,
   BAYENS_E_NOCONV = -6,   /* an iteration (the polar iteration of bayens_w2_single) did not converge: outputs invalid */
-  BAYENS_E_INTERNAL = -7  /* a device-side wait gave up (bayens_loglik_rows' substitution chain): outputs invalid */
+  BAYENS_E_INTERNAL = -7  /* an internal invariant failed (not raised by a stalled substitution chain: bayens_loglik_rows recovers) */
 };
 
 /* ---- context, memory and timing plumbing -------------------------------------------------- */
@@ -154,7 +154,13 @@ int bayens_widen_f32(bayens_ctx* ctx, int loc, size_t n, const float* src, doubl
 /* LogLikelihoodWeight._compute inner loops, MVN branch (ensembles/weights.py:88-104):
  * ll_mean[b][t] = mean_r log N(obs[r][t] * 1_N ; mu_b, cov_b)   obs [R_obs][N]
  * cov_chol [B][N][N]: lower factors, only the lower triangle is read (one chained launch over the compact factor).
- * BAYENS_E_INTERNAL if the device-side chain gives up waiting (outputs invalid). */
+ * Forward-progress note: the chained launch hands partial results from workgroup to workgroup (a consumer polls device memory
+ * for the block its predecessor publishes).  Its block ids are ordered so that a workgroup only waits for workgroups with
+ * SMALLER ids, and it assumes what the hardware dispatcher does in practice but no programming model promises - that
+ * workgroups are dispatched in id order, so every producer is resident or finished when its consumer starts.  The wait is
+ * bounded (2^21 polls); when it runs out - a GPU shared with other work can reorder dispatch - the entry does NOT fail: it
+ * recomputes the rows through the blocked triangular solve (no cross-workgroup waits), counts the event
+ * (bayens_chain_stalls, bayens_diag.h) and says so once on stderr.  Results are identical to rounding either way. */
 int bayens_loglik_rows(bayens_ctx* ctx, int loc, int B, int N, int R_obs,
                        const double* mu, const double* cov_chol, const double* logdet,
                        const double* obs, double* ll_mean);

@@ -68,6 +68,10 @@ int bayens_set_medium_min_batch(bayens_ctx* ctx, int min_batch);
  * choice by size (fused kernels for N <= 254).  The parity tests use it to hold all routes to the same fixtures in one
  * process (the environment switches BAYENS_NO_SMALL / BAYENS_NO_MEDIUM are read once per process). */
 int bayens_set_fit_route(bayens_ctx* ctx, int route);
+/* Number of bayens_loglik_rows calls on this context whose one-launch chained substitution gave up (a consumer workgroup ran
+ * out of polls - see the note at bayens_loglik_rows in bayens.h) and were recomputed through the blocked solve.  The results of
+ * such a call are correct; its run time is that of the fallback.  bench.py reports the count beside its timing of the entry. */
+int bayens_chain_stalls(bayens_ctx* ctx, long* count);
 
 /* Diagnostic: the pack -> [ncclAllGather image] -> unpack index arithmetic of bayens_allgather_member_rows without a
  * communicator: the host tables ll / mean / var [M][P] are split over `nranks` fictitious ranks exactly as

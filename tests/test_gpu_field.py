@@ -97,6 +97,32 @@ def test_field_weight_table_stays_resident_and_host_schemes_work(ctx):
     assert np.allclose(w.mean("time").values, np.asarray(w.values).mean(axis=1))
 
 
+def test_equality_of_resident_and_field_posteriors_does_not_download(ctx):
+    """Distribution.__eq__: a deep copy of a resident posterior shares its HBM buffers and is equal by identity (no 64 MB
+    covariance download per member); per-gridpoint fields - whose `covariance` raises - compare by their marginals; a field that
+    went through pickle is the marginal pair and no longer equal to the resident original (documented on __eq__)."""
+    import copy
+    import pickle
+    mc, _ = _field_collection(2, 3, 12, 2, 3, seed=21)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=1, progress_bar=False)
+    d0, d1 = mc.models[0].distribution, mc.models[1].distribution
+    assert d0 == copy.deepcopy(d0) and d0 == d0 and not (d0 == d1)
+    with pytest.raises(NotImplementedError):
+        d0.covariance
+    assert not (pickle.loads(pickle.dumps(d0)) == d0)
+    # full-covariance resident posteriors: identity short-circuit (the buffers stay untouched) and value comparison
+    data, _ = go.synthetic_ensemble(2, 40, R=4, seed=2)
+    time = np.arange(40)
+    pm = lambda a, name: es.ProcessModel(DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": time}), name)
+    mc2 = es.ModelCollection([pm(data[m], f"m{m}") for m in range(2)])
+    mc2.fit(model=es.GPDTW1D(), n_optim_nits=1, progress_bar=False)
+    e0 = mc2.models[0].distribution
+    clone = copy.deepcopy(e0)
+    assert clone == e0 and clone._resident is not None and e0._mu is None          # nothing was downloaded for the comparison
+    assert not (e0 == mc2.models[1].distribution)
+    assert pickle.loads(pickle.dumps(e0)) == e0                                      # full-covariance posteriors survive pickling
+
+
 def test_field_at_the_references_historical_horizon(ctx):
     """N = 165 time steps per grid point (the reference's historical annual horizon, experiments/full_experiment_script.py:57 -
     the fused small-member kernel stops at 94): GPDTW1D(per_gridpoint=True) takes the fused mid-size kernel with the reduced

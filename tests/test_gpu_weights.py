@@ -547,12 +547,15 @@ def test_loglik_rows_falls_back_to_the_blocked_solve_when_the_chain_stalls(ctx, 
     chol = np.linalg.cholesky(A @ A.transpose(0, 2, 1) / N + 0.5 * np.eye(N))
     logdet = np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(axis=1)
     mu, obs = rng.standard_normal((M, N)), rng.standard_normal((4, N))
+    before = ctx.chain_stalls()
     chained = ctx.loglik_rows(mu, chol, logdet, obs)
+    assert ctx.chain_stalls() == before                                          # the chained launch itself went through
     np.savez(tmp_path / "in.npz", mu=mu, chol=chol, logdet=logdet, obs=obs)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, numpy as np; sys.path.insert(0, %r); from bayesian_ensembling_amd import _lib; "
             "d = np.load(%r); c = _lib.Context(0); "
-            "np.save(%r, c.loglik_rows(d['mu'], d['chol'], d['logdet'], d['obs']))"
+            "np.save(%r, c.loglik_rows(d['mu'], d['chol'], d['logdet'], d['obs'])); "
+            "assert c.chain_stalls() == 1"                                      # the fallback is counted, not silent
             % (root, str(tmp_path / "in.npz"), str(tmp_path / "out.npy")))
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BAYENS_FORCE_CHAIN_STALL="1"), timeout=300)
     fallback = np.load(tmp_path / "out.npy")

@@ -270,22 +270,36 @@ def test_rendezvous_refuses_a_directory_others_can_write_to(tmp_path):
     parallel.FileRendezvous(str(d), 0, 1).close()
 
 
-def test_rendezvous_ignores_the_files_of_an_earlier_attempt(tmp_path):
-    """A restarted attempt in the same directory (same launcher pid / port / run id) must not read the previous attempt's
-    round files: every attempt has its own session token, and a session file left by a dead rank 0 is not taken."""
+def test_rendezvous_ignores_the_files_of_an_earlier_attempt(tmp_path, monkeypatch):
+    """A restarted attempt in the same directory must not read the previous attempt's files: every attempt has its own
+    session token, rank 0 clears what earlier attempts left behind, and a non-zero rank takes a session file only if it
+    carries the NONCE of its own attempt (not: if the pid in it is alive - a recycled pid, a zombie or a still-running
+    earlier rank 0 would all pass that)."""
     d = tmp_path / "rdzv"
+    monkeypatch.setenv("BAYENS_RDZV_NONCE", "attempt-1")
     first = parallel.FileRendezvous(str(d), 0, 1)
     assert first.allgather_obj([True, "old"]) == [[True, "old"]]
-    stale = sorted(os.listdir(d))
-    second = parallel.FileRendezvous(str(d), 0, 1)               # rank 0 of the next attempt: new token
+    stale = sorted(n for n in os.listdir(d) if not n.startswith("session."))
+    assert stale
+    monkeypatch.setenv("BAYENS_RDZV_NONCE", "attempt-2")
+    second = parallel.FileRendezvous(str(d), 0, 1)               # rank 0 of the next attempt: new token, directory cleared
     assert second.session != first.session
+    assert not any(name in os.listdir(d) for name in stale)
     assert second.allgather_obj(b"\x01\x02") == [b"\x01\x02"] and second.round == 1
-    assert all(name in os.listdir(d) for name in stale if not name.startswith("session."))
-    # a non-zero rank only accepts a session whose rank 0 is alive
-    with open(d / "session.0", "wb") as f:
-        f.write(parallel._encode({"token": "dead", "pid": 2 ** 22 + 12345}))
+    # a non-zero rank of attempt 3 does not adopt attempt 2's session although the rank 0 that wrote it (this process) is alive
+    monkeypatch.setenv("BAYENS_RDZV_NONCE", "attempt-3")
     with pytest.raises(TimeoutError):
         parallel.FileRendezvous(str(d), 1, 2, timeout_s=0.3)
+    # ... and takes one that carries its own nonce, whatever pid is in it
+    with open(d / "session.0", "wb") as f:
+        f.write(parallel._encode({"token": "mine", "pid": 2 ** 22 + 12345, "nonce": "attempt-3"}))
+    assert parallel.FileRendezvous(str(d), 1, 2, timeout_s=5).session == "mine"
+    # a symlink to a directory this user owns is not a rendezvous directory
+    target = tmp_path / "elsewhere"
+    target.mkdir(mode=0o700)
+    os.symlink(target, tmp_path / "link")
+    with pytest.raises(PermissionError):
+        parallel.FileRendezvous(str(tmp_path / "link"), 0, 1)
     arr = np.arange(6.0).reshape(2, 3)
     assert np.array_equal(parallel._decode(parallel._encode(arr)), arr) and parallel._decode(parallel._encode(None)) is None
     with pytest.raises(ValueError):
