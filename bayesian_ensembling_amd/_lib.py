@@ -125,6 +125,7 @@ def load():
     lib.bayens_set_fit_route.argtypes = [_vp, C.c_int]
     lib.bayens_chain_stalls.argtypes = [_vp, C.POINTER(C.c_long)]
     lib.bayens_small_wave_stamps.argtypes = [_vp, _vp]
+    lib.bayens_potrf256_stamps.argtypes = [_vp, _vp]
     lib.bayens_test_member_rows_exchange.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
@@ -755,6 +756,11 @@ class Context:
         """Per-wave stamps of the last recorded small fit: (8, 16) uint64 (zeros where a build places no stamp)."""
         out = np.zeros(128, dtype=np.uint64)
         self._check(self.lib.bayens_small_wave_stamps(self.h, _ptr(out)))
+        return out.reshape(8, 16)
+
+    def potrf256_stamps(self):
+        out = np.zeros(128, dtype=np.uint64)
+        self._check(self.lib.bayens_potrf256_stamps(self.h, _ptr(out)))
         return out.reshape(8, 16)
 
     def test_potrf(self, A):

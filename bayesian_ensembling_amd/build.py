@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbayens.so")
-SOURCES = ["gemm.hip", "kernels.hip", "dba.hip", "small.hip", "medium.hip", "capi.hip", "driver.cpp"]
+SOURCES = ["gemm.hip", "kernels.hip", "dba.hip", "small.hip", "medium.hip", "potrf256.hip", "capi.hip", "driver.cpp"]
 # the fp32 instance of the fit: the same sources compiled a second time with real = float (namespace bayens_f32)
 SOURCES_F32 = ["gemm.hip", "kernels.hip", "small.hip", "driver.cpp", "fit_f32.hip"]
 ARCH = "gfx950"

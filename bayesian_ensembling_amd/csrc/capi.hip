@@ -17,6 +17,7 @@
 #include "fit_ws.h"
 #include "hip_prims.h"
 #include "medium.h"
+#include "potrf256.h"
 #include "small.h"
 
 using namespace bayens;
@@ -1707,6 +1708,15 @@ int bayens_small_stamps(bayens_ctx* c, int enable, unsigned long long* stamps32)
       BAYENS_HIP(hipMemcpy(stamps32, c->small_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     if (!enable && c->small_stamps) { (void)hipFree(c->small_stamps); c->small_stamps = nullptr; }
+    return 0;
+  });
+}
+
+int bayens_potrf256_stamps(bayens_ctx* c, unsigned long long* stamps128) {
+  return guarded(c, [&]() {
+    if (!stamps128) return fail(c, BAYENS_E_ARG, "potrf256_stamps: null output");
+    BAYENS_HIP(hipStreamSynchronize(c->stream));
+    potrf256n::potrf256_stamps(stamps128);
     return 0;
   });
 }

@@ -86,6 +86,7 @@ static void potrf_rec(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride
     P.potrf_leaf2(nb, A, inv, inv_stride, base, info);
     return;
   }
+  if (n == 4 * LEAF && extra == 0 && P.potrf_diag256(nb, A, inv, inv_stride, base, info)) return;   // one fused launch
   int n1 = split_point(n), n2 = n - n1;
   potrf_rec(P, nb, n1, A, inv, inv_stride, info, base, 0);
   // [L21; E1] = [A21; E1] L11^-T

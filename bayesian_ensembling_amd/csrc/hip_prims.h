@@ -89,6 +89,7 @@ struct HipPrims : Prims {
   void trsm_panel(int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B, int mode) override;
   void potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
   void potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
+  bool potrf_diag256(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) override;
   void copy(int nb, int n, Mat src, Mat dst) override;
   void tri_copy(int nb, int n, Mat src, Mat dst) override;
   void transpose_lower(int nb, int n, Mat W, Mat Wt) override;

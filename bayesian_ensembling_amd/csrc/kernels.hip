@@ -1615,6 +1615,23 @@ void HipPrims::potrf_leaf(int nb, Mat Ablk, real* inv, long inv_stride, int pivo
                      leaf_stamps);
   LAUNCH_CHECK();
 }
+#ifndef BAYENS_F32
+}  // namespace BAYENS_NS
+#include "potrf256.h"
+namespace BAYENS_NS {
+#endif
+bool HipPrims::potrf_diag256(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) {
+#ifdef BAYENS_F32
+  (void)nb; (void)Ablk; (void)inv; (void)inv_stride; (void)pivot_base; (void)info;
+  return false;                                   // (the fp32 instance keeps the four-launch composition)
+#else
+  static const bool off = getenv("BAYENS_NO_POTRF256") != nullptr;      // measurement switch
+  if (off) return false;
+  potrf256n::potrf_diag256(stream, nb, Ablk, inv, inv_stride, pivot_base, info);
+  return true;
+#endif
+}
+
 void HipPrims::potrf_leaf2(int nb, Mat Ablk, real* inv, long inv_stride, int pivot_base, int* info) {
   hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(nb), dim3(256), 0, stream, Ablk, inv, inv_stride, pivot_base, info);
   LAUNCH_CHECK();

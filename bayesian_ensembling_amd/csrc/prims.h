@@ -83,6 +83,12 @@ struct Prims {
     potrf_leaf(nb, Ablk.sub(LEAF, LEAF), inv + LEAF * LEAF, inv_stride, pivot_base + LEAF, info);
   }
 
+  // A whole 256 x 256 diagonal block (four leaves): returns false when the back end has no fused form, and the driver then
+  // runs the recursive composition (potrf_rec in driver.cpp, which is the definition of the result up to rounding).
+  virtual bool potrf_diag256(int /*nb*/, Mat /*Ablk*/, real* /*inv*/, long /*inv_stride*/, int /*pivot_base*/, int* /*info*/) {
+    return false;
+  }
+
   virtual void copy(int nb, int n, Mat src, Mat dst) = 0;        // full n x n copy
   virtual void tri_copy(int nb, int n, Mat src, Mat dst) = 0;    // dst = tril(src), zeros above
   virtual void transpose_lower(int nb, int n, Mat W, Mat Wt) = 0;  // Wt = tril(W)^T (zeros below diag)

@@ -52,6 +52,10 @@ int bayens_small_stamps(bayens_ctx* ctx, int enable, unsigned long long* stamps3
 /* ... and the per-wave stamps of the same recording: stamps128[wave * 16 + k], k-th WSTAMP of wave `wave` (0..7) of workgroup 0
  * (which phases carry them is a property of the build; tools/small_phases.py prints what it finds). */
 int bayens_small_wave_stamps(bayens_ctx* ctx, unsigned long long* stamps128);
+/* Diagnostic: cycle-counter stamps [8 waves][16] of workgroup 0 of the last launch of the fused 256 x 256 diagonal-block
+ * Cholesky (csrc/potrf256.hip): 0 start, 1 inputs in, 3 first diagonal tile factored, 4 / 5 after block columns 0 / 7,
+ * 6 after the last, 7 outputs issued, 9 block inverses done (tools/potrf256_phases.py). */
+int bayens_potrf256_stamps(bayens_ctx* ctx, unsigned long long* stamps128);
 /* in-place blocked Cholesky (lower) of [nb][n][n], n % 64 == 0 */
 int bayens_test_potrf(bayens_ctx* ctx, int nb, int n, double* A, int* info);
 /* B <- B * L^-T (mode 0) or B * L^-1 (mode 1), L [nb][n][n] lower (already factored), B [nb][m][n] */

@@ -92,6 +92,30 @@ def test_blocked_cholesky(ctx, nb, n):
     assert np.array_equal(np.triu(Lg, 1), np.zeros_like(Lg))
 
 
+def test_fused_256_diagonal_block_cholesky_and_its_block_inverses(ctx):
+    """csrc/potrf256.hip (one launch per 256 x 256 diagonal block, the block's tiles register-resident): the factor against
+    LAPACK with garbage above the diagonal on input (only the lower triangle is read), zeros above it on output, a batch larger
+    than one, every pivot position reported, and - through a triangular solve that multiplies by them - the inverted 64 x 64
+    diagonal blocks it leaves for the fused panel solves."""
+    rng = np.random.default_rng(256)
+    nb, n = 5, 512
+    M = rng.standard_normal((nb, n, n))
+    S = M @ np.swapaxes(M, 1, 2) + n * np.eye(n)
+    Sin = np.tril(S) + np.triu(rng.standard_normal((nb, n, n)) * 1e3, 1)          # the strict upper triangle is never read
+    Lg, info = ctx.test_potrf(Sin)
+    ref = np.linalg.cholesky(S)
+    assert not info.any() and relerr(Lg, ref) < 1e-12
+    assert np.array_equal(np.triu(Lg, 1), np.zeros_like(Lg))
+    for piv in (0, 15, 16, 100, 255, 256 + 77, 511):
+        bad = np.eye(n)[None].repeat(2, axis=0)
+        bad[1, piv, piv] = -1.0
+        _, info = ctx.test_potrf(bad)
+        assert info[0] == 0 and info[1] == piv + 1, piv
+    Bm = rng.standard_normal((nb, 64, n))
+    want = np.stack([np.linalg.solve(ref[b], Bm[b].T).T for b in range(nb)])      # B L^-T
+    assert relerr(ctx.test_trsm(ref, Bm, 0), want) < 1e-11
+
+
 def test_cholesky_reports_the_failing_pivot(ctx):
     S = np.eye(256)[None].repeat(2, axis=0)
     S[1, 130, 130] = -3.0
