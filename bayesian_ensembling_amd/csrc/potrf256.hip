@@ -231,79 +231,113 @@ __device__ __forceinline__ void factor_wave(double* a, long ld, double* inv, lon
   PSTAMP(3);
   // The column loop is a RUN-TIME loop over compile-time slots (tile q = WK + 6 s has constant (i, j); "is it in column k" /
   // "is it right of column k" are scalar tests): fully unrolled over the 15 columns the kernel was 350 KB of straight-line code,
-  // each instruction executed once - the waves waited for their instructions (87 us per 32 x 256 factorisation, 63 with only
-  // the 16 x 16 factorisation as a real call, [see profiles] with this loop).
-#pragma unroll 1
-  for (int k = 0; k < NT - 1; ++k) {
-    double* pk = panel + (k & 1) * NT * TS;
+  // each instruction executed once, and the waves waited for their instructions.
+  // Columns go in PAIRS (k, k + 1), k even: after the panel of column k only the tiles of column k + 1 take its rank-16 update;
+  // every tile further right waits for the panel of column k + 1 and takes both in ONE operation (eight MFMAs behind sixteen
+  // operand reads): half as many tile operations, each with twice the matrix work behind its fixed cost (a branch, an LDS round
+  // trip) - a tile operation of four MFMAs took ~850 cycles where its MFMAs need 256.
+  auto store_col = [&](int k, const double* pk, long ldo, int lane_o) {
+    // the finished tiles of column k leave for memory off the chain's path: read back from the panel tile, so that a store
+    // instruction covers four whole 128-byte rows (32-byte segments straight from the registers took ~700 cycles per
+    // instruction to issue), and zeros go into the mirror image of a tile that lies inside a diagonal 64-block (the consumers
+    // of a factor read whole 64 x 64 diagonal blocks: the triangle above the diagonal must hold zeros, and the input holds the
+    // symmetric values there when it comes out of a GEMM)
+    static_for<TPW>([&](auto S) {
+      constexpr int s = decltype(S)::value, q = WK + NWK * s, i = tile_row(q), j = tile_col(q);
+      if (j == k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int e = lane_o + 64 * t, r = e >> 4, c = e & 15;
+          a[(long)(16 * i + r) * ldo + 16 * j + c] = pk[i * TS + swz(r, c)];
+        }
+        if constexpr ((i >> 2) == (j >> 2)) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int e = lane_o + 64 * t;
+            a[(long)(16 * j + (e >> 4)) * ldo + 16 * i + (e & 15)] = 0.0;
+          }
+        }
+      }
+      FENCE();
+    });
+  };
+  auto panel_col = [&](int k, double* pk) {      // L_ik^T = inv(L_kk) A_ik^T (right-hand side from registers); tile -> LDS, standard orientation
     const double* ik = dinv + k * TS;
+    static_for<TPW>([&](auto S) {
+      constexpr int s = decltype(S)::value, q = WK + NWK * s, i = tile_row(q), j = tile_col(q);
+      if (j == k) {
+        const v4d zero = {0, 0, 0, 0};
+        T[s] = mma_nb<false>(zero, ik, T[s], o);
+        st_tile_t(pk + i * TS, o, T[s]);
+      }
+      FENCE();
+    });
+  };
+  auto chain_step = [&](int kn, v4d d) {         // factor + invert diagonal tile kn (all its updates applied), L_kn,kn out
+    bad = diag16_call(d, L_DFAC + (kn & 1) * TS, L_DINV + kn * TS, pivot_base + 16 * kn, bad);
+    LWAIT();
+    write_diag(kn, dfac + (kn & 1) * TS);
+    report();
+  };
+#pragma unroll 1
+  for (int k = 0; k < NT; k += 2) {
+    double* p0 = panel;                   // panel of column k (k even)
+    double* p1 = panel + NT * TS;         // panel of column k + 1
     // (output addresses are derived from an opaque copy of the leading dimension: otherwise the compiler recognises the row
     //  addresses of the input phase, keeps all 80 of them alive through the loop and spills 500 registers for it)
     long ldo = ld;
     asm volatile("" : "+s"(ldo));
     int lane_o = lane;                    // (likewise the lane-dependent row / column offsets of the stores: recomputed here - a few
     asm volatile("" : "+v"(lane_o));      //  integer operations - instead of hoisted out of the loop, spilled and reloaded from memory)
-    // ---- panel: L_ik^T = inv(L_kk) A_ik^T (right-hand side from registers); the tile goes to LDS in standard orientation
+    // ---- 1: panel of column k
+    if constexpr (WORKER) panel_col(k, p0);
+    SYNC();
+    // ---- 2: wave 0: diagonal tile k + 1 | workers: column k out, the rank-16 update of the tiles of column k + 1
+    if constexpr (CHAIN) {
+      v4d d = ld_tile(diag + (k + 1) * TS, o);
+      d = mma_sub_nt(d, p0 + (k + 1) * TS, p0 + (k + 1) * TS, o);
+      chain_step(k + 1, d);
+    }
     if constexpr (WORKER) {
+      store_col(k, p0, ldo, lane_o);
       static_for<TPW>([&](auto S) {
         constexpr int s = decltype(S)::value, q = WK + NWK * s, i = tile_row(q), j = tile_col(q);
-        if (j == k) {
-          const v4d zero = {0, 0, 0, 0};
-          T[s] = mma_nb<false>(zero, ik, T[s], o);
-          st_tile_t(pk + i * TS, o, T[s]);
-        }
+        if (j == k + 1) T[s] = mma_sub_nt(T[s], p0 + j * TS, p0 + i * TS, o);        // T_ij -= L_jk L_ik^T  (T = A^T)
         FENCE();
       });
     }
     SYNC();
-    if constexpr (CHAIN) {
-      // ---- the chain: the column's update of the next diagonal tile, then its factorisation + inverse
-      v4d d = ld_tile(diag + (k + 1) * TS, o);
-      d = mma_sub_nt(d, pk + (k + 1) * TS, pk + (k + 1) * TS, o);
-      bad = diag16_call(d, L_DFAC + ((k + 1) & 1) * TS, L_DINV + (k + 1) * TS, pivot_base + 16 * (k + 1), bad);
-      LWAIT();
-      write_diag(k + 1, dfac + ((k + 1) & 1) * TS);
-      report();
+    // ---- 3: panel of column k + 1
+    if constexpr (WORKER) panel_col(k + 1, p1);
+    SYNC();
+    // ---- 4: wave 0: diagonal tile k + 2 (both columns' updates) | workers: column k + 1 out, the rank-32 update of everything
+    // right of it - register tiles, and the diagonal tiles beyond k + 2 in LDS (symmetric images)
+    if (k + 2 < NT) {
+      if constexpr (CHAIN) {
+        v4d d = ld_tile(diag + (k + 2) * TS, o);
+        d = mma_sub_nt(d, p0 + (k + 2) * TS, p0 + (k + 2) * TS, o);
+        d = mma_sub_nt(d, p1 + (k + 2) * TS, p1 + (k + 2) * TS, o);
+        chain_step(k + 2, d);
+      }
     }
     if constexpr (WORKER) {
-      // ---- the finished tiles of column k leave for memory here, off the chain's path (the panel phase above is on it)
+      store_col(k + 1, p1, ldo, lane_o);
       static_for<TPW>([&](auto S) {
         constexpr int s = decltype(S)::value, q = WK + NWK * s, i = tile_row(q), j = tile_col(q);
-        if (j == k) {
-          // read back from the panel tile, so that a store instruction covers four whole 128-byte rows (32-byte segments
-          // straight from the registers took ~700 cycles per instruction to issue) ...
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int e = lane_o + 64 * t, r = e >> 4, c = e & 15;
-            a[(long)(16 * i + r) * ldo + 16 * j + c] = pk[i * TS + swz(r, c)];
-          }
-          // ... and zeros into its mirror image when the tile lies inside a diagonal 64-block (the consumers of a factor read
-          // whole 64 x 64 diagonal blocks: the triangle above the diagonal must hold zeros, and the input holds the symmetric
-          // values there when it comes out of a GEMM)
-          if constexpr ((i >> 2) == (j >> 2)) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int e = lane_o + 64 * t;
-              a[(long)(16 * j + (e >> 4)) * ldo + 16 * i + (e & 15)] = 0.0;
-            }
-          }
+        if (j > k + 1) {
+          T[s] = mma_sub_nt(T[s], p0 + j * TS, p0 + i * TS, o);
+          T[s] = mma_sub_nt(T[s], p1 + j * TS, p1 + i * TS, o);
         }
         FENCE();
       });
-      // ---- trailing update of the register tiles, T_ij -= L_jk L_ik^T (T = A^T) ...
-      static_for<TPW>([&](auto S) {
-        constexpr int s = decltype(S)::value, q = WK + NWK * s, i = tile_row(q), j = tile_col(q);
-        if (j > k) T[s] = mma_sub_nt(T[s], pk + j * TS, pk + i * TS, o);
-        FENCE();
-      });
-      // ... and of the diagonal tiles beyond the next one, in LDS (symmetric images)
       static_for<3>([&](auto JJ) {
         constexpr int jj = WK + NWK * decltype(JJ)::value;
         if constexpr (jj < NT) {
-          if (jj > k + 1) {
+          if (jj > k + 2) {
             double* dj = diag + jj * TS;
             v4d t = ld_tile(dj, o);
-            t = mma_sub_nt(t, pk + jj * TS, pk + jj * TS, o);
+            t = mma_sub_nt(t, p0 + jj * TS, p0 + jj * TS, o);
+            t = mma_sub_nt(t, p1 + jj * TS, p1 + jj * TS, o);
             st_tile(dj, o, t);
           }
         }
@@ -312,7 +346,7 @@ __device__ __forceinline__ void factor_wave(double* a, long ld, double* inv, lon
     }
     SYNC();
     if (k == 0) PSTAMP(4);
-    if (k == 7) PSTAMP(5);
+    if (k == 6) PSTAMP(5);
   }
   PSTAMP(6);
 
