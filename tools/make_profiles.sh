@@ -62,4 +62,11 @@ timeout -k 10 300 python3 tools/api_path_c5.py > $OUT/${TAG}_api_path_c5.json 2>
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 31 50 > $OUT/${TAG}_fuzz_seed31.log 2>&1 || exit 20
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 32 50 > $OUT/${TAG}_fuzz_seed32.log 2>&1 || exit 21
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 47 50 > $OUT/${TAG}_fuzz_seed47.log 2>&1 || exit 22
+# round 4: the fused 256-wide diagonal-block Cholesky by wave, the fp64 VALU rates the small kernel is priced against, the
+# small kernel's reduced export, and the config-5 API path stage by stage
+timeout -k 10 120 python3 tools/potrf256_phases.py > $OUT/${TAG}_potrf256_phases.txt 2>&1 || exit 23
+timeout -k 10 120 python3 tools/valu64_bench.py > $OUT/${TAG}_valu64_bench.txt 2>&1 || exit 24
+timeout -k 10 200 python3 tools/small_phases.py 86 8 8192 reduced > $OUT/${TAG}_small_phases_reduced.txt 2>&1 || exit 25
+timeout -k 10 300 python3 tools/api_path_c5_profile.py > $OUT/${TAG}_api_path_c5_profile.txt 2>&1 || exit 26
+timeout -k 10 300 python3 tools/scale_check.py > $OUT/${TAG}_scale_check.txt 2>&1 || exit 27
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
