@@ -154,6 +154,25 @@ __device__ __forceinline__ v4r mma(v4r acc, const real* A, const real* B, const 
   return acc;
 }
 
+// (measurement only, tools/worker_bench.py) The same product with ONE accumulator chain and no fp64
+// vector arithmetic at all.  fp64 vector operations issue on the matrix pipe and wait out the 64-cycle MFMA the other wave of the
+// SIMD has in it, so the sign multiply and the merge of two chains (8 v_*_f64 per product) cost more than the ~14-cycle bubble
+// of a dependent MFMA, which the partner wave fills anyway.  NEG: acc -= op(A) op(B), the sign flipped in the integer pipe.
+__device__ __forceinline__ double flip_sign(double x) { return __hiloint2double(__double2hiint(x) ^ (int)0x80000000, __double2loint(x)); }
+__device__ __forceinline__ float flip_sign(float x) { return __int_as_float(__float_as_int(x) ^ (int)0x80000000); }
+template <bool TA, bool TB, bool NEG>
+__device__ __forceinline__ v4r mma1(v4r acc, const real* A, const real* B, const Lane& o) {
+  real a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = A[TA ? o.cr[q] : o.rc[q]]; b[q] = B[TB ? o.rc[q] : o.cr[q]]; }
+  // (all eight operand reads in flight before the first MFMA: left alone, the compiler re-uses ONE register pair per operand and
+  //  issues the reads of step q + 1 after the MFMA of step q - four exposed LDS round trips per product)
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = MFMAR(NEG ? flip_sign(a[q]) : a[q], b[q], acc);
+  return acc;
+}
+
 // acc += sum_{k0 <= k < k1} A_k B_k.  la(k, q) / lb(k, q) return this lane's A / B operand of MFMA q of step k (LDS
 // reads).  Two steps per trip: the sixteen operand reads of a pair of steps are requested together and their eight
 // MFMAs run as two accumulator chains (a dependent v_mfma_f64_16x16x4 waits 78 cycles, its predecessor holds the pipe
@@ -1282,6 +1301,100 @@ __global__ void diag_bench_kernel(int variant, int reps, double* out, double see
     for (int c = 0; c < 8; ++c) sum += x[c];
     if (tid == 0) { out[0] = (double)(t1 - t0) / reps; out[1] = sum; }
     if (sum == 12345.678) out[2] = sum;
+    return;
+  }
+  if (kind >= 12 && kind <= 16) {         // the factorisation's worker pattern: tile updates T_c -= T_a T_b^T on LDS tiles
+    __shared__ double Tw[26 * TS];        // (variant & 512: wave 0 runs the serial 16x16 factorisation beside them and wave 4 idles)
+    for (int e = tid; e < 26 * TS; e += blockDim.x) Tw[e] = 1.0 + 1e-6 * e;
+    __syncthreads();
+    const bool chain = (variant & 512) != 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    if (chain && wave == 0) {
+      int bad = 0;
+      for (int rep = 0; rep < reps / 4 + 1; ++rep) {
+        for (int e = lane; e < 256; e += 64) T[e] = T0[e];
+        diag16(ld_tile_sym64(T, o), T, D, lane, 0, bad, o);
+      }
+      if (bad == 12345) out[3] = 1.0;
+    } else if (!(chain && wave == 4)) {
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      if (kind == 12) {
+        for (int rep = 0; rep < reps; ++rep) {
+          double* t = Tw + (wv + 8 * (rep & 1)) * TS;
+          v4r acc = ld_tile(t, o);
+          acc = mma<false, true>(acc, Tw + (16 + (rep + wv) % 5) * TS, Tw + (21 + (rep + 2 * wv) % 5) * TS, o, -1);
+          st_tile(t, o, acc);
+        }
+      } else if (kind == 13) {
+        for (int rep = 0; rep < reps; ++rep) {
+          double* t = Tw + (wv + 8 * (rep & 1)) * TS;
+          v4r acc = ld_tile(t, o);
+          acc = mma1<false, true, true>(acc, Tw + (16 + (rep + wv) % 5) * TS, Tw + (21 + (rep + 2 * wv) % 5) * TS, o);
+          st_tile(t, o, acc);
+        }
+      } else if (kind == 14) {            // two updates per trip: 24 reads in flight, the two accumulator chains alternate
+        for (int rep = 0; rep < reps; rep += 2) {
+          double* t0p = Tw + wv * TS;
+          double* t1p = Tw + (wv + 8) * TS;
+          const double* a0 = Tw + (16 + (rep + wv) % 5) * TS; const double* b0 = Tw + (21 + (rep + 2 * wv) % 5) * TS;
+          const double* a1 = Tw + (16 + (rep + 1 + wv) % 5) * TS; const double* b1 = Tw + (21 + (rep + 1 + 2 * wv) % 5) * TS;
+          v4r c0 = ld_tile(t0p, o), c1 = ld_tile(t1p, o);
+          real x0[4], y0[4], x1[4], y1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { x0[q] = a0[o.rc[q]]; y0[q] = b0[o.rc[q]]; x1[q] = a1[o.rc[q]]; y1[q] = b1[o.rc[q]]; }
+          asm volatile("" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), "+v"(x0[3]), "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]));
+          asm volatile("" : "+v"(x1[0]), "+v"(x1[1]), "+v"(x1[2]), "+v"(x1[3]), "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]), "+v"(y1[3]));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { c0 = MFMAR(flip_sign(x0[q]), y0[q], c0); c1 = MFMAR(flip_sign(x1[q]), y1[q], c1); }
+          st_tile(t0p, o, c0);
+          st_tile(t1p, o, c1);
+        }
+      } else if (kind == 15) {            // one update per trip, the operands of the next one requested before this one's MFMAs
+        double* t = Tw + wv * TS;
+        v4r acc = ld_tile(t, o);
+        real x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q] = Tw[(16 + wv % 5) * TS + o.rc[q]]; y[q] = Tw[(21 + (2 * wv) % 5) * TS + o.rc[q]]; }
+        for (int rep = 0; rep < reps; ++rep) {
+          double* tn = Tw + (wv + 8 * ((rep + 1) & 1)) * TS;
+          const double* an = Tw + (16 + (rep + 1 + wv) % 5) * TS; const double* bn = Tw + (21 + (rep + 1 + 2 * wv) % 5) * TS;
+          v4r accn = ld_tile(tn, o);
+          real xn[4], yn[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xn[q] = an[o.rc[q]]; yn[q] = bn[o.rc[q]]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = MFMAR(flip_sign(x[q]), y[q], acc);
+          __builtin_amdgcn_sched_barrier(0);
+          st_tile(t, o, acc);
+          t = tn; acc = accn;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { x[q] = xn[q]; y[q] = yn[q]; }
+        }
+        if (acc[0] == 12345.678) out[2] = acc[1];
+      } else {                            // 16: two chains per update as shipped, signs flipped in the integer pipe, reads pinned
+        for (int rep = 0; rep < reps; ++rep) {
+          double* t = Tw + (wv + 8 * (rep & 1)) * TS;
+          const double* a0 = Tw + (16 + (rep + wv) % 5) * TS; const double* b0 = Tw + (21 + (rep + 2 * wv) % 5) * TS;
+          v4r acc = ld_tile(t, o);
+          real x[4], y[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { x[q] = a0[o.rc[q]]; y[q] = b0[o.rc[q]]; }
+          asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+          v4r acc2 = {0, 0, 0, 0};
+          acc = MFMAR(flip_sign(x[0]), y[0], acc);
+          acc2 = MFMAR(flip_sign(x[2]), y[2], acc2);
+          acc = MFMAR(flip_sign(x[1]), y[1], acc);
+          acc2 = MFMAR(flip_sign(x[3]), y[3], acc2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+          st_tile(t, o, acc);
+        }
+      }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    __syncthreads();
+    if (tid == 64) { out[0] = (double)(t1 - t0) / reps; out[1] = Tw[5]; }
     return;
   }
   if (kind == 7 || kind == 8) {           // every wave: `reps` tile products of 6 steps each from LDS tiles (the GS pattern)

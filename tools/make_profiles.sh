@@ -69,4 +69,5 @@ timeout -k 10 120 python3 tools/valu64_bench.py > $OUT/${TAG}_valu64_bench.txt 2
 timeout -k 10 200 python3 tools/small_phases.py 86 8 8192 reduced > $OUT/${TAG}_small_phases_reduced.txt 2>&1 || exit 25
 timeout -k 10 300 python3 tools/api_path_c5_profile.py > $OUT/${TAG}_api_path_c5_profile.txt 2>&1 || exit 26
 timeout -k 10 300 python3 tools/scale_check.py > $OUT/${TAG}_scale_check.txt 2>&1 || exit 27
+(timeout -k 10 100 python3 tools/worker_bench.py; python3 tools/flow_model.py) > $OUT/${TAG}_worker_bench.txt 2>&1 || exit 28
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
