@@ -32,7 +32,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src, f32 in [(f, False) for f in SOURCES] + [(f, True) for f in SOURCES_F32]:
         obj = os.path.join(bdir, src + (".f32.o" if f32 else ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + \
-              (["-DBAYENS_F32"] if f32 else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+              (["-DBAYENS_F32"] if f32 else []) + os.environ.get("BAYENS_EXTRA_DEFS", "").split() + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         jobs.append((cmd, obj))
 
     def compile_one(job):

@@ -21,6 +21,7 @@
 //   * the blocked factorisations keep the current block column, the current block row of the inverse and of the factor
 //     in LDS, so a trailing / inverse / Gram update is one coalesced read-modify-write of its output tile.
 // With no LDS limit on the matrices the tile count is a RUN-TIME value (one instantiation for every N).
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 
@@ -51,14 +52,36 @@ __device__ __forceinline__ void unpack_step(int& i, int& j, int step) {      // 
 }
 // accumulator-native tile in the scratch: element (row, col) at nidx(row, col); lane l owns doubles [4l, 4l + 4)
 __device__ __forceinline__ int nidx(int row, int col) { return ((col + 16 * (row & 3)) << 2) + (row >> 2); }
-__device__ __forceinline__ v4d ldn(const double* t, int lane) { return reinterpret_cast<const v4d*>(t)[lane]; }
-__device__ __forceinline__ void stn(double* t, int lane, v4d a) { reinterpret_cast<v4d*>(t)[lane] = a; }
+#ifdef BAYENS_MEDIUM_CHECK
+// Debug build (python -m bayesian_ensembling_amd.build with BAYENS_EXTRA_DEFS=-DBAYENS_MEDIUM_CHECK): every access to the tile
+// scratch is checked against the launching workgroup's OWN region before it is made; an access outside it is counted, its
+// address recorded, and NOT performed (loads return zeros) - an indexing error shows up as a count instead of as a memory fault
+// (or, worse, as a silent read of a neighbour's tiles).  medium_fit prints the result after every launch.
+__device__ unsigned long long g_chk[4];   // [0] scratch base, [1] bytes per workgroup, [2] violations, [3] first offending address
+__device__ __forceinline__ bool chk_ok(const void* p, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)p)) return true;
+#endif
+  const unsigned long long a = (unsigned long long)p + 32ull * lane;
+  const unsigned long long lo = g_chk[0] + (unsigned long long)blockIdx.x * g_chk[1];
+  if (a >= lo && a + 32 <= lo + g_chk[1]) return true;
+  if (atomicAdd(&g_chk[2], 1ull) == 0) g_chk[3] = a;
+  return false;
+}
+#define CHK_LD(p) if (!chk_ok((const void*)(p), lane)) return v4d{0, 0, 0, 0}
+#define CHK_ST(p) if (!chk_ok((const void*)(p), lane)) return
+#else
+#define CHK_LD(p)
+#define CHK_ST(p)
+#endif
+__device__ __forceinline__ v4d ldn(const double* t, int lane) { CHK_LD(t); return reinterpret_cast<const v4d*>(t)[lane]; }
+__device__ __forceinline__ void stn(double* t, int lane, v4d a) { CHK_ST(t); reinterpret_cast<v4d*>(t)[lane] = a; }
 // the same through pointers that carry the GLOBAL address space in their type: a pointer that crosses a real function call
 // is a generic one, its accesses FLAT ones (which also count as LDS operations: every operand read would wait for them)
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) v4d gv4d;
-__device__ __forceinline__ v4d ldg(const gdouble* t, int lane) { return reinterpret_cast<const gv4d*>(t)[lane]; }
-__device__ __forceinline__ void stg(gdouble* t, int lane, v4d a) { reinterpret_cast<gv4d*>(t)[lane] = a; }
+__device__ __forceinline__ v4d ldg(const gdouble* t, int lane) { CHK_LD((const double*)t); return reinterpret_cast<const gv4d*>(t)[lane]; }
+__device__ __forceinline__ void stg(gdouble* t, int lane, v4d a) { CHK_ST((const double*)t); reinterpret_cast<gv4d*>(t)[lane] = a; }
 // LDS tile <- accumulator registers, transposed (element (row, col) of the registers lands at (col, row))
 __device__ __forceinline__ void st_tile_t(double* t, const Lane& o, v4d a) {
 #pragma unroll
@@ -996,8 +1019,24 @@ void medium_fit(hipStream_t stream, const MediumArgs& g_in, int n_cus) {
                                    128 * 1024));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
+#ifdef BAYENS_MEDIUM_CHECK
+  {
+    unsigned long long h[4] = {(unsigned long long)g.scratch, (unsigned long long)g.scratch_stride * sizeof(double), 0ull, 0ull};
+    BAYENS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chk), h, sizeof(h)));
+  }
+#endif
   hipLaunchKernelGGL(medium_fit_kernel, dim3(medium_grid(g.B, g.N, n_cus)), dim3(NTH), lds, stream, g);
   BAYENS_HIP(hipGetLastError());
+#ifdef BAYENS_MEDIUM_CHECK
+  {
+    unsigned long long h[4];
+    BAYENS_HIP(hipStreamSynchronize(stream));
+    BAYENS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chk), sizeof(h)));
+    std::fprintf(stderr, "[bayens medium check] B=%d N=%d grid=%d: %llu scratch accesses outside the workgroup's region%s",
+                 g.B, g.N, medium_grid(g.B, g.N, n_cus), h[2], h[2] ? "" : "\n");
+    if (h[2]) std::fprintf(stderr, ", first at base%+lld bytes (region size %llu)\n", (long long)(h[3] - h[0]), h[1]);
+  }
+#endif
 }
 
 }  // namespace mediumn
