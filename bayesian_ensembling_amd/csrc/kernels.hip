@@ -32,23 +32,56 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;   // valid in lane 0
 }
 
+// exp(x) for x <= 0 and sqrt(d) for d >= 1e-36 as the fused kernels evaluate them (csrc/small.hip: Cody-Waite reduction +
+// degree-13 Taylor polynomial + v_ldexp_f64; v_rsq_f64 seed + two Goldschmidt corrections): the kernel-matrix passes are bound by
+// the fp64 vector rate, and the library's exp / sqrt cost half as much again for range and special-case handling these arguments
+// never need (round 4)
+__device__ __forceinline__ double exp_neg(double x) {
+  x = x < -745.0 ? -745.0 : x;
+  const double n = rint(x * 1.4426950408889634);
+  double t = fma(n, -0.6931471803691238, x);
+  t = fma(n, -1.9082149292705877e-10, t);
+  double p = 1.6059043836821613e-10;
+  p = fma(p, t, 2.08767569878681e-09);
+  p = fma(p, t, 2.505210838544172e-08);
+  p = fma(p, t, 2.755731922398589e-07);
+  p = fma(p, t, 2.7557319223985893e-06);
+  p = fma(p, t, 2.48015873015873e-05);
+  p = fma(p, t, 0.0001984126984126984);
+  p = fma(p, t, 0.001388888888888889);
+  p = fma(p, t, 0.008333333333333333);
+  p = fma(p, t, 0.041666666666666664);
+  p = fma(p, t, 0.16666666666666666);
+  p = fma(p, t, 0.5);
+  p = fma(p, t, 1.0);
+  p = fma(p, t, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+__device__ __forceinline__ double sqrt_pos(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double r = d * y;
+  const double h = 0.5 * y;
+  r = fma(fma(-r, r, d), h, r);
+  r = fma(fma(-r, r, d), h, r);
+  return r;
+}
 // K(r2) and dK/dlengthscale for the three stationary kernels (GPflow 2.1.5 forms; Matern-3/2 is the only
 // one the reference instantiates, models.py:186).
 __device__ __forceinline__ void kern_eval(int kernel, double var, double ls, double r2, double& K, double& dK) {
   if (kernel == 2) {
     double r2c = r2 > 0.0 ? r2 : 0.0;
-    K = var * exp(-0.5 * r2c);
+    K = var * exp_neg(-0.5 * r2c);
     dK = K * r2c / ls;
     return;
   }
   const bool clamp = r2 <= 1e-36;
-  const double r = sqrt(r2 > 1e-36 ? r2 : 1e-36);
+  const double r = sqrt_pos(r2 > 1e-36 ? r2 : 1e-36);
   if (kernel == 0) {
-    double e = exp(-SQRT3 * r);
+    double e = exp_neg(-SQRT3 * r);
     K = var * (1.0 + SQRT3 * r) * e;
     dK = 3.0 * var * r * r * e / ls;
   } else {
-    double e = exp(-SQRT5 * r);
+    double e = exp_neg(-SQRT5 * r);
     K = var * (1.0 + SQRT5 * r + (5.0 / 3.0) * r * r) * e;
     dK = (5.0 / 3.0) * var * r * r * (1.0 + SQRT5 * r) * e / ls;
   }
