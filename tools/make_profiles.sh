@@ -62,6 +62,7 @@ timeout -k 10 300 python3 tools/api_path_c5.py > $OUT/${TAG}_api_path_c5.json 2>
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 31 50 > $OUT/${TAG}_fuzz_seed31.log 2>&1 || exit 20
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 32 50 > $OUT/${TAG}_fuzz_seed32.log 2>&1 || exit 21
 timeout -k 10 400 python3 tests/dev/fuzz_fit.py 47 50 > $OUT/${TAG}_fuzz_seed47.log 2>&1 || exit 22
+for s in 101 202 303 404; do timeout -k 10 400 python3 tests/dev/fuzz_fit.py $s 60 > $OUT/${TAG}_fuzz_seed$s.log 2>&1 || exit 29; done
 # round 4: the fused 256-wide diagonal-block Cholesky by wave, the fp64 VALU rates the small kernel is priced against, the
 # small kernel's reduced export, and the config-5 API path stage by stage
 timeout -k 10 120 python3 tools/potrf256_phases.py > $OUT/${TAG}_potrf256_phases.txt 2>&1 || exit 23
