@@ -10,7 +10,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbayens.so")
+# BAYENS_LIB: a variant build (build.py, e.g. the bounds-checked mid-size kernel) instead of the product library - diagnostics only
+LIB_PATH = os.environ.get("BAYENS_LIB") or os.path.join(HERE, "libbayens.so")
 HEADER = os.path.join(HERE, "..", "include", "bayens.h")            # the drop-in boundary
 DIAG_HEADER = os.path.join(HERE, "..", "include", "bayens_diag.h")  # diagnostics / benchmarks (not part of the boundary)
 

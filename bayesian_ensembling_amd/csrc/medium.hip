@@ -24,6 +24,42 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#ifdef BAYENS_MEDIUM_CHECK
+// Debug build (BAYENS_EXTRA_DEFS=-DBAYENS_MEDIUM_CHECK python -m bayesian_ensembling_amd.build -> libbayens_debug.so, used through
+// BAYENS_LIB): EVERY global access of the kernel - the tile scratch, X / y / nu, every output, the loss trace, the stamps - is
+// checked before it is made against the regions medium_fit registered (the tile scratch against the launching workgroup's OWN
+// region); an access outside them is counted, its address, source line and workgroup recorded, and NOT performed (loads return
+// zeros): an indexing error shows up as a count instead of as a memory fault (or, worse, as a silent read of a neighbour's tiles).
+// medium_fit prints the result after every launch.
+namespace bayens { namespace mediumn {
+constexpr int CHK_REGIONS = 16;
+__device__ unsigned long long g_reg[2 * CHK_REGIONS];   // (base, bytes) of every array handed to the kernel; region 0 = the tile scratch
+__device__ unsigned long long g_chk[8];                 // [1] scratch bytes per workgroup, [2] violations, [3] first address, [4] its line, [5] its workgroup
+__device__ __forceinline__ bool chk_fail(unsigned long long a, int site) {
+  if (atomicAdd(&g_chk[2], 1ull) == 0) { g_chk[3] = a; g_chk[4] = (unsigned long long)site; g_chk[5] = blockIdx.x; }
+  return false;
+}
+__device__ __forceinline__ bool chk_g(const void* p, unsigned bytes, int site) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned long long lo = g_reg[0] + (unsigned long long)blockIdx.x * g_chk[1];
+  if (a >= lo && a + bytes <= lo + g_chk[1]) return true;
+  for (int k = 1; k < CHK_REGIONS; ++k)
+    if (g_reg[2 * k + 1] && a >= g_reg[2 * k] && a + bytes <= g_reg[2 * k] + g_reg[2 * k + 1]) return true;
+  return chk_fail(a, site);
+}
+template <class T> __device__ __forceinline__ T chk_ld(const T* p, int site) { return chk_g(p, sizeof(T), site) ? *p : T(0); }
+template <class T, class V> __device__ __forceinline__ void chk_st(T* p, V v, int site) { if (chk_g(p, sizeof(T), site)) *p = (T)v; }
+}}
+#define GLD(lv) ::bayens::mediumn::chk_ld(&(lv), __LINE__)
+#define GST(lv, v) ::bayens::mediumn::chk_st(&(lv), (v), __LINE__)
+#else
+#define GLD(lv) (lv)
+#define GST(lv, v) ((lv) = (v))
+#endif
 
 #define BAYENS_SMALL_HELPERS_ONLY
 #include "small.hip"
@@ -41,7 +77,14 @@ using namespace smalln;
 // workgroup barrier that also publishes global stores: vector-memory loads AND stores return through vmcnt on gfx9
 #define GSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define LWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define MSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[k] = __builtin_readcyclecounter(); } while (0)
+// (diagnostic build -DBAYENS_MEDIUM_STOPS, g.tune bits 8..: the workgroup ends at phase boundary k of iteration `it_now` when the launch asks for it -
+//  BAYENS_MEDIUM_TUNE = (1 + k + 16 it) << 8 - which is how a device fault is bracketed between two boundaries)
+#ifdef BAYENS_MEDIUM_STOPS
+#define MSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) GST(g.stamps[k], __builtin_readcyclecounter()); \
+                       if ((g.tune >> 8) == 1 + (k) + 16 * it_now) return; } while (0)
+#else
+#define MSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) GST(g.stamps[k], __builtin_readcyclecounter()); } while (0)
+#endif
 
 constexpr int TPW = 9;                 // accumulator tiles a wave holds per pass of a product phase (72 VGPRs)
 constexpr int PASS_TILES = TPW * NW;   // output tiles per pass
@@ -53,23 +96,15 @@ __device__ __forceinline__ void unpack_step(int& i, int& j, int step) {      // 
 // accumulator-native tile in the scratch: element (row, col) at nidx(row, col); lane l owns doubles [4l, 4l + 4)
 __device__ __forceinline__ int nidx(int row, int col) { return ((col + 16 * (row & 3)) << 2) + (row >> 2); }
 #ifdef BAYENS_MEDIUM_CHECK
-// Debug build (python -m bayesian_ensembling_amd.build with BAYENS_EXTRA_DEFS=-DBAYENS_MEDIUM_CHECK): every access to the tile
-// scratch is checked against the launching workgroup's OWN region before it is made; an access outside it is counted, its
-// address recorded, and NOT performed (loads return zeros) - an indexing error shows up as a count instead of as a memory fault
-// (or, worse, as a silent read of a neighbour's tiles).  medium_fit prints the result after every launch.
-__device__ unsigned long long g_chk[4];   // [0] scratch base, [1] bytes per workgroup, [2] violations, [3] first offending address
-__device__ __forceinline__ bool chk_ok(const void* p, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)p)) return true;
-#endif
+// a whole tile access: lane l touches the 32 bytes at t + 32 l of the workgroup's OWN scratch region
+__device__ __forceinline__ bool chk_ok(const void* p, int lane, int site) {
   const unsigned long long a = (unsigned long long)p + 32ull * lane;
-  const unsigned long long lo = g_chk[0] + (unsigned long long)blockIdx.x * g_chk[1];
+  const unsigned long long lo = g_reg[0] + (unsigned long long)blockIdx.x * g_chk[1];
   if (a >= lo && a + 32 <= lo + g_chk[1]) return true;
-  if (atomicAdd(&g_chk[2], 1ull) == 0) g_chk[3] = a;
-  return false;
+  return chk_fail(a, site);
 }
-#define CHK_LD(p) if (!chk_ok((const void*)(p), lane)) return v4d{0, 0, 0, 0}
-#define CHK_ST(p) if (!chk_ok((const void*)(p), lane)) return
+#define CHK_LD(p) if (!chk_ok((const void*)(p), lane, __LINE__)) return v4d{0, 0, 0, 0}
+#define CHK_ST(p) if (!chk_ok((const void*)(p), lane, __LINE__)) return
 #else
 #define CHK_LD(p)
 #define CHK_ST(p)
@@ -340,7 +375,8 @@ __device__ __noinline__ int potrf_v2(PotrfArgs e_in, int bad) {
         };
         const int n_inv_ops = below * (k + 1);
         int q = pos - n_trail;                                                 // position inside the inverse's part of the sequence
-        int j = k + 1 + q / (k + 1), i = q - (j - (k + 1)) * (k + 1);
+        int j = k + 1, i = q;                                                  // (j, i) = (k + 1 + q / (k + 1), q % (k + 1)) without a division: a runtime
+        while (i > k) { i -= k + 1; ++j; }                                     //  divisor costs a float reciprocal and a register that lives across the loop
         int have = 0, hi = 0, hj = 0;
 #pragma unroll 1
         while (q < n_inv_ops) {
@@ -375,7 +411,7 @@ __device__ __forceinline__ void staged_product(const Ctx& c, int n_out, bool squ
       const int p = base + c.wave + s * NW;
       int i = 0, j = 0;
       if (p < n_out) {
-        if (square) { i = p / c.NT; j = p - i * c.NT; }
+        if (square) { j = p; while (j >= c.NT) { j -= c.NT; ++i; } }        // (p / NT, p % NT) without a runtime division
         else unpack_step(i, j, p);
       }
       ti[s] = p < n_out ? i : -1;
@@ -458,13 +494,13 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     int bad = 0;
     // ---- member set-up ----
     for (int t = tid; t < NP; t += NTH) {
-      const double nu = t < N ? g.nu[(long)b * N + t] : 1.0;
-      const double y = t < N ? g.y[(long)b * N + t] : 0.0;
+      const double nu = t < N ? GLD(g.nu[(long)b * N + t]) : 1.0;
+      const double y = t < N ? GLD(g.y[(long)b * N + t]) : 0.0;
       yv[t] = y; dv[t] = 1.0 / nu; rs[t] = 1.0 / sqrt(nu); yd[t] = y / nu;
       th[t] = 0; mv[t] = 0;
       double sq = 0.0;
       if (t < N)
-        for (int d = 0; d < R; ++d) { const double v = X[(long)t * R + d]; sq = fma(v, v, sq); }
+        for (int d = 0; d < R; ++d) { const double v = GLD(X[(long)t * R + d]); sq = fma(v, v, sq); }
       ssq[t] = sq;
     }
     if (tid < 8) misc[tid] = tid < 2 ? 0.5413248546129181 /* softplus^-1(1) */ : 0.0;
@@ -566,21 +602,21 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
           for (int r = 0; r < 4; ++r) {
             double v = acc[r] * lt_[r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (o.lr() == 0) Cb[(size_t)p * 16 + o.kq(r)] = v;
+            if (o.lr() == 0) GST(Cb[(size_t)p * 16 + o.kq(r)], v);
           }
         });
       GSYNC();
       for (int t = tid; t < NP; t += NTH) {
         const int i = t >> 4;
         double f = 0.0;
-        for (int j = 0; j <= i; ++j) f += Cb[(size_t)lt(i, j) * 16 + (t & 15)];
+        for (int j = 0; j <= i; ++j) f += GLD(Cb[(size_t)lt(i, j) * 16 + (t & 15)]);
         wv[t] = f;
       }
       GSYNC();
       double part = 0.0;
       for (int t = tid; t < N; t += NTH) {
         const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
-        const double stt = Sb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)];
+        const double stt = GLD(Sb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
         part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
       }
       part = wave_sum(part);
@@ -589,13 +625,15 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       if (tid == 0) {
         double tot = 0.0;
         for (int w = 0; w < NW; ++w) tot += misc[16 + w];
-        g.loss[(long)b * g.loss_stride + slot] = tot - 0.5 * N + misc[11];
+        GST(g.loss[(long)b * g.loss_stride + slot], tot - 0.5 * N + misc[11]);
       }
       GSYNC();
     };
 
+    [[maybe_unused]] int it_now = 0;
 #pragma unroll 1
     for (int it = 0; it < g.n_iters; ++it) {
+      it_now = it;
       MSTAMP(0);
       refresh_hypers();
       kmat(true);                                                          // K0 + J I at the current hypers  (models.py:209)
@@ -636,7 +674,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
       MSTAMP(4);
       if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
         s = wave_sum(s);
         if (lane == 0) misc[32 + wave] = s;
         GSYNC();
@@ -821,6 +859,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
     }
 
     // ---- prediction at the final hypers with the (m, S) of the last step    (models.py:217-220)
+    it_now = g.n_iters;
     MSTAMP(9);
     refresh_hypers();
     kmat(false);
@@ -928,10 +967,10 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
             if (row < N && col < N) {
               // (a diagonal tile is a full 16x16 accumulation: its lower half is exported and mirrored, so that cov is exactly symmetric)
               if (g.cov && (i != j || col <= row)) {
-                g.cov[((long)b * N + row) * N + col] = a[r];
-                g.cov[((long)b * N + col) * N + row] = a[r];
+                GST(g.cov[((long)b * N + row) * N + col], a[r]);
+                GST(g.cov[((long)b * N + col) * N + row], a[r]);
               }
-              if (g.var && row == col) g.var[(long)b * N + row] = a[r];
+              if (g.var && row == col) GST(g.var[(long)b * N + row], a[r]);
             } else {
               // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
               double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
@@ -944,39 +983,50 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         }
     }
     if (g.mu)
-      for (int t = tid; t < N; t += NTH) g.mu[(long)b * N + t] = av[t];
+      for (int t = tid; t < N; t += NTH) GST(g.mu[(long)b * N + t], av[t]);
     GSYNC();
     MSTAMP(11);
     if (g.chol || g.logdet || g.basis) {
       bad = potrf_v2<false, 0>(pargs(Cb, Cb, Gb), bad);                       // Distribution.__post_init__ (data.py:38-39)
       if (g.chol) {
-        for (int e = tid; e < NT * NT * 256; e += NTH) {
-          const int tt = e >> 8, i = tt / NT, j = tt - i * NT, rr = (e >> 4) & 15, cc = e & 15;
-          const int row = 16 * i + rr, col = 16 * j + cc;
-          if (row < N && col < N) g.chol[((long)b * N + row) * N + col] = col <= row ? Cb[lt(i, j) * TS + nidx(rr, cc)] : 0.0;
+        // every tile (i, j) of the N x N factor, the tiles dealt over the waves: the lower ones are read as they lie in the scratch (one
+        // coalesced 2 KB load), the upper ones are zeros; a wave instruction stores four 128-byte row segments
+        int i = 0, j = wave;
+        while (j >= NT) { j -= NT; ++i; }
+#pragma unroll 1
+        for (int p = wave; p < NT * NT; p += NW) {
+          v4d t = {0, 0, 0, 0};
+          if (j <= i) t = ldn(Cb + (size_t)lt(i, j) * TS, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
+            if (row < N && col < N) GST(g.chol[((long)b * N + row) * N + col], col <= row ? t[r] : 0.0);
+          }
+          j += NW;
+          while (j >= NT) { j -= NT; ++i; }
         }
       }
       if (g.basis) {
         for (int e = tid; e < 2 * N; e += NTH) {
-          const int which = e / N, cc = e - which * N, row = N + which;
-          g.basis[((long)b * 2 + which) * N + cc] = Cb[lt(row >> 4, cc >> 4) * TS + nidx(row & 15, cc & 15)];
+          const int which = e >= N ? 1 : 0, cc = e - which * N, row = N + which;
+          GST(g.basis[((long)b * 2 + which) * N + cc], GLD(Cb[lt(row >> 4, cc >> 4) * TS + nidx(row & 15, cc & 15)]));
         }
       }
       if (g.logdet) {
         double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
+        for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
         s = wave_sum(s);
         if (lane == 0) misc[16 + wave] = s;
         GSYNC();
         if (tid == 0) {
           double tot = 0.0;
           for (int w = 0; w < NW; ++w) tot += misc[16 + w];
-          g.logdet[b] = tot;
+          GST(g.logdet[b], tot);
         }
       }
     }
-    if (tid == 0 && g.hyp) { g.hyp[(long)b * 2] = misc[8]; g.hyp[(long)b * 2 + 1] = misc[9]; }
-    if (wave == 0 && lane == 0) g.info[b] = bad;
+    if (tid == 0 && g.hyp) { GST(g.hyp[(long)b * 2], misc[8]); GST(g.hyp[(long)b * 2 + 1], misc[9]); }
+    if (wave == 0 && lane == 0) GST(g.info[b], bad);
     MSTAMP(12);
     GSYNC();                                                                // LDS and the scratch are re-initialised for the next member
   }
@@ -1019,22 +1069,86 @@ void medium_fit(hipStream_t stream, const MediumArgs& g_in, int n_cus) {
                                    128 * 1024));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
+  // every array the kernel is handed, with its size in bytes (region 0 = the tile scratch, one stride per resident workgroup)
+  const int grid = medium_grid(g.B, g.N, n_cus);
+  const size_t BN = (size_t)g.B * g.N;
+  struct Region { const char* name; const void* base; size_t bytes; };
+  const Region regions[] = {
+    {"scratch", g.scratch, (size_t)grid * g.scratch_stride * sizeof(double)},
+    {"X", g.X, BN * g.R * sizeof(double)}, {"y", g.y, BN * sizeof(double)}, {"nu", g.nu, BN * sizeof(double)},
+    {"mu", g.mu, BN * sizeof(double)}, {"cov", g.cov, BN * g.N * sizeof(double)}, {"var", g.var, BN * sizeof(double)},
+    {"chol", g.chol, BN * g.N * sizeof(double)}, {"logdet", g.logdet, (size_t)g.B * sizeof(double)},
+    {"hyp", g.hyp, (size_t)g.B * 2 * sizeof(double)}, {"basis", g.basis, BN * 2 * sizeof(double)},
+    {"info", g.info, (size_t)g.B * sizeof(int)}, {"loss", g.loss, (size_t)g.B * g.loss_stride * sizeof(double)},
+    {"stamps", g.stamps, 160 * sizeof(unsigned long long)}};
+  constexpr int n_regions = (int)(sizeof(regions) / sizeof(regions[0]));
+  // BAYENS_ALLOC_MAP=1: the map goes to stderr before the launch, so that the address of a device fault can be attributed
+  static const bool alloc_map = std::getenv("BAYENS_ALLOC_MAP") != nullptr;
+  if (alloc_map) {
+    std::fprintf(stderr, "[bayens medium map] B=%d N=%d R=%d T=%d grid=%d lds=%zu scratch_stride=%zu bytes\n", g.B, g.N, g.R, g.n_iters, grid,
+                 lds, (size_t)g.scratch_stride * sizeof(double));
+    for (const Region& r : regions)
+      if (r.base) std::fprintf(stderr, "[bayens medium map]   %-8s %p .. %p (%zu bytes)\n", r.name, r.base, (const void*)((const char*)r.base + r.bytes), r.bytes);
+    std::fflush(stderr);
+  }
 #ifdef BAYENS_MEDIUM_CHECK
   {
-    unsigned long long h[4] = {(unsigned long long)g.scratch, (unsigned long long)g.scratch_stride * sizeof(double), 0ull, 0ull};
+    static_assert(n_regions <= CHK_REGIONS, "region table");
+    unsigned long long hr[2 * CHK_REGIONS] = {};
+    for (int k = 0; k < n_regions; ++k) { hr[2 * k] = (unsigned long long)regions[k].base; hr[2 * k + 1] = regions[k].base ? regions[k].bytes : 0; }
+    unsigned long long h[8] = {0ull, (unsigned long long)g.scratch_stride * sizeof(double), 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    BAYENS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_reg), hr, sizeof(hr)));
     BAYENS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chk), h, sizeof(h)));
   }
 #endif
-  hipLaunchKernelGGL(medium_fit_kernel, dim3(medium_grid(g.B, g.N, n_cus)), dim3(NTH), lds, stream, g);
+  // BAYENS_MEDIUM_GUARD=<MiB> (diagnostic): the launch runs on a private tile scratch with guard bands of that size in front of
+  // and behind it, filled with NaN canaries that carry their own index; after the launch every canary is compared.  A stray
+  // STORE shows up as a modified canary (offset and value printed), a stray LOAD whose value is used as NaNs in the outputs.
+  static const long guard_mib = [] { const char* e = std::getenv("BAYENS_MEDIUM_GUARD"); return e ? std::atol(e) : 0L; }();
+  char* guard_block = nullptr;
+  const size_t guard_bytes = (size_t)(guard_mib > 0 ? guard_mib : 0) << 20, body_bytes = (size_t)grid * g.scratch_stride * sizeof(double);
+  std::vector<unsigned long long> canary;
+  if (guard_bytes) {
+    BAYENS_HIP(hipMalloc((void**)&guard_block, 2 * guard_bytes + body_bytes));
+    canary.resize(guard_bytes / 8);
+    for (size_t i = 0; i < canary.size(); ++i) canary[i] = 0x7ff8dead00000000ull | i;
+    BAYENS_HIP(hipMemcpy(guard_block, canary.data(), guard_bytes, hipMemcpyHostToDevice));
+    BAYENS_HIP(hipMemcpy(guard_block + guard_bytes + body_bytes, canary.data(), guard_bytes, hipMemcpyHostToDevice));
+    BAYENS_HIP(hipMemset(guard_block + guard_bytes, 0, body_bytes));
+    g.scratch = reinterpret_cast<double*>(guard_block + guard_bytes);
+    std::fprintf(stderr, "[bayens medium guard] scratch %p .. %p with %ld MiB of canaries on either side\n", (void*)g.scratch,
+                 (void*)(guard_block + guard_bytes + body_bytes), guard_mib);
+  }
+  hipLaunchKernelGGL(medium_fit_kernel, dim3(grid), dim3(NTH), lds, stream, g);
   BAYENS_HIP(hipGetLastError());
+  if (guard_bytes) {
+    BAYENS_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> back(canary.size());
+    for (int side = 0; side < 2; ++side) {
+      BAYENS_HIP(hipMemcpy(back.data(), guard_block + (side ? guard_bytes + body_bytes : 0), guard_bytes, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < back.size(); ++i)
+        if (back[i] != canary[i]) {
+          if (bad < 24) {
+            double v; std::memcpy(&v, &back[i], 8);
+            const long off = side ? (long)(body_bytes + 8 * i) : (long)(8 * i) - (long)guard_bytes;
+            std::fprintf(stderr, "[bayens medium guard]   scratch base%+ld bytes (tile %+.3f): 0x%016llx = %.17g\n", off, off / 2048.0, back[i], v);
+          }
+          ++bad;
+        }
+      std::fprintf(stderr, "[bayens medium guard] %s guard: %zu of %zu canaries modified\n", side ? "rear" : "front", bad, back.size());
+    }
+    BAYENS_HIP(hipFree(guard_block));
+  }
 #ifdef BAYENS_MEDIUM_CHECK
   {
-    unsigned long long h[4];
+    unsigned long long h[8];
     BAYENS_HIP(hipStreamSynchronize(stream));
     BAYENS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chk), sizeof(h)));
-    std::fprintf(stderr, "[bayens medium check] B=%d N=%d grid=%d: %llu scratch accesses outside the workgroup's region%s",
-                 g.B, g.N, medium_grid(g.B, g.N, n_cus), h[2], h[2] ? "" : "\n");
-    if (h[2]) std::fprintf(stderr, ", first at base%+lld bytes (region size %llu)\n", (long long)(h[3] - h[0]), h[1]);
+    std::fprintf(stderr, "[bayens medium check] B=%d N=%d grid=%d: %llu global accesses outside the registered regions%s",
+                 g.B, g.N, grid, h[2], h[2] ? "" : "\n");
+    if (h[2]) std::fprintf(stderr, ", first at %p = scratch base%+lld bytes (workgroup %llu, medium.hip:%llu; region per workgroup %llu bytes)\n",
+                           (void*)h[3], (long long)(h[3] - (unsigned long long)g.scratch), h[5], h[4], h[1]);
   }
 #endif
 }

@@ -26,6 +26,13 @@
 #include "hip_prims.h"
 #include "small.h"
 
+// global loads / stores of the fused kernels: plain here; the bounds-checked build of the mid-size kernel (medium.hip,
+// BAYENS_MEDIUM_CHECK) routes them through a region check
+#ifndef GLD
+#define GLD(lv) (lv)
+#define GST(lv, v) ((lv) = (v))
+#endif
+
 // Compiled twice, like gemm.hip / kernels.hip: `real` = double (namespace bayens, the reference precision) and, with
 // -DBAYENS_F32, `real` = float (namespace bayens_f32: fp32 tiles and v_mfma_f32_16x16x4_f32 products; the 16x16 diagonal
 // factorisations, the squared distances of the kernel matrix, the vectors and every reduction stay fp64).
@@ -56,32 +63,19 @@ __device__ __forceinline__ real* tiles_base() { return reinterpret_cast<real*>(l
 // column lr.  Step q of a tile product contracts over the index set kq[q] = {4q + lk} (fp64) / {4lk + q} (fp32) - the
 // order of a sum is free - so that in BOTH precisions accumulator register q is element (kq[q], lr): an accumulator
 // tile is a B operand as it stands, and one table of offsets serves operand reads and accumulator stores.
-#ifndef BAYENS_SMALL_HELPERS_ONLY
 struct Lane {
   int rc[4];   // rc[q] = swizzled offset of element (lr, kq(q))
   int cr[4];   // cr[q] = swizzled offset of element (kq(q), lr)   (= accumulator register q of this lane)
   int lane;
   // lr, lk and kq(q) are two or three integer instructions away from the lane id and are NOT kept in registers (round 4): as
   // struct members they were what the register allocator spilled to scratch - and reloaded from memory, a ~500-cycle round
-  // trip, in front of every tile epilogue that needed a row / column index
+  // trip, in front of every tile epilogue that needed a row / column index.
+  // (Rounds 3-4 kept a second, stored-member form of this struct for medium.hip / potrf256.hip because the mid-size kernel
+  //  "faulted with the computed form".  The cause was neither form: DESIGN section 5c, tools/check_exec_prologue.py.)
   __device__ __forceinline__ int lr() const { return lane & 15; }
   __device__ __forceinline__ int lk() const { return lane >> 4; }
   __device__ __forceinline__ int kq(int q) const;
 };
-#else
-// (medium.hip keeps the members stored: its kernel is built from the same helpers, and with the computed form above it FAULTED
-//  on a 20-member batch - a memory access fault in a build whose source differs in nothing but where these integers live - while
-//  single members passed; the stored form is the build that passed every test of rounds 3 and 4.  Until that sensitivity is
-//  understood the mid-size kernel stays on the tested form.)
-struct Lane {
-  int rc[4], cr[4];
-  int kq_[4];
-  int lr_, lk_;
-  __device__ __forceinline__ int lr() const { return lr_; }
-  __device__ __forceinline__ int lk() const { return lk_; }
-  __device__ __forceinline__ int kq(int q) const { return kq_[q]; }
-};
-#endif
 
 #ifdef BAYENS_F32
 #define MFMAR(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
@@ -97,20 +91,12 @@ __device__ __forceinline__ int kq_of(int lk, int q) { return 4 * q + lk; }
 __device__ __forceinline__ int swz(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
 __device__ __forceinline__ int dist_row(int lr) { return lr; }
 #endif
-#ifndef BAYENS_SMALL_HELPERS_ONLY
 __device__ __forceinline__ int Lane::kq(int q) const { return kq_of(lane >> 4, q); }
 __device__ __forceinline__ void lane_init(Lane& o, int lane) {
   o.lane = lane;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { o.rc[q] = swz(o.lr(), o.kq(q)); o.cr[q] = swz(o.kq(q), o.lr()); }
 }
-#else
-__device__ __forceinline__ void lane_init(Lane& o, int lane) {
-  o.lr_ = lane & 15; o.lk_ = lane >> 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { o.kq_[q] = kq_of(o.lk_, q); o.rc[q] = swz(o.lr_, o.kq_[q]); o.cr[q] = swz(o.kq_[q], o.lr_); }
-}
-#endif
 __device__ __forceinline__ int lt(int i, int j) { return ((i * (i + 1)) >> 1) + j; }     // j <= i
 __device__ __forceinline__ void unpack_lower(int p, int& i, int& j) {
   i = 0;
@@ -567,8 +553,8 @@ __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_l
     const int c0 = o.lk(), c1 = 4 + o.lk();
     // (unconditional loads from clamped addresses, zeroed afterwards: a load under a condition is a branch whose value is
     //  awaited at the join - four serial round trips instead of one)
-    const double la0 = (double)xa[c0 < R ? c0 : 0], lb0 = (double)xb[c0 < R ? c0 : 0];
-    const double la1 = (double)xa[c1 < R ? c1 : 0], lb1 = (double)xb[c1 < R ? c1 : 0];
+    const double la0 = (double)GLD(xa[c0 < R ? c0 : 0]), lb0 = (double)GLD(xb[c0 < R ? c0 : 0]);
+    const double la1 = (double)GLD(xa[c1 < R ? c1 : 0]), lb1 = (double)GLD(xb[c1 < R ? c1 : 0]);
     const double a0 = (ra < N && c0 < R) ? la0 : 0.0, b0 = (rb < N && c0 < R) ? lb0 : 0.0;
     const double a1 = (ra < N && c1 < R) ? la1 : 0.0, b1 = (rb < N && c1 < R) ? lb1 : 0.0;
     acc = MFMA(a0, b0, acc);
@@ -577,7 +563,7 @@ __device__ __forceinline__ v4d r2_tile(const real* X, int N, int R, double inv_l
 #pragma unroll 2
     for (int k0 = 0; k0 < R; k0 += 4) {
       const int c = k0 + o.lk();
-      const double la = (double)xa[c < R ? c : 0], lb = (double)xb[c < R ? c : 0];
+      const double la = (double)GLD(xa[c < R ? c : 0]), lb = (double)GLD(xb[c < R ? c : 0]);
       const double a = (ra < N && c < R) ? la : 0.0;
       const double b = (rb < N && c < R) ? lb : 0.0;
       acc = MFMA(a, b, acc);

@@ -69,3 +69,27 @@ def test_nothing_but_the_gemms_own_dma_setup_touches_m0():
     assert mod.main() == 0
     bad, _ = mod.check("s_mov_b32 m0, s4\ns_nop 0\nglobal_load_lds_dwordx4 v[0:1], off\nv_readlane_b32 s5, v1, m0\n")
     assert bad and "outside lds_dma16" in bad[0]
+
+
+def test_no_kernel_of_the_build_carries_a_vector_instruction_ahead_of_its_blocks_exec_restore():
+    """tools/check_exec_prologue.py: every translation unit of the product compiled to gfx950 assembly (both precisions, no GPU
+    needed) and scanned for the code-generation defect behind round 4's device fault - and the scanner itself
+    on the block that faulted, reduced to its skeleton, and on the two legitimate shapes it must not flag."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_exec_prologue", os.path.join(root, "tools", "check_exec_prologue.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main([]) == 0
+    faulting = ("_Zkernel:\n\ts_and_saveexec_b64 s[0:1], vcc\n\ts_cbranch_execz .LBB4_39\n.LBB4_38:\n\tds_write_b64 v0, v[200:201]\n"
+                "\ts_andn2_b64 exec, exec, s[2:3]\n\ts_cbranch_execnz .LBB4_38\n.LBB4_39:\n\ts_mov_b32 s80, 0xfee00000\n"
+                "\tv_mov_b32_e32 v190, v209\n\ts_mov_b32 s81, 0xbfe62e42\n\ts_or_b64 exec, exec, s[0:1]\n\ts_swappc_b64 s[30:31], s[0:1]\n")
+    hits = mod.scan(faulting)
+    assert hits and all("v190, v209" in h[3] for h in hits)
+    clean = faulting.replace("\tv_mov_b32_e32 v190, v209\n\ts_mov_b32 s81, 0xbfe62e42\n\ts_or_b64 exec, exec, s[0:1]\n",
+                             "\ts_mov_b32 s81, 0xbfe62e42\n\ts_or_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v190, v209\n")
+    assert mod.scan(clean) == []
+    if_else = ("_Zkernel:\n\ts_and_saveexec_b64 s[0:1], vcc\n\ts_xor_b64 s[0:1], exec, s[0:1]\n\ts_cbranch_execz .LBB1_130\n"
+               "\tv_lshlrev_b32_e32 v3, 4, v162\n.LBB1_130:\n\ts_andn2_saveexec_b64 s[0:1], s[0:1]\n\tv_xad_u32 v3, v162, v137, v161\n"
+               "\ts_or_b64 exec, exec, s[0:1]\n")
+    assert mod.scan(if_else) == []

@@ -64,6 +64,32 @@ def test_medium_kernel_reproduces_the_references_pickled_n165_posterior(mctx, fn
     assert relerr(out["hyp"][0], g["hyp"]) < 1e-5
 
 
+def test_the_papers_collection_shape_every_member_against_the_oracle(mctx):
+    """20 members x N = 165 x R = 9 (pre_fitting_cmip6models.py:76-77: one collection of the paper) in ONE batch, every member and
+    every output - the log-likelihood basis included - against the oracle.  This is the shape on which a build of round 4 faulted:
+    the compiler had parked a register across the call of the factorisation with EXEC = 0 (DESIGN section 5c;
+    tools/check_exec_prologue.py keeps that out of the build), `e / N` of the basis export came out as garbage and the kernel read
+    below its scratch - with 20 members the scratch is a mapping of its own and the read faults, with 1-2 members it only
+    returned a wrong basis, which the diagnostic of that round did not look at."""
+    import scipy.linalg as sla
+    M, N, R, T = 20, 165, 9, 2
+    data, _ = go.synthetic_ensemble(M, N, R=R, seed=N + R)
+    X, y, nu = member_inputs(data)
+    out = mctx.gp_fit_batch(X, y, nu, T)
+    assert not out["info"].any()
+    with threadpool_limits(4):
+        for m in range(M):
+            mo, co, ho = go.gp_fit(X[m], y[m], nu[m], T)[:3]
+            Lc, ld = go.mvn_factor(co)
+            assert relerr(out["mu"][m], mo) < 1e-10 and relerr(out["cov"][m], co) < 1e-10, m
+            assert relerr(out["chol"][m], Lc) < 1e-10 and relerr(out["hyp"][m], ho) < 1e-10, m
+            assert abs(out["logdet"][m] - ld) < 1e-9 * max(1.0, abs(ld)), m
+            assert relerr(out["basis"][m, 0], sla.solve_triangular(Lc, np.ones(N), lower=True)) < 1e-9, m
+            assert relerr(out["basis"][m, 1], sla.solve_triangular(Lc, mo, lower=True)) < 1e-9, m
+    red = mctx.gp_fit_batch_reduced(X, y, nu, T)                       # the reduced export of the same batch (per-gridpoint fields)
+    assert np.array_equal(red["mu"], out["mu"]) and np.array_equal(red["basis"], out["basis"]) and np.array_equal(red["hyp"], out["hyp"])
+
+
 def test_medium_and_general_paths_agree_and_large_batches_take_the_fused_kernel(ctx):
     """A batch of 130 members of N = 120: the default dispatch (fused kernel) against the general path (forced), member by
     member; members at the edges of the grid of workgroups against the oracle.  And N = 200 (13 tiles per side): general
