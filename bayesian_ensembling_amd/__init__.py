@@ -7,7 +7,7 @@ from .data import Distribution, ModelCollection, ProcessModel
 from .dtwa import performDBA
 from .ensemble_scheme import AbstractEnsembleScheme, Barycentre, MultiModelMean, WeightedModelMean
 from .labelled import DataArray, concat
-from .models import GPDTW1D, MeanFieldApproximation
+from .models import GPDTW1D, MeanFieldApproximation, fit_collections
 from .nc4 import open_dataarray
 from .weights import (AbstractWeight, CRPSWeight, InverseSquareWeight, KSDWeight, LogLikelihoodWeight,
                       ModelSimilarityWeight, UniformWeight)

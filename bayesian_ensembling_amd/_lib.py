@@ -74,6 +74,8 @@ def load():
     lib.bayens_gp_fit_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
+    lib.bayens_gp_fit_batch_ragged.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                               C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_gp_fit_batch_reduced.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                                 C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_transpose_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -369,6 +371,57 @@ class Context:
             raise err
         return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis,
                 "loss": loss}
+
+    @staticmethod
+    def ragged_layout(Xs):
+        """Members with different realisation counts -> (R [B] int32, x_off [B] uint64, X: the members' (N, R_b) blocks one behind
+        the other) - the layout bayens_gp_fit_batch_ragged takes."""
+        Xs = [np.ascontiguousarray(x, dtype=np.float64) for x in Xs]
+        N = Xs[0].shape[0]
+        if any(x.ndim != 2 or x.shape[0] != N for x in Xs):
+            raise ValueError("every member must be an (N, R_b) array with the same N")
+        R = np.array([x.shape[1] for x in Xs], dtype=np.int32)
+        off = np.zeros(len(Xs), dtype=np.uint64)
+        off[1:] = np.cumsum(N * R.astype(np.uint64))[:-1]
+        return R, off, np.concatenate([x.ravel() for x in Xs])
+
+    def gp_fit_batch_ragged(self, Xs, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6,
+                            want_chol=True, want_loss=False):
+        """Xs: a list of (N, R_b) arrays - members of equal N whose realisation counts differ - fitted in ONE launch
+        (bayens_gp_fit_batch_ragged; ensembles/data.py:385-395 fits them one after the other)."""
+        R, off, X = self.ragged_layout(Xs)
+        B, N = len(Xs), Xs[0].shape[0]
+        y_mean, y_var = _f64(y_mean).reshape(B, N), _f64(y_var).reshape(B, N)
+        mu, cov = np.empty((B, N)), np.empty((B, N, N))
+        chol = np.empty((B, N, N)) if want_chol else None
+        logdet = np.empty(B) if want_chol else None
+        hyp = np.empty((B, 2))
+        basis = np.empty((B, 2, N)) if want_chol else None
+        info = np.zeros(B, dtype=np.int32)
+        loss = np.empty((B, (int(n_iters) + 24) // 25)) if want_loss and n_iters > 0 else None
+        rc = self.lib.bayens_gp_fit_batch_ragged(self.h, HOST, B, N, _ptr(R), _ptr(off), _ptr(X), _ptr(y_mean), _ptr(y_var),
+                                                 int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
+                                                 _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
+        return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis, "loss": loss}
+
+    def gp_fit_batch_ragged_dev(self, B, N, R, x_off, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
+                                kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, loss=None):
+        """Device-resident buffers (X: the concatenated blocks); R / x_off are HOST arrays (int32 / uint64, see ragged_layout)."""
+        R = np.ascontiguousarray(R, dtype=np.int32)
+        x_off = np.ascontiguousarray(x_off, dtype=np.uint64)
+        info = np.zeros(B, dtype=np.int32)
+        rc = self.lib.bayens_gp_fit_batch_ragged(self.h, DEVICE, B, N, _ptr(R), _ptr(x_off), _ptr(X), _ptr(y_mean), _ptr(y_var),
+                                                 int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
+                                                 _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
+        if rc != 0:
+            err = BayensError(rc, self.lib.bayens_last_error(self.h).decode())
+            err.info = info
+            raise err
+        return info
 
     def gp_fit_batch_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
                          kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, f32=False, loss=None):

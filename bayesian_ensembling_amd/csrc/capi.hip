@@ -188,7 +188,8 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
         FitWorkspace w = ws_view(c, b0, b1 - b0);
         FitParams fg = fp;
         if (fg.loss_trace) fg.loss_trace += (size_t)b0 * fg.loss_stride;
-        gp_fit(*c->gprims[g], w, fg, dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
+        if (fg.Rv) { fg.Rv += b0; fg.xoff += b0; }          // (a ragged batch: the offsets are absolute, X's base stays)
+        gp_fit(*c->gprims[g], w, fg, fg.Rv ? dX : dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
                dmu + (size_t)b0 * N, dcov + (size_t)b0 * N * N, dchol ? dchol + (size_t)b0 * N * N : nullptr,
                dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr,
                dbasis ? dbasis + (size_t)b0 * 2 * N : nullptr);
@@ -486,6 +487,101 @@ int bayens_set_fit_route(bayens_ctx* c, int route) {
   return 0;
 }
 
+}  // extern "C"
+
+namespace {
+// bayens_gp_fit_batch / bayens_gp_fit_batch_ragged.  Rv / x_off (HOST arrays, null: every member has R realisations): member b
+// has Rv[b] <= R realisations, its [N][Rv[b]] block starts x_off[b] doubles into X, which holds x_total doubles in all.
+int fit_batch_impl(bayens_ctx* c, const char* who, int loc, int B, int N, int R, const int* Rv, const size_t* x_off, size_t x_total,
+                   const double* X, const double* y_mean, const double* y_var, int kernel, int n_iters, double gamma, double lr,
+                   double jitter, double* mu, double* cov, double* cov_chol, double* logdet, double* hyp, double* loss_trace,
+                   int* info, double* ll_basis) {
+  const std::string tag = std::string(who) + ": ";
+  // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
+  static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
+  const bool small = !no_small && c->fit_route == 0 && smalln::small_fit_supported(N, R);
+  // mid-size members (94 < N <= 254, the reference's N = 165 series): ONE kernel too, matrices in an L2-resident scratch
+  // (medium.hip; BAYENS_NO_MEDIUM=1 forces the general path)
+  // Measured (profiles/r03_medium_kernel.txt, us per optimiser iteration): the fused kernel is flat in the batch - one CU per
+  // member: 124 at N = 100, 322 at N = 165, 858 at N = 250 up to 256 members - where the general path, which shares every
+  // launch between the members, goes 228 / 357 / 488 at 20 members and 717 at (N = 165, 256 members).  So: up to 12 tiles
+  // per side (N <= 190) the fused kernel always; above that from 128 members on (bayens_set_medium_min_batch overrides).
+  static const bool no_medium = getenv("BAYENS_NO_MEDIUM") != nullptr;
+  const int medium_from = c->medium_min_batch > 0 ? c->medium_min_batch : ((N + 2 + 15) / 16 <= 12 ? 1 : 128);
+  const bool medium = !small && !no_medium && c->fit_route == 0 && B >= medium_from && mediumn::medium_fit_supported(N, R);
+  const int Np = pad_to_leaf(N);
+  if (!small && !medium) ensure_ws(c, B, Np);
+  Stage st(c, loc);
+  const double* dX = st.in(X, x_total);
+  const double* dy = st.in(y_mean, (size_t)B * N);
+  const double* dnu = st.in(y_var, (size_t)B * N);
+  double* dmu = st.out(mu, (size_t)B * N);
+  double* dcov = st.out(cov, (size_t)B * N * N);
+  double* dchol = st.out(cov_chol, (size_t)B * N * N);
+  double* dld = st.out(logdet, (size_t)B);
+  double* dhyp = st.out(hyp, (size_t)B * 2);
+  double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
+  // the ragged layout goes to the device as two small arrays (they are host arrays whatever `loc` says)
+  const int* dRv = nullptr;
+  const long* dxoff = nullptr;
+  std::vector<long> hoff;
+  if (Rv) {
+    int* r = st.scratch<int>((size_t)B);
+    long* o = st.scratch<long>((size_t)B);
+    hoff.resize(B);
+    for (int b = 0; b < B; ++b) hoff[b] = (long)x_off[b];
+    BAYENS_HIP(hipMemcpyAsync(r, Rv, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipMemcpyAsync(o, hoff.data(), (size_t)B * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    dRv = r;
+    dxoff = o;
+  }
+  auto report = [&](const int* dinfo) {
+    std::vector<int> hinfo(B, 0);
+    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, tag + "matrix not positive definite (see info[])");
+    return 0;
+  };
+  const int loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+  if (small) {
+    int* dinfo = st.scratch<int>((size_t)B);
+    smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo};
+    a.stamps = c->small_stamps;
+    a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
+    a.loss_stride = loss_stride;
+    a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
+    a.Rv = dRv;
+    a.xoff = dxoff;
+    smalln::small_fit(c->stream, a, c->n_cus);
+    return report(dinfo);
+  }
+  if (medium) {
+    int* dinfo = st.scratch<int>((size_t)B);
+    mediumn::MediumArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo,
+                          c->medium_scratch((size_t)mediumn::medium_grid(B, N, c->n_cus) * mediumn::medium_scratch_doubles(N))};
+    a.stamps = c->small_stamps;
+    a.loss_stride = loss_stride;
+    a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
+    a.Rv = dRv;
+    a.xoff = dxoff;
+    a.x_elems = (long)x_total;
+    mediumn::medium_fit(c->stream, a, c->n_cus);
+    return report(dinfo);
+  }
+  FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+  fp.loss_stride = loss_stride;
+  fp.loss_trace = fp.loss_stride > 0 ? st.out(loss_trace, (size_t)B * fp.loss_stride) : nullptr;
+  fp.Rv = dRv;
+  fp.xoff = dxoff;
+  fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
+  return report(c->dws.ws.info);
+}
+}  // namespace
+
+extern "C" {
+
 int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const double* X, const double* y_mean,
                         const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
                         double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
@@ -494,73 +590,30 @@ int bayens_gp_fit_batch(bayens_ctx* c, int loc, int B, int N, int R, const doubl
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch: unknown kernel id");
-    // small members (N <= 94): the whole fit is ONE kernel, one workgroup per member, matrices resident in LDS (small.hip)
-    static const bool no_small = getenv("BAYENS_NO_SMALL") != nullptr;
-    const bool small = !no_small && c->fit_route == 0 && smalln::small_fit_supported(N, R);
-    // mid-size members (94 < N <= 254, the reference's N = 165 series): ONE kernel too, matrices in an L2-resident scratch
-    // (medium.hip; BAYENS_NO_MEDIUM=1 forces the general path)
-    // Measured (profiles/r03_medium_kernel.txt, us per optimiser iteration): the fused kernel is flat in the batch - one CU per
-    // member: 124 at N = 100, 322 at N = 165, 858 at N = 250 up to 256 members - where the general path, which shares every
-    // launch between the members, goes 228 / 357 / 488 at 20 members and 717 at (N = 165, 256 members).  So: up to 12 tiles
-    // per side (N <= 190) the fused kernel always; above that from 128 members on (bayens_set_medium_min_batch overrides).
-    static const bool no_medium = getenv("BAYENS_NO_MEDIUM") != nullptr;
-    const int medium_from = c->medium_min_batch > 0 ? c->medium_min_batch : ((N + 2 + 15) / 16 <= 12 ? 1 : 128);
-    const bool medium = !small && !no_medium && c->fit_route == 0 && B >= medium_from && mediumn::medium_fit_supported(N, R);
-    const int Np = pad_to_leaf(N);
-    if (!small && !medium) ensure_ws(c, B, Np);
-    Stage st(c, loc);
-    const double* dX = st.in(X, (size_t)B * N * R);
-    const double* dy = st.in(y_mean, (size_t)B * N);
-    const double* dnu = st.in(y_var, (size_t)B * N);
-    double* dmu = st.out(mu, (size_t)B * N);
-    double* dcov = st.out(cov, (size_t)B * N * N);
-    double* dchol = st.out(cov_chol, (size_t)B * N * N);
-    double* dld = st.out(logdet, (size_t)B);
-    double* dhyp = st.out(hyp, (size_t)B * 2);
-    double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
-    if (small) {
-      int* dinfo = st.scratch<int>((size_t)B);
-      smalln::SmallArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo};
-      a.stamps = c->small_stamps;
-      a.kpark = c->small_park(smalln::small_park_doubles(B, N, c->n_cus));
-      a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
-      a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
-      smalln::small_fit(c->stream, a, c->n_cus);
-      std::vector<int> hinfo(B, 0);
-      BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      st.finish();
-      int bad = 0;
-      for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
-      if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
-      return 0;
+    return fit_batch_impl(c, "gp_fit_batch", loc, B, N, R, nullptr, nullptr, (size_t)B * N * R, X, y_mean, y_var, kernel, n_iters,
+                          gamma, lr, jitter, mu, cov, cov_chol, logdet, hyp, loss_trace, info, ll_basis);
+  });
+}
+
+int bayens_gp_fit_batch_ragged(bayens_ctx* c, int loc, int B, int N, const int* R, const size_t* x_off, const double* X,
+                               const double* y_mean, const double* y_var, int kernel, int n_iters, double gamma, double lr,
+                               double jitter, double* mu, double* cov, double* cov_chol, double* logdet, double* hyp,
+                               double* loss_trace, int* info, double* ll_basis) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || !R || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged: unknown kernel id");
+    int Rmax = 0;
+    std::vector<size_t> off(B);
+    size_t total = 0;
+    for (int b = 0; b < B; ++b) {
+      if (R[b] <= 0) return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged: every member needs at least one realisation");
+      Rmax = std::max(Rmax, R[b]);
+      off[b] = x_off ? x_off[b] : total;                 // null: the members' blocks lie one behind the other
+      total = std::max(total, off[b] + (size_t)N * R[b]);
     }
-    if (medium) {
-      int* dinfo = st.scratch<int>((size_t)B);
-      mediumn::MediumArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, dcov, nullptr, dchol, dld, dhyp, dbasis, dinfo,
-                            c->medium_scratch((size_t)mediumn::medium_grid(B, N, c->n_cus) * mediumn::medium_scratch_doubles(N))};
-      a.stamps = c->small_stamps;
-      a.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
-      a.loss = (loss_trace && a.loss_stride > 0) ? st.out(loss_trace, (size_t)B * a.loss_stride) : nullptr;
-      mediumn::medium_fit(c->stream, a, c->n_cus);
-      std::vector<int> hinfo(B, 0);
-      BAYENS_HIP(hipMemcpyAsync(hinfo.data(), dinfo, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      st.finish();
-      int bad = 0;
-      for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
-      if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
-      return 0;
-    }
-    FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
-    fp.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
-    fp.loss_trace = fp.loss_stride > 0 ? st.out(loss_trace, (size_t)B * fp.loss_stride) : nullptr;
-    fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
-    std::vector<int> hinfo(B, 0);
-    BAYENS_HIP(hipMemcpyAsync(hinfo.data(), c->dws.ws.info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    st.finish();
-    int bad = 0;
-    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
-    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch: matrix not positive definite (see info[])");
-    return 0;
+    return fit_batch_impl(c, "gp_fit_batch_ragged", loc, B, N, Rmax, R, off.data(), total, X, y_mean, y_var, kernel, n_iters, gamma,
+                          lr, jitter, mu, cov, cov_chol, logdet, hyp, loss_trace, info, ll_basis);
   });
 }
 

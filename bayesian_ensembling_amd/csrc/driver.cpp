@@ -231,8 +231,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     P.mark("kmat");
     // (the blocks above the block diagonal of Lb are cleared by the first call of the fit and stay clear; woodbury: the same
     //  pass leaves diag(nu) + gamma (K0 + J I) in Cb)
-    if (woodbury) P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0, ws.Cb, fp.gamma, ws.nu);
-    else P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0);
+    if (woodbury) P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0, ws.Cb, fp.gamma, ws.nu, fp.Rv, fp.xoff);
+    else P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, it == 0, Mat{nullptr, 0, 0}, 0.0, nullptr, fp.Rv, fp.xoff);
     P.mark("potrf K");
     // woodbury: K0 + J I and diag(nu) + gamma (K0 + J I) factor as ONE batch of 2 nb members (Lb and Cb are interleaved member by
     // member, FitWorkspace::paired): the factorisation is bound by its chain of small kernels, not by its flop, and the
@@ -310,7 +310,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
-  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, fp.n_iters == 0);
+  P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, fp.n_iters == 0, Mat{nullptr, 0, 0}, 0.0, nullptr, fp.Rv, fp.xoff);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
   if (fp.loss_trace && fp.n_iters > 0 && (fp.n_iters - 1) % LOSS_EVERY == 0)
     neg_elbo(P, ws, fp, (fp.n_iters - 1) / LOSS_EVERY);

@@ -63,6 +63,10 @@ struct FitParams {
   // optional: -ELBO after the iterations it = 0, 25, 50, ... (models.py:211-215), device [nb][loss_stride]
   double* loss_trace = nullptr;
   int loss_stride = 0;
+  // a ragged batch (device arrays [nb], null: uniform): member b has Rv[b] <= R realisations and its [N][Rv[b]] block starts
+  // xoff[b] elements into X (ensembles/data.py:385-395 fits members of different realisation counts one after the other)
+  const int* Rv = nullptr;
+  const long* xoff = nullptr;
 };
 constexpr int LOSS_EVERY = 25;   // models.py:211
 

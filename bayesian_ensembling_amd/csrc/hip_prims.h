@@ -97,7 +97,7 @@ struct HipPrims : Prims {
                   const real* y_in, const real* nu_in, real* y_pad, real* nu_pad, int* info, bool lam_identity = true) override;
   void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
             Mat Lb, bool clear_upper = true, Mat Mb = Mat{nullptr, 0, 0}, double m_scale = 0.0,
-            const real* m_diag = nullptr) override;
+            const real* m_diag = nullptr, const int* Rv = nullptr, const long* xoff = nullptr) override;
   void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) override;
   void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                real* out) override;

@@ -393,11 +393,15 @@ __global__ void extract_diag_kernel(int N, const double* cov, double* var) {
 // kernel matrix (GPflow Matern32.K as used at models.py:186-189,198,217): r2 = -2 X~X~^T + s_i + s_j with
 // the X~X~^T contraction on the fp64 matrix cores; the epilogue (sqrt/exp) runs on the 4 results per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ void xprep_kernel(int N, int Np, int R, int R4, const real* X, const double* ustate,
-                             double* xs, double* ssq) {
+__global__ void xprep_kernel(int N, int Np, int R_all, int R4, const real* X_all, const double* ustate,
+                             double* xs, double* ssq, const int* Rv, const long* xoff) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Np) return;
+  // a ragged batch (Rv): this member's own realisation count and block of X; the columns up to R4 are zeros either way, which
+  // add nothing to a squared distance - the kernel matrix is bit for bit that of a uniform batch of Rv[b] realisations
+  const int R = Rv ? Rv[b] : R_all;
+  const real* X = X_all + (xoff ? xoff[b] : (long)b * N * R_all) - (long)b * N * R;
   const double ls = softplus_d(ustate[b * 8 + 1]);
   if (i == 0) {   // (variance, lengthscale) of this member behind the squared norms: the tile kernels read them instead of
     double* vl = ssq + (long)gridDim.y * Np + 2 * b;   // evaluating softplus in every thread of every workgroup
@@ -1689,10 +1693,10 @@ void HipPrims::init_state(int nb, int N, int Np, Mat Lam, real* theta1, real* mv
   LAUNCH_CHECK();
 }
 void HipPrims::kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel, double jitter,
-                    Mat Lb, bool clear_upper, Mat Mb, double m_scale, const real* m_diag) {
+                    Mat Lb, bool clear_upper, Mat Mb, double m_scale, const real* m_diag, const int* Rv, const long* xoff) {
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
-  hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq);
+  hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq, Rv, xoff);
   hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
                      kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0, clear_upper ? 1 : 0, Mb,
                      m_scale, m_diag);

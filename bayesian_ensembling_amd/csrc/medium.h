@@ -32,6 +32,11 @@ struct MediumArgs {
   int NT = 0;               // filled in by medium_fit
   long scratch_stride = 0;  // filled in by medium_fit
   int tune = 0;             // measurement switches (BAYENS_MEDIUM_TUNE), filled in by medium_fit
+  // members whose realisation counts differ (ensembles/data.py:385-395 fits them one after the other): Rv[b] realisations of
+  // member b, whose [N][Rv[b]] block starts xoff[b] elements into X.  Null: every member has R realisations, X is [B][N][R].
+  const int* Rv = nullptr;
+  const long* xoff = nullptr;
+  long x_elems = 0;         // elements of X in all (0: B N R) - only the diagnostics read it
 };
 
 bool medium_fit_supported(int N, int R);

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
   c.NT = NT; c.NTT = NTT; c.wave = wave; c.lane = lane; c.tid = tid; c.SA = SA;
   lane_init(c.o, lane);
   const Lane& o = c.o;
-  const int N = g.N, R = g.R;
+  const int N = g.N;
   const double J = g.jitter;
 
   auto pargs = [&](double* A_, double* X_, double* G_) {
@@ -490,7 +490,8 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
 
 #pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
-    const double* X = g.X + (long)b * N * R;
+    const int R = g.Rv ? g.Rv[b] : g.R;                                   // (a ragged batch: this member's own realisation count)
+    const double* X = g.X + (g.xoff ? g.xoff[b] : (long)b * N * g.R);
     int bad = 0;
     // ---- member set-up ----
     for (int t = tid; t < NP; t += NTH) {
@@ -1075,7 +1076,7 @@ void medium_fit(hipStream_t stream, const MediumArgs& g_in, int n_cus) {
   struct Region { const char* name; const void* base; size_t bytes; };
   const Region regions[] = {
     {"scratch", g.scratch, (size_t)grid * g.scratch_stride * sizeof(double)},
-    {"X", g.X, BN * g.R * sizeof(double)}, {"y", g.y, BN * sizeof(double)}, {"nu", g.nu, BN * sizeof(double)},
+    {"X", g.X, (g.x_elems ? (size_t)g.x_elems : BN * g.R) * sizeof(double)}, {"y", g.y, BN * sizeof(double)}, {"nu", g.nu, BN * sizeof(double)},
     {"mu", g.mu, BN * sizeof(double)}, {"cov", g.cov, BN * g.N * sizeof(double)}, {"var", g.var, BN * sizeof(double)},
     {"chol", g.chol, BN * g.N * sizeof(double)}, {"logdet", g.logdet, (size_t)g.B * sizeof(double)},
     {"hyp", g.hyp, (size_t)g.B * 2 * sizeof(double)}, {"basis", g.basis, BN * 2 * sizeof(double)},

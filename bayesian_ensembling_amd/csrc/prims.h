@@ -104,9 +104,10 @@ struct Prims {
   // K0 = L L^T - jitter*I (driver.cpp) and the hyper-gradient re-evaluates the kernel (grad_adam).
   // clear_upper = false: the 64x64 blocks above the block diagonal are not written (they hold zeros from an earlier call).
   // With Mb: also Mb = tril(m_scale (K0 + jitter*I) + diag(m_diag)) on the blocks on and below the block diagonal.
+  // Rv / xoff (device, [nb]; null: uniform): member b has Rv[b] <= R realisations, its [N][Rv[b]] block starts xoff[b] elements into X.
   virtual void kmat(int nb, int N, int Np, int R, const real* X, const double* ustate, int kernel,
                     double jitter, Mat Lb, bool clear_upper = true, Mat Mb = Mat{nullptr, 0, 0}, double m_scale = 0.0,
-                    const real* m_diag = nullptr) = 0;
+                    const real* m_diag = nullptr, const int* Rv = nullptr, const long* xoff = nullptr) = 0;
 
   virtual void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) = 0;  // dst_ij = src_ij/sqrt(nu_i)
   // out = beta * out + alpha * L^T (v / nu)   (L lower triangular)

@@ -32,6 +32,10 @@ struct SmallArgs {
   // per-workgroup park of the unit-variance kernel values (k1, k2) of an iteration's kernel matrix, so that its hyper-gradient
   // does not evaluate sqrt / exp a second time: small_park_doubles() doubles, device memory (L2-resident: 86 KB per workgroup)
   double* kpark = nullptr;
+  // members whose realisation counts differ (ensembles/data.py:385-395 fits them one after the other): Rv[b] realisations of
+  // member b, whose [N][Rv[b]] block starts xoff[b] elements into X.  Null: every member has R realisations, X is [B][N][R].
+  const int* Rv = nullptr;
+  const long* xoff = nullptr;
 };
 
 // size of SmallArgs::kpark for a batch of B members of N time points on a device with n_cus compute units

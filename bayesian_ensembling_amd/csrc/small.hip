@@ -619,13 +619,14 @@ __global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // t
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   Lane o;
   lane_init(o, lane);
-  const int N = g.N, R = g.R;
+  const int N = g.N;
   const double J = g.jitter;
   const bool w4idle = !(g.tune & 1);
 
 #pragma unroll 1
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
-    const real* X = g.X + (long)b * N * R;
+    const int R = g.Rv ? g.Rv[b] : g.R;                                   // (a ragged batch: this member's own realisation count)
+    const real* X = g.X + (g.xoff ? g.xoff[b] : (long)b * N * g.R);
     int bad = 0;
     // ---- member set-up ----
     for (int t = tid; t < NP; t += NTH) {

@@ -160,7 +160,10 @@ class GPDTW1D:
 
     def fit_collection(self, process_models, n_optim_nits: int = 500, compile_objective: bool = False,
                        progress_bar: bool = True):
-        """All members at once: one bayens_gp_fit_batch call per distinct realisation count."""
+        """All members at once.  The reference fits them one after the other (ensembles/data.py:385-395); their realisation
+        counts differ (its pickled collections: R in {25, 9, 16}, {25, 25, 5, 6, 3, 5}; experiments/data: 3 ... 50).  Every
+        member of equal length N goes into ONE launch whatever its R (bayens_gp_fit_batch_ragged); the fp32 mode keeps one
+        launch per distinct realisation count."""
         del compile_objective   # accepted for signature compatibility (a tf.function knob)
         if self.per_gridpoint and all(pm.model_data.ndim > 2 for pm in process_models):
             return self.fit_field(process_models, n_optim_nits)
@@ -168,28 +171,42 @@ class GPDTW1D:
         # here the same samples are kept on each Distribution as `.losses` (and skipped when progress_bar=False)
         ctx = _lib.default_context()
         pro = [self._prologue(pm) for pm in process_models]
+        if self.target == "dba":                      # the device DBA runs per distinct (N, R): its series are a dense [B][R][N]
+            shapes = {}
+            for i, (X, _, _) in enumerate(pro):
+                shapes.setdefault(X.shape, []).append(i)
+            for shape, idxs in shapes.items():
+                y, _ = ctx.dba_batch(np.ascontiguousarray(np.stack([pro[i][0].T for i in idxs])), 10)
+                for j, i in enumerate(idxs):
+                    pro[i] = (pro[i][0], y[j], pro[i][2])
+        f32 = self.dtype != np.float64
         groups = {}
         for i, (X, _, _) in enumerate(pro):
-            groups.setdefault(X.shape, []).append(i)
+            groups.setdefault(X.shape if f32 else X.shape[0], []).append(i)
         dists = [None] * len(process_models)
-        f32 = self.dtype != np.float64
-        for shape, idxs in groups.items():
-            X = np.stack([pro[i][0] for i in idxs])
-            if self.target == "dba":
-                y, _ = ctx.dba_batch(np.ascontiguousarray(np.swapaxes(X, 1, 2)), 10)
-            else:
-                y = np.stack([pro[i][1] for i in idxs])
+        kid = _lib.KERNEL_IDS[self.kernel]
+        for _, idxs in groups.items():
+            y = np.stack([pro[i][1] for i in idxs])
             nu = np.stack([pro[i][2] for i in idxs])
-            B, N, R = X.shape
+            B, N = y.shape
             # the posteriors stay in HBM (resident.py): inputs go up (a few MB), the fit runs on resident buffers, and
             # only the hyper-parameters and loss samples come back; mu / cov / chol are fetched if somebody reads them
             batch = ResidentBatch(ctx, B, N, self.dtype)
             n_loss = (int(n_optim_nits) + 24) // 25 if progress_bar else 0
+            uniform = len({pro[i][0].shape[1] for i in idxs}) == 1
+            if uniform:
+                Rs, off, X = None, None, np.stack([pro[i][0] for i in idxs])
+            else:
+                Rs, off, X = ctx.ragged_layout([pro[i][0] for i in idxs])
             dX, dy, dnu = ctx.to_device(X, self.dtype), ctx.to_device(y, self.dtype), ctx.to_device(nu, self.dtype)
             dloss = ctx.empty((B, n_loss)) if n_loss else None
             try:
-                ctx.gp_fit_batch_dev(B, N, R, dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol, batch.logdet,
-                                     batch.hyp, kernel=_lib.KERNEL_IDS[self.kernel], basis=batch.basis, f32=f32, loss=dloss)
+                if uniform:
+                    ctx.gp_fit_batch_dev(B, N, X.shape[2], dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol, batch.logdet,
+                                         batch.hyp, kernel=kid, basis=batch.basis, f32=f32, loss=dloss)
+                else:
+                    ctx.gp_fit_batch_ragged_dev(B, N, Rs, off, dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol,
+                                                batch.logdet, batch.hyp, kernel=kid, basis=batch.basis, loss=dloss)
                 batch.finish()
                 hyp = batch.hyp.download()
                 loss = dloss.download() if dloss is not None else None
@@ -223,3 +240,22 @@ class MeanFieldApproximation:
         mean, var = _lib.default_context().multi_model_mean(data, np.array([R], dtype=np.int32))
         blank = ones_like(model.model_data[0].drop_vars("realisation")) * np.nan
         return Distribution(mu=mean, covariance=var, dim_array=blank.rename("blank"), dist_type=dx.Normal)
+
+
+def fit_collections(collections, model=None, **kwargs):
+    """Fits SEVERAL ModelCollections at once: experiments/full_experiment_script.py:87-113 calls `ModelCollection.fit` on
+    fourteen collections back to back (one per scenario and period; ~20 members each).  Members are independent
+    (ensembles/data.py:391), so every member of equal length - whichever collection it belongs to, whatever its realisation
+    count - is one workgroup of ONE launch: ~280 members fill the 256 compute units where 20 leave 236 of them idle.
+    Same result as `for mc in collections: mc.fit(model, **kwargs)`; `model` must offer `fit_collection` (GPDTW1D)."""
+    import warnings
+    model = GPDTW1D() if model is None else model
+    if not hasattr(model, "fit_collection"):
+        for mc in collections:
+            mc.fit(model, **kwargs)
+        return
+    members = [pm for mc in collections for pm in mc.models]
+    if any(pm.distribution != None for pm in members):  # noqa: E711  (data.py:388-390)
+        warnings.warn("Removing the model's previously learnt distribution")
+    for pm, dist in zip(members, model.fit_collection(members, **kwargs)):
+        pm.distribution = dist

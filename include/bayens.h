@@ -104,6 +104,22 @@ int bayens_gp_fit_batch(bayens_ctx* ctx, int loc, int B, int N, int R,
                         double* mu, double* cov, double* cov_chol, double* logdet,
                         double* hyp, double* loss_trace, int* info, double* ll_basis);
 
+/* The same for members whose realisation counts DIFFER - what ModelCollection.fit actually meets (ensembles/data.py:385-395 loops
+ * over members one after the other; the reference's pickled collections hold R in {25, 9, 16}, {25, 9, 10}, {25, 25, 5, 6, 3, 5},
+ * experiments/data R = 3 ... 50) and what experiments/full_experiment_script.py:87-113 does fourteen times in a row: every member
+ * of equal N goes into ONE launch, whatever its R and whichever collection it belongs to ("a per-member R[b] array").
+ *   R      [B]  realisations of member b (HOST array whatever `loc` says)
+ *   x_off  [B]  offset, in doubles, of member b's [N][R[b]] block (realisation_set.T, models.py:182) inside X (HOST array);
+ *               NULL: the blocks lie one behind the other in member order
+ *   X           the members' blocks; everything else as in bayens_gp_fit_batch.
+ * In the fused kernels (N <= 254) R is only the inner extent of the kernel-matrix tile loads, in the general path the
+ * contraction length of the distance product: each member's result is bit for bit that of a uniform batch of its own R. */
+int bayens_gp_fit_batch_ragged(bayens_ctx* ctx, int loc, int B, int N, const int* R, const size_t* x_off,
+                               const double* X, const double* y_mean, const double* y_var,
+                               int kernel, int n_iters, double gamma, double lr, double jitter,
+                               double* mu, double* cov, double* cov_chol, double* logdet,
+                               double* hyp, double* loss_trace, int* info, double* ll_basis);
+
 /* [nb][A][B] -> [nb][B][A] (out of place).  The per-gridpoint field keeps its tables fit-major ([member][grid point][time]);
  * the reference's consumers flatten (time, lat, lon) in the data's order (ensembles/ensemble_scheme.py:51-52,
  * weights.py:93-100 `.ravel()`): this is the device-side change of layout between the two. */

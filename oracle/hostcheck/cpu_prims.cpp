@@ -158,11 +158,13 @@ struct CpuPrims : Prims {
     }
     return (-2.0 * g + si) + sj;
   }
-  void kmat(int nb, int N, int Np, int R, const double* X, const double* ustate, int kernel, double jitter,
-            Mat Lb, bool clear_upper, Mat Mb, double m_scale, const double* m_diag) override {
+  void kmat(int nb, int N, int Np, int R_all, const double* X, const double* ustate, int kernel, double jitter,
+            Mat Lb, bool clear_upper, Mat Mb, double m_scale, const double* m_diag, const int* Rv, const long* xoff) override {
     for (int b = 0; b < nb; ++b) {
       double var = softplus(ustate[b * 8 + 0]), ls = softplus(ustate[b * 8 + 1]);
-      const double* Xb = X + (size_t)b * N * R;
+      last_Rv = Rv; last_xoff = xoff;                                       // (the device keeps the scaled X of kmat for grad_adam; so does this)
+      const int R = Rv ? Rv[b] : R_all;                                     // (a ragged batch: the member's own realisation count)
+      const double* Xb = X + (xoff ? (size_t)xoff[b] : (size_t)b * N * R_all);
       for (int i = 0; i < Np; ++i)
         for (int j = 0; j < Np; ++j) {
           double K, d;
@@ -257,12 +259,15 @@ struct CpuPrims : Prims {
         a[(size_t)b * n + i] = s - y[(size_t)b * n + i];
       }
   }
-  void grad_adam(int nb, int N, int Np, int R, const double* X, int kernel, Mat Kbt, double* ustate, double lr,
+  const int* last_Rv = nullptr;
+  const long* last_xoff = nullptr;
+  void grad_adam(int nb, int N, int Np, int R_all, const double* X, int kernel, Mat Kbt, double* ustate, double lr,
                  const double* pvec, double sym_gamma) override {
     for (int b = 0; b < nb; ++b) {
       double* u = ustate + b * 8;
       double var = softplus(u[0]), ls = softplus(u[1]);
-      const double* Xb = X + (size_t)b * N * R;
+      const int R = last_Rv ? last_Rv[b] : R_all;
+      const double* Xb = X + (last_xoff ? (size_t)last_xoff[b] : (size_t)b * N * R_all);
       double gv = 0, gl = 0;
       for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) {
@@ -434,6 +439,20 @@ int hostcheck_gp_fit(int B, int N, int R, const double* X, const double* y_mean,
   FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
   fp.loss_trace = loss_trace;
   fp.loss_stride = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+  gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp, basis);
+  for (int b = 0; b < B; ++b) info[b] = h.info[b];
+  return 0;
+}
+
+// the same over a ragged batch: member b has Rv[b] <= R realisations, its [N][Rv[b]] block starts xoff[b] doubles into X
+int hostcheck_gp_fit_ragged(int B, int N, int R, const int* Rv, const long* xoff, const double* X, const double* y_mean,
+                            const double* y_var, int kernel, int n_iters, double gamma, double lr, double jitter, double* mu,
+                            double* cov, double* chol, double* logdet, double* hyp, int* info, double* basis) {
+  CpuPrims P;
+  HostWs h(B, pad_to_leaf(N));
+  FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+  fp.Rv = Rv;
+  fp.xoff = xoff;
   gp_fit(P, h.ws, fp, X, y_mean, y_var, mu, cov, chol, logdet, hyp, basis);
   for (int b = 0; b < B; ++b) info[b] = h.info[b];
   return 0;

@@ -116,3 +116,35 @@ def test_polar_iteration_gives_the_w2_trace_term(hostcheck):
     iters = hostcheck.hostcheck_nuclear(nb, N, P(L), P(nuc))
     ref = [np.trace(go.sqrtm_svd(go.sqrtm_svd(covs[0]) @ covs[j] @ go.sqrtm_svd(covs[0]))) for j in range(1, nb + 1)]
     assert iters <= 8 and relerr(nuc, np.array(ref)) < 1e-12
+
+
+def test_ragged_batch_through_the_driver_equals_the_members_fitted_alone(hostcheck):
+    """driver.cpp with FitParams::Rv / xoff (bayens_gp_fit_batch_ragged): members of R = 3, 7, 4 in one batch - blocks of X at
+    explicit offsets, out of order and with a gap - against the same members fitted alone, and one of them against the oracle."""
+    N, T, Rs = 70, 3, [3, 7, 4]
+    datas = [go.synthetic_ensemble(1, N, R=r, seed=10 + r)[0][0] for r in Rs]          # (R, N) each
+    Xs = [np.ascontiguousarray(d.T) for d in datas]
+    y = np.stack([d.mean(axis=0) for d in datas]); nu = np.stack([d.var(axis=0) for d in datas])
+    # layout: member 2 first, then a gap of 5 doubles, member 0, member 1
+    order, off, pos = [2, 0, 1], np.zeros(3, dtype=np.int64), 0
+    chunks = []
+    for k in order:
+        if k == 0:
+            chunks.append(np.full(5, np.nan)); pos += 5
+        off[k] = pos
+        chunks.append(Xs[k].ravel()); pos += Xs[k].size
+    X = np.concatenate(chunks)
+    B = 3
+    mu, cov, chol = np.zeros((B, N)), np.zeros((B, N, N)), np.zeros((B, N, N))
+    ld, hyp, info, basis = np.zeros(B), np.zeros((B, 2)), np.zeros(B, dtype=np.int32), np.zeros((B, 2, N))
+    Rv = np.array(Rs, dtype=np.int32)
+    hostcheck.hostcheck_gp_fit_ragged(B, N, int(Rv.max()), Rv.ctypes.data_as(ip), off.ctypes.data_as(ctypes.POINTER(ctypes.c_long)),
+                                      P(X), P(y), P(nu), 0, T, ctypes.c_double(0.5), ctypes.c_double(0.01), ctypes.c_double(1e-6),
+                                      P(mu), P(cov), P(chol), P(ld), P(hyp), info.ctypes.data_as(ip), P(basis))
+    assert not info.any()
+    for m in range(B):
+        m1, c1, l1, d1, h1, i1 = hc_fit(hostcheck, Xs[m][None], y[m][None], nu[m][None], T)
+        assert np.array_equal(mu[m], m1[0]) and np.array_equal(cov[m], c1[0]) and np.array_equal(chol[m], l1[0])
+        assert ld[m] == d1[0] and np.array_equal(hyp[m], h1[0]) and np.array_equal(basis[m], hc_fit.basis[0])
+    mo, co, ho = go.gp_fit(Xs[1], y[1], nu[1], T)
+    assert relerr(mu[1], mo) < 1e-9 and relerr(cov[1], co) < 1e-9 and relerr(hyp[1], ho) < 1e-11
