@@ -462,6 +462,71 @@ def mid_size_line(ctx, M=20, N=165, R=9, T=2500):
     return out
 
 
+def paper_script_line(ctx, n_collections=14, members=20, T=2000, reps=2):
+    """The fits of the reference's experiment script as ONE call: experiments/full_experiment_script.py:87-113 fits fourteen
+    ModelCollections back to back (per scenario: the historical period, annual series N = 165, and the projection, N = 86), ~20
+    members each with R = 3 ... 50 realisations, GPDTW1D with n_optim_nits = 2000 - on the CPU, member after member.  Here
+    es.fit_collections stacks every member of equal length into one ragged launch (bayens_gp_fit_batch_ragged): 140 workgroups of
+    the fused mid-size kernel and 140 of the fused small-member kernel instead of 14 x (distinct R) launches of <= 20.  Through the
+    Python classes, host realisations in, posteriors resident; `one_collection_at_a_time` = `for mc: mc.fit(...)` beside it."""
+    import warnings
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    from bayesian_ensembling_amd.synthetic import SplitMix64, synthetic_ensemble
+    rng = SplitMix64(0x5C817)
+
+    def collections():
+        out = []
+        for c in range(n_collections):
+            N = 165 if c % 2 == 0 else 86
+            tcoord = np.arange(N)
+            pms = []
+            for m in range(members):
+                R = 3 + int(rng.uniform() * 48)                                     # 3 ... 50 (experiments/data: 3 ... 50)
+                data, _ = synthetic_ensemble(1, N, R=R, seed=0x5C817 + 977 * c + m)
+                pms.append(es.ProcessModel(DataArray(data[0], ("realisation", "time"), {"realisation": np.arange(R), "time": tcoord}),
+                                           f"c{c}m{m}"))
+            out.append(es.ModelCollection(pms))
+        return out
+    mcs = collections()
+    Rs = [pm.n_realisations for mc in mcs for pm in mc.models]
+    times = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for key in ("one_call", "one_collection_at_a_time"):
+            best = None
+            for _ in range(reps + 1 if key == "one_call" else 1):
+                t0 = time.perf_counter()
+                if key == "one_call":
+                    es.fit_collections(mcs, es.GPDTW1D(), n_optim_nits=T, progress_bar=False)
+                else:
+                    for mc in mcs:
+                        mc.fit(model=es.GPDTW1D(), n_optim_nits=T, progress_bar=False)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            times[key] = best
+            if key == "one_call":       # what the bit-equality tests say in -m gpu, asserted on the timed run too: finite, and the hypers in range
+                hyp = np.array([[pm.distribution.hyperparameters["variance"], pm.distribution.hyperparameters["lengthscale"]]
+                                for mc in mcs for pm in mc.models])
+                mu0 = np.asarray(mcs[0][0].distribution.mean.values)
+                assert np.isfinite(hyp).all() and (hyp > 0).all() and np.isfinite(mu0).all()
+                ref_hyp = hyp.copy()
+            else:
+                hyp = np.array([[pm.distribution.hyperparameters["variance"], pm.distribution.hyperparameters["lengthscale"]]
+                                for mc in mcs for pm in mc.models])
+                assert np.array_equal(hyp, ref_hyp), "one call and collection-by-collection disagree"
+    n = n_collections * members
+    return {"wall_s": round(times["one_call"], 3), "member_fits_per_s": round(n / times["one_call"], 1),
+            "one_collection_at_a_time_s": round(times["one_collection_at_a_time"], 3),
+            "speedup_vs_one_collection_at_a_time": round(times["one_collection_at_a_time"] / times["one_call"], 2),
+            "members": n, "realisations_min_max": [int(min(Rs)), int(max(Rs))], "checked": "hyper-parameters finite and identical "
+            "between the two ways of calling (bit for bit); parity of the ragged launch itself: tests/test_gpu_ragged.py",
+            "workload": f"{n_collections} collections x {members} members ({(n_collections + 1) // 2} of N=165, {n_collections // 2} of N=86), "
+                        f"R drawn from 3..50 per member, matern32, n_optim_nits={T}: es.fit_collections(collections, GPDTW1D()) through "
+                        f"the Python classes (best of {reps}), host realisations in, posteriors resident in HBM"}
+
+
 def spawn_ranks(args):
     """bench.py --gpus N with no launcher: start N ranks here, one device each, before anything touches a GPU."""
     rdzv = tempfile.mkdtemp(prefix="bayens_rdzv_")
@@ -672,6 +737,7 @@ def main():
                           "independent N=86, R=8 fits + per-gridpoint LogLikelihoodWeight + Barycentre; full_export: 432 points")
         extra["config5"] = c5
         extra["n165_T2500"] = mid_size_line(ctx)
+        extra["paper_script"] = paper_script_line(ctx)
         extra.update(api_path_c5(ctx, 32, 36, 48, 86, 8, T))
         extra["api_path_c5_vs_resident_step"] = round(extra["api_path_c5_ms_per_step"] / c5["ms_per_step"], 3)
         for key, kern, is32 in (("rbf_f64", "rbf", False), ("config3_f32_matern52", "matern52", True)):
