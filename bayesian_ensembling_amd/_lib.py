@@ -159,7 +159,11 @@ class DeviceBuffer:
         self.ptr = ctx._take_cached(self.nbytes)        # a block of exactly this size freed earlier, if there is one
         if self.ptr is None:
             p = _vp()
-            ctx._check(ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p)))
+            rc = ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p))
+            if rc != 0 and ctx._cache:                  # HBM may be full of blocks the cache is holding on to: give them back, once
+                ctx.trim_cache()
+                rc = ctx.lib.bayens_malloc(ctx.h, self.nbytes, C.byref(p))
+            ctx._check(rc)
             self.ptr = p.value
 
     def upload(self, arr):
@@ -194,7 +198,9 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            if not self.ctx._give_cached(self.nbytes, self.ptr):
+            # (a buffer that outlives its context - Context.close() has destroyed the device context and everything it owned - has
+            #  nothing left to free)
+            if getattr(self.ctx, "h", None) is not None and not self.ctx._give_cached(self.nbytes, self.ptr):
                 self.ctx.lib.bayens_free(self.ctx.h, self.ptr)
             self.ptr = None
 
@@ -219,8 +225,10 @@ class Context:
                                   "there is no CPU fallback)")
         self.h = h
         self.device = device
-        # Freed blocks are kept for re-use by size (every operation of a context is ordered on its one stream, so a block
-        # may be handed out again the moment its owner lets go of it).  hipMalloc / hipFree cost a millisecond or more each and
+        # Freed blocks are kept for re-use by size.  A block may be handed out again the moment its owner lets go of it because
+        # every operation on it is ordered on the context's one stream - with ONE exception the callers must close themselves:
+        # a buffer written through upload_context()'s second stream (fit_field's `draw`) is only freed after the uploading thread
+        # has been joined and the synchronous copies it made have returned.  hipMalloc / hipFree cost a millisecond or more each and
         # hipFree waits for the device: through the plug-in classes a weighting step allocated and freed half a dozen tables
         # around 0.2 ms of kernels.  Bounded: at most CACHE_BYTES in all, nothing above CACHE_MAX_BLOCK.
         self._cache = {}

@@ -260,7 +260,7 @@ class ResidentDataArray(DataArray):
     """A DataArray whose values live in HBM until somebody reads them (round 4: the [model, time, *space] weight table of a
     per-gridpoint field is 38 MB at BASELINE config 5; the reference hands xr.DataArray objects from a weight to a scheme -
     weights.py:118-123 -> ensemble_scheme.py:52 - and here the scheme reads the device table where it lies).  `values` /
-    `data` / np.asarray() download on first use and keep the host copy; shape, dims and coords never touch the device.
+    `data` / np.asarray() download on first use, keep the host copy and end the residency (the copy is writable); shape, dims and coords never touch the device.
     `resident` = (owner, device table in the DEVICE's layout, layout tag): what a consumer that knows the layout uses."""
 
     def __init__(self, fetch, shape, dims, coords, name, resident):
@@ -282,6 +282,10 @@ class ResidentDataArray(DataArray):
     def values(self):
         if self._host is None:
             self._host = np.asarray(self._fetch()).reshape(self._shape)
+        # The host copy is writable, as an xarray's is (`w.values[mask] = 0`, `w.data *= k`): from the moment it is handed out the
+        # device table may no longer describe the data, so a later consumer (Barycentre, ensemble_scheme.py:49-56) must read the
+        # host copy - it re-uploads it - not the stale table in HBM.
+        self.resident = None
         return self._host
 
     @values.setter

@@ -20,6 +20,7 @@ from __future__ import annotations
 import io
 import json
 import os
+import re
 import stat
 import sys
 import threading
@@ -160,8 +161,11 @@ class FileRendezvous(_HostRows):
         n = os.environ.get("BAYENS_RDZV_NONCE")
         if n:
             return n
+        # (the parent's pid is part of the fallback only under torch's launcher, whose ranks share their parent; under srun / mpirun
+        #  wrappers they need not - set BAYENS_RDZV_NONCE there, or every non-zero rank waits for a session that never matches)
+        shared_parent = "TORCHELASTIC_RUN_ID" in os.environ
         return ":".join([os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
-                         os.environ.get("MASTER_PORT", "0"), str(os.getppid())])
+                         os.environ.get("MASTER_PORT", "0"), str(os.getppid()) if shared_parent else "-"])
 
     def _open_session(self) -> str:
         """The session token of THIS attempt.  Rank 0 clears what earlier attempts left in the directory, draws a token and
@@ -173,11 +177,7 @@ class FileRendezvous(_HostRows):
         path = os.path.join(self.dir, f"session.{restart}")
         nonce = self.attempt_nonce()
         if self.rank == 0:
-            for name in os.listdir(self.dir):            # stale session / round / done files of earlier attempts
-                try:
-                    os.remove(os.path.join(self.dir, name))
-                except OSError:
-                    pass
+            self._remove_own_files()                     # stale session / round / done files of earlier attempts
             token = f"{restart}-{os.urandom(8).hex()}"
             with open(path + ".tmp", "wb") as f:
                 f.write(_encode({"token": token, "pid": os.getpid(), "nonce": nonce}))
@@ -248,15 +248,23 @@ class FileRendezvous(_HostRows):
             if time.time() > deadline:
                 return
             time.sleep(0.002)
-        for name in os.listdir(self.dir):
-            try:
-                os.remove(os.path.join(self.dir, name))
-            except OSError:
-                pass
+        self._remove_own_files()
         try:
-            os.rmdir(self.dir)
+            os.rmdir(self.dir)                           # (only an empty directory goes: somebody else's files keep it)
         except OSError:
             pass
+
+    # the names this class writes: session.<restart>, <restart>-<16 hex>.<round>.<rank>, <restart>-<16 hex>.done.<rank>, and their
+    # .tmp forms.  Nothing else in the directory is ever touched: BAYENS_RDZV may name a directory that holds a user's files.
+    _OWN = re.compile(r"^(session\.\d+|\d+-[0-9a-f]{16}\.(\d{6}|done)\.\d+)(\.tmp)?$")
+
+    def _remove_own_files(self):
+        for name in os.listdir(self.dir):
+            if self._OWN.match(name):
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
 
 
 class CommInitWatchdog:

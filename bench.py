@@ -50,6 +50,19 @@ def fit_flops(N, R, T, f32=False):
     return T * (13.0 / 3.0 * n3 + n2r) - first_saves + (3.0 * n3 + n2r) + n3 / 3.0
 
 
+def check_known_answer(name, hyp0, mu0, trace_cov):
+    """A long timed run held to the oracle's stored answer for member 0 (tests/golden/bench_values.json, written by
+    oracle/make_bench_values.py from the NumPy oracle): final (variance, lengthscale), mean(mu), trace(cov) within the 1e-5
+    relative bar BASELINE.json states for fp64.  Returns the worst relative deviation; raises when outside the bar."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench_values.json")
+    ref = json.load(open(path))[name]
+    dev = max(abs(float(hyp0[0]) / ref["variance"] - 1.0), abs(float(hyp0[1]) / ref["lengthscale"] - 1.0),
+              abs(float(np.mean(mu0)) / ref["mean_mu"] - 1.0), abs(float(trace_cov) / ref["trace_cov"] - 1.0))
+    if not (np.isfinite(dev) and dev < 1e-5):
+        raise AssertionError(f"{name}: member 0 is {dev:.2e} (relative) away from the oracle's stored answer")
+    return dev
+
+
 def make_inputs(M, N, R, R_obs, seed):
     """Seeded synthetic ensemble: quadratic trend + AR(1) noise; y_mean = mean over realisations."""
     from bayesian_ensembling_amd.synthetic import synthetic_ensemble
@@ -448,6 +461,9 @@ def mid_size_line(ctx, M=20, N=165, R=9, T=2500):
             tfl = M * fit_flops(N, R, T) / (ms * 1e-3) / 1e12
             out[key] = {"collection_fit_s": round(ms * 1e-3, 4), "us_per_iteration": round(ms * 1e3 / T, 1),
                         "fit_algorithmic_tflops": round(tfl, 3)}
+            if (M, N, R, T) == (20, 165, 9, 2500):          # the timed result itself against the oracle's stored answer
+                dev = check_known_answer("n165_T2500", dhyp.download()[0], dmu.download()[0], np.trace(dcov.download_rows(0, 1)[0]))
+                out[key]["member0_vs_oracle_rel"] = float(f"{dev:.2e}")
     finally:
         ctx.set_medium_min_batch(0)
         for b in (dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis):
@@ -714,8 +730,11 @@ def main():
 
     # ---- extra lines (single GPU, the headline preset): API-default iteration count, config 3, the RBF wording ----
     if world == 1 and not args.no_extras and args.config == "c2" and (M, N, T, args.kernel, f32) == (32, 2000, 2, "matern32", False):
-        ctx.timer_start(); wl.fit(T=500); t500_ms = ctx.timer_stop()
+        ctx.timer_start(); info500 = wl.fit(T=500); t500_ms = ctx.timer_stop()
+        assert not np.asarray(info500).any()
+        dev500 = check_known_answer("c2_T500", wl.dhyp.download()[0], wl.dmu.download()[0], np.trace(wl.dcov.download_rows(0, 1)[0]))
         extra["n_optim_nits_500"] = {
+            "member0_vs_oracle_rel": float(f"{dev500:.2e}"),
             "member_fits_per_s": round(M / (t500_ms * 1e-3), 3), "fit_batch_s": round(t500_ms * 1e-3, 3),
             "fit_algorithmic_tflops": round(M * fit_flops(N, R, 500) / (t500_ms * 1e-3) / 1e12, 3),
             "note": "the API default n_optim_nits=500 (ensembles/models.py:167), same 32 x 2000 batch, one fit batch"}

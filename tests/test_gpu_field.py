@@ -95,6 +95,16 @@ def test_field_weight_table_stays_resident_and_host_schemes_work(ctx):
     assert relerr(raw_soft.values, ref) < 1e-10 and relerr(w_soft.values, ref / ref.sum(axis=0, keepdims=True)) < 1e-10
     # arithmetic / reductions on the resident table behave like any DataArray (PerfectModelTest takes weights.mean('time'))
     assert np.allclose(w.mean("time").values, np.asarray(w.values).mean(axis=1))
+    # an xarray-style edit IN PLACE of the table a caller has read (`w.values[...] = ...`) must reach the scheme: handing out the
+    # writable host copy ends the residency, so Barycentre reads the edited copy, not the stale table in HBM
+    w2 = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2)
+    assert w2.resident is not None
+    w2.values[:] = 1.0 / M                                                          # uniform weights, edited in place
+    assert w2.resident is None
+    post_edit = es.Barycentre()(mc, w2)
+    uniform = DataArray(np.full(w2.shape, 1.0 / M), w2.dims, dict(w2.coords), w2.name)
+    post_uniform = es.Barycentre()(mc, uniform)
+    assert np.array_equal(post_edit.mu, post_uniform.mu) and not np.array_equal(post_edit.mu, post_resident.mu)
 
 
 def test_equality_of_resident_and_field_posteriors_does_not_download(ctx):

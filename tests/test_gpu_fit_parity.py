@@ -81,6 +81,47 @@ def test_fit_reproduces_the_references_pickled_posteriors(ctx, fname):
     assert abs(logdet[0] - float(g["logdet_gold"])) < 1e-9
 
 
+
+@pytest.mark.parametrize("fname", [f for f in golden_files() if "hist" in f])
+def test_general_path_reproduces_the_references_pickled_posteriors_over_2500_iterations(ctx, fname):
+    """The long horizon on the GENERAL route (csrc/driver.cpp on the batched primitives - the route of the N = 2000 headline): by
+    size every fixture goes to a fused kernel, so the route is forced (bayens_set_fit_route) and the six N = 165 members of
+    experiments/pre_fit_models/histssp*.pkl run their 2500 iterations (models.py:167,208-210) through it, to the same bars."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    X, _, nu = go.prologue(g["data"])
+    ctx.set_fit_route(1)
+    try:
+        out = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], int(g["n_iters"]))
+        short = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], 100)
+    finally:
+        ctx.set_fit_route(0)
+    fused = ctx.gp_fit_batch(X[None], g["y_mean"][None], nu[None], int(g["n_iters"]))
+    tol_cov, tol_mu, tol_hyp = golden_tolerances(g)
+    e_cov, e_mu, e_hyp = relerr(out["cov"][0], g["cov_gold"]), np.max(np.abs(out["mu"][0] - g["mu_gold"])), relerr(out["hyp"][0], g["hyp"])
+    print(f"{fname} general route: cov {e_cov:.2e} (< {tol_cov:.1e}) mu {e_mu:.2e} (< {tol_mu:.1e}) hyp {e_hyp:.2e} (< {tol_hyp:.1e})")
+    assert e_cov < tol_cov and e_mu < tol_mu and e_hyp < tol_hyp
+    assert not np.array_equal(out["cov"], fused["cov"])                    # (two programs: else the route did not switch)
+    with threadpool_limits(1):
+        mo, co, ho = go.gp_fit(X, g["y_mean"], nu, 100)
+    assert relerr(short["cov"][0], co) < 1e-10 and relerr(short["mu"][0], mo) < 1e-10 and relerr(short["hyp"][0], ho) < 1e-10
+
+
+@pytest.mark.parametrize("N,R,T", [(320, 6, 500), (1000, 8, 100)])
+def test_general_path_long_trajectories_stay_on_the_oracles(ctx, N, R, T):
+    """N > 254 is the general route by size; the API default n_optim_nits = 500 (models.py:167) at N = 320 and 100 iterations at
+    N = 1000, one member each against the oracle: mean, covariance, hyper-parameters and the loss samples at 1e-7."""
+    data, _ = go.synthetic_ensemble(1, N, R=R, seed=N + T)
+    X, y, nu = member_inputs(data)
+    out = ctx.gp_fit_batch(X, y, nu, T, want_loss=True)
+    assert not out["info"].any()
+    with threadpool_limits(4):
+        mo, co, ho, lo = go.gp_fit(X[0], y[0], nu[0], T, loss_every=25)
+    e = dict(mu=relerr(out["mu"][0], mo), cov=relerr(out["cov"][0], co), hyp=relerr(out["hyp"][0], ho),
+             loss=float(np.max(np.abs(out["loss"][0] - lo) / np.abs(lo))))
+    print(f"general route N={N} T={T}: {e}")
+    assert max(e.values()) < 1e-7
+
+
 def test_fit_is_deterministic_and_independent_of_workspace_history(ctx):
     # regression: the Cholesky-backward solve once read 64-blocks of a reused workspace that nothing had written
     data, _ = go.synthetic_ensemble(2, 200, R=8, seed=21)

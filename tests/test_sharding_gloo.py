@@ -304,3 +304,31 @@ def test_rendezvous_ignores_the_files_of_an_earlier_attempt(tmp_path, monkeypatc
     assert np.array_equal(parallel._decode(parallel._encode(arr)), arr) and parallel._decode(parallel._encode(None)) is None
     with pytest.raises(ValueError):
         parallel._decode(b"\x80\x04junk")                        # a pickle stream is not a format this reader accepts
+
+
+def test_rendezvous_never_touches_files_it_did_not_write(tmp_path, monkeypatch):
+    """BAYENS_RDZV may name a directory that already holds a user's files (a results directory): opening a session and closing it
+    remove the rendezvous' own names only - session.<n>, <restart>-<hex>.<round>.<rank>, <restart>-<hex>.done.<rank>, their .tmp
+    forms - and the directory itself only when nothing else is left in it."""
+    d = tmp_path / "results"
+    d.mkdir(mode=0o700)
+    keep = {"results.json": b"{}", "session_notes.txt": b"mine", "0-notahexname.000001.0": b"x", "run.tmp": b"y"}
+    for name, body in keep.items():
+        (d / name).write_bytes(body)
+    (d / "session.0").write_bytes(b"stale")
+    (d / "0-0123456789abcdef.000004.1").write_bytes(b"stale")
+    (d / "0-0123456789abcdef.done.1").write_bytes(b"")
+    (d / "0-0123456789abcdef.000005.0.tmp").write_bytes(b"stale")
+    monkeypatch.setenv("BAYENS_RDZV_NONCE", "attempt-x")
+    r = parallel.FileRendezvous(str(d), 0, 1)
+    left = set(os.listdir(d))
+    assert set(keep) <= left and not any(n.startswith("0-0123456789abcdef") for n in left)
+    assert r.allgather_obj("a") == ["a"]
+    r.close()
+    assert set(os.listdir(d)) == set(keep) and all((d / n).read_bytes() == b for n, b in keep.items())
+    # without the torch launcher the fallback nonce does not depend on the parent's pid (ranks under srun / mpirun share none)
+    monkeypatch.delenv("BAYENS_RDZV_NONCE")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert parallel.FileRendezvous.attempt_nonce().endswith(":-")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    assert parallel.FileRendezvous.attempt_nonce().endswith(str(os.getppid()))
