@@ -85,7 +85,7 @@ struct bayens_ctx {
   // low-parallelism steps of one group (64x64 diagonal blocks, narrow panels) overlap the big GEMMs of the others
   std::vector<hipStream_t> gstreams;
   std::vector<HipPrims*> gprims;
-  int ngroups = 1;
+  int ngroups = 0;                 // member groups of a fit batch; 0 = by batch size (fit_in_groups)
   double* sscratch = nullptr;      // small persistent device scratch (per-member scalars)
   size_t sscratch_cap = 0;
   double* small_scratch(size_t count) {
@@ -169,7 +169,13 @@ FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) { return c->dws.view(b0, nb)
 void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
                    double* dmu, double* dcov, double* dchol, double* dld, double* dhyp, double* dbasis) {
   const int N = fp.N, R = fp.R;
-  const int G = std::max(1, std::min(std::min(c->ngroups, (int)c->gstreams.size()), B));
+  // Two groups of members on two streams (each with its look-ahead side stream) let one half's latency-bound steps - the 256-wide
+  // diagonal factorisations, the narrow panel solves: a few CUs busy - run beside the other half's large products: 58.9 against
+  // 60.4 ms per 32 x 2000 step (profiles/r05_groups_sweep.txt; four groups: 69 ms, the products no longer fill the chip).  By
+  // default (bayens_set_groups(ctx, 0)) a batch of at least 32 members that splits into halves of a multiple of 8 members - what
+  // the GEMM's XCD-aware tile dealing wants - runs as two groups, anything else as one.
+  const int want = c->ngroups > 0 ? c->ngroups : ((B >= 32 && B % 16 == 0) ? 2 : 1);
+  const int G = std::max(1, std::min(std::min(want, (int)c->gstreams.size()), B));
   BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
   if (G == 1) {                                      // one group: no host thread, run on the first group stream
     FitWorkspace w = ws_view(c, 0, B);
@@ -464,7 +470,7 @@ int bayens_profile_shapes(bayens_ctx* c, char* buf, int buf_len) {
 }
 
 int bayens_set_groups(bayens_ctx* c, int n_groups) {
-  if (!c || n_groups < 1 || n_groups > 16) return BAYENS_E_ARG;
+  if (!c || n_groups < 0 || n_groups > 16) return BAYENS_E_ARG;
   c->ngroups = n_groups;
   return 0;
 }

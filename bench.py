@@ -628,7 +628,7 @@ def main():
     ap.add_argument("--realisations", type=int, default=8)
     ap.add_argument("--nits", type=int, default=2, help="n_optim_nits (2 = the reference's test scale)")
     ap.add_argument("--kernel", default=None, choices=["matern32", "matern52", "rbf"])
-    ap.add_argument("--groups", type=int, default=1, help="member groups = HIP streams per fit batch")
+    ap.add_argument("--groups", type=int, default=0, help="member groups = HIP streams per fit batch (0: the library's default, by batch size)")
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"],
                     help="f64 = the reference precision (the headline); f32 = BASELINE config 3 (1e-3 parity bar)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "file"],
@@ -800,7 +800,7 @@ def main():
                                " + Barycentre",
                    "preset": args.config, "members_per_gpu": M, "members_total": M * world, "timesteps": N,
                    "realisations": R, "n_optim_nits": T, "kernel": args.kernel, "obs_realisations": wl.R_obs,
-                   "member_groups": args.groups,
+                   "member_groups": args.groups if args.groups else "library default: two groups (streams) for a batch of >= 32 members, else one",
                    "parallelism": (f"member-sharded x{world}, one RCCL all-gather of packed [M_loc,3,N] rows per step"
                                    if world > 1 else "single GPU"),
                    "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib, "rccl_ranks": rccl_ranks,

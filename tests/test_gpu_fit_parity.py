@@ -205,7 +205,7 @@ def test_loss_trace_is_the_references_training_loss(ctx, M, N, T):
     try:
         assert np.array_equal(ctx.gp_fit_batch(X, y, nu, T, want_loss=True)["loss"], out["loss"])
     finally:
-        ctx.set_groups(1)
+        ctx.set_groups(0)
 
 
 F32_TOL = 1e-3      # BASELINE.json: 1e-3 relative for fp32
@@ -444,16 +444,32 @@ def test_config3_full_size_against_the_fp64_oracle(ctx):
 
 
 def test_member_groups_do_not_change_the_result(ctx):
+    """The general route splits a batch over member groups = streams (two by default from 32 members on, include/bayens.h
+    bayens_set_groups): one, three and the default number of groups give the same bits (N = 130 is forced onto the general route;
+    N = 320 with 32 members takes it - and the default split - by size)."""
     data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
     X, y, nu = member_inputs(data)
-    one = ctx.gp_fit_batch(X, y, nu, 2)
-    ctx.set_groups(3)
+    ctx.set_fit_route(1)
     try:
+        ctx.set_groups(1)
+        one = ctx.gp_fit_batch(X, y, nu, 2)
+        ctx.set_groups(3)
         three = ctx.gp_fit_batch(X, y, nu, 2)
     finally:
-        ctx.set_groups(1)
+        ctx.set_groups(0)
+        ctx.set_fit_route(0)
     for k in ("mu", "cov", "chol", "logdet", "hyp", "basis"):
         assert np.array_equal(one[k], three[k]), k
+    data, _ = go.synthetic_ensemble(32, 320, R=3, seed=32)
+    X, y, nu = member_inputs(data)
+    auto = ctx.gp_fit_batch(X, y, nu, 2, want_chol=False)
+    ctx.set_groups(1)
+    try:
+        single = ctx.gp_fit_batch(X, y, nu, 2, want_chol=False)
+    finally:
+        ctx.set_groups(0)
+    for k in ("mu", "cov", "hyp"):
+        assert np.array_equal(auto[k], single[k]), k
 
 
 def test_bench_contract_line(ctx):
