@@ -110,10 +110,40 @@ static int potrf_block_width() {
   return nbw;
 }
 
+// Left-looking form of the same factorisation: block column j first receives ALL the updates of the columns before it in ONE
+// product, [A_jj; A_below] -= [L_j,0:j; L_below,0:j] L_j,0:j^T - an (n - k0) x NB output contracted over k0 = j NB - then its diagonal
+// block is factored and its panel solved.  Same flop as the right-looking form, but the products are long in k (the right-looking
+// rank-NB updates read and write the whole trailing triangle per block column and run at 14-50 TFLOP/s, profiles/r04_gemm_shapes.txt:
+// half of the dominant kernel's time).  There is no trailing update to run beside the latency-bound diagonal block and panel solve:
+// that overlap comes from the other member group's products (fit_in_groups, two groups by default).
+static int potrf_left_looking() {
+  static int v = [] { const char* e = std::getenv("BAYENS_POTRF_LEFT"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
+static void potrf_left(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows) {
+  const int NB = potrf_block_width();
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int w = n - k0 < NB ? n - k0 : NB;
+    const int below = n - k0 - w;
+    real* invk = inv_at(inv, k0 / LEAF);
+    const int m = n - k0 + extra_rows;                 // the block column from its diagonal block down, appended rows included
+    if (k0 > 0)
+      P.gemm(nb, m, w, k0, -1.0, A.sub(k0, 0), A.sub(k0, 0), 1.0, A.sub(k0, k0), GEMM_TB | GEMM_TRI_OUT, 0.0);
+    potrf_rec(P, nb, w, A.sub(k0, k0), invk, inv_stride, info, k0, below == 0 ? extra_rows : 0);
+    if (below == 0) break;
+    trsm_rlt(P, nb, below + extra_rows, w, A.sub(k0, k0), invk, inv_stride, A.sub(k0 + w, k0));
+  }
+}
+
 void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows) {
   const int NB = potrf_block_width();
   if (n <= NB) {
     potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+    return;
+  }
+  if (potrf_left_looking()) {
+    potrf_left(P, nb, n, A, inv, inv_stride, info, extra_rows);
     return;
   }
   for (int k0 = 0; k0 < n; k0 += NB) {
