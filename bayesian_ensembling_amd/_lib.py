@@ -868,6 +868,20 @@ def upload_context(ctx):
     return c
 
 
+_side_ctxs = {}
+
+
+def side_context(ctx, k):
+    """The k-th extra context (k >= 1; its own HIP stream and workspaces) on the device of `ctx`: launches queued through it run
+    beside those of `ctx` (GPDTW1D.fit_collection gives every group of equal-length members its own).  Buffers of `ctx` may be
+    passed to it - device memory is shared; the caller orders the two streams (Context.sync) where one reads what the other wrote."""
+    key = (ctx.device, int(k))
+    c = _side_ctxs.get(key)
+    if c is None:
+        c = _side_ctxs[key] = Context(ctx.device)
+    return c
+
+
 def default_context():
     """Process-wide context on the device LOCAL_RANK selects (one process per GPU)."""
     global _default_ctx

@@ -158,6 +158,36 @@ class GPDTW1D:
             dists.append(d)
         return dists
 
+    def _prepare_group(self, ctx, pro, idxs, n_loss):
+        """Resident inputs and outputs of ONE launch: the members `idxs` (equal length, any realisation counts)."""
+        y = np.stack([pro[i][1] for i in idxs])
+        nu = np.stack([pro[i][2] for i in idxs])
+        B, N = y.shape
+        # the posteriors stay in HBM (resident.py): inputs go up (a few MB), the fit runs on resident buffers, and
+        # only the hyper-parameters and loss samples come back; mu / cov / chol are fetched if somebody reads them
+        batch = ResidentBatch(ctx, B, N, self.dtype)
+        if len({pro[i][0].shape[1] for i in idxs}) == 1:
+            Rs, off, X = None, None, np.stack([pro[i][0] for i in idxs])
+            R = X.shape[2]
+        else:
+            Rs, off, X = ctx.ragged_layout([pro[i][0] for i in idxs])
+            R = None
+        return {"idxs": idxs, "batch": batch, "B": B, "N": N, "R": R, "Rs": Rs, "off": off,
+                "X": ctx.to_device(X, self.dtype), "y": ctx.to_device(y, self.dtype), "nu": ctx.to_device(nu, self.dtype),
+                "loss": ctx.empty((B, n_loss)) if n_loss else None}
+
+    @staticmethod
+    def _launch_group(fctx, pr, n_optim_nits, kid, f32):
+        """Queues (and waits for) the fit of a prepared group through the context `fctx` - the owner of the buffers, or a side
+        context with its own stream when several groups run beside each other."""
+        b = pr["batch"]
+        if pr["Rs"] is None:
+            fctx.gp_fit_batch_dev(pr["B"], pr["N"], pr["R"], pr["X"], pr["y"], pr["nu"], n_optim_nits, b.mu, b.cov, b.chol, b.logdet,
+                                  b.hyp, kernel=kid, basis=b.basis, f32=f32, loss=pr["loss"])
+        else:
+            fctx.gp_fit_batch_ragged_dev(pr["B"], pr["N"], pr["Rs"], pr["off"], pr["X"], pr["y"], pr["nu"], n_optim_nits, b.mu, b.cov,
+                                         b.chol, b.logdet, b.hyp, kernel=kid, basis=b.basis, loss=pr["loss"])
+
     def fit_collection(self, process_models, n_optim_nits: int = 500, compile_objective: bool = False,
                        progress_bar: bool = True):
         """All members at once.  The reference fits them one after the other (ensembles/data.py:385-395); their realisation
@@ -185,40 +215,50 @@ class GPDTW1D:
             groups.setdefault(X.shape if f32 else X.shape[0], []).append(i)
         dists = [None] * len(process_models)
         kid = _lib.KERNEL_IDS[self.kernel]
-        for _, idxs in groups.items():
-            y = np.stack([pro[i][1] for i in idxs])
-            nu = np.stack([pro[i][2] for i in idxs])
-            B, N = y.shape
-            # the posteriors stay in HBM (resident.py): inputs go up (a few MB), the fit runs on resident buffers, and
-            # only the hyper-parameters and loss samples come back; mu / cov / chol are fetched if somebody reads them
-            batch = ResidentBatch(ctx, B, N, self.dtype)
-            n_loss = (int(n_optim_nits) + 24) // 25 if progress_bar else 0
-            uniform = len({pro[i][0].shape[1] for i in idxs}) == 1
-            if uniform:
-                Rs, off, X = None, None, np.stack([pro[i][0] for i in idxs])
+        n_loss = (int(n_optim_nits) + 24) // 25 if progress_bar else 0
+        # set-up of every group on the calling thread (allocation cache and uploads of `ctx`), then the launches
+        prepared = [self._prepare_group(ctx, pro, idxs, n_loss) for idxs in groups.values()]
+        try:
+            if len(prepared) > 1 and not f32:
+                # Groups of different length are independent launches: a script's historical N = 165 and projection N = 86
+                # collections (experiments/full_experiment_script.py:87-113) run BESIDE each other, each through its own context
+                # = stream, driven by a helper thread (the blocking C call releases the GIL), so that the workgroups of one and of
+                # the other share the 256 compute units instead of taking turns on them.
+                import threading
+                ctx.sync()                                   # the uploads ran on ctx's stream: every side stream must see them
+                errors = []
+
+                def launch(k):
+                    try:
+                        self._launch_group(_lib.side_context(ctx, k) if k else ctx, prepared[k], n_optim_nits, kid, f32)
+                    except Exception as e:       # noqa: BLE001 - re-raised on the calling thread
+                        errors.append(e)
+                threads = [threading.Thread(target=launch, args=(k,)) for k in range(1, len(prepared))]
+                for t in threads:
+                    t.start()
+                launch(0)
+                for t in threads:
+                    t.join()
+                if errors:
+                    raise errors[0]
             else:
-                Rs, off, X = ctx.ragged_layout([pro[i][0] for i in idxs])
-            dX, dy, dnu = ctx.to_device(X, self.dtype), ctx.to_device(y, self.dtype), ctx.to_device(nu, self.dtype)
-            dloss = ctx.empty((B, n_loss)) if n_loss else None
-            try:
-                if uniform:
-                    ctx.gp_fit_batch_dev(B, N, X.shape[2], dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol, batch.logdet,
-                                         batch.hyp, kernel=kid, basis=batch.basis, f32=f32, loss=dloss)
-                else:
-                    ctx.gp_fit_batch_ragged_dev(B, N, Rs, off, dX, dy, dnu, n_optim_nits, batch.mu, batch.cov, batch.chol,
-                                                batch.logdet, batch.hyp, kernel=kid, basis=batch.basis, loss=dloss)
+                for pr in prepared:
+                    self._launch_group(ctx, pr, n_optim_nits, kid, f32)
+            for pr in prepared:
+                batch, idxs = pr["batch"], pr["idxs"]
                 batch.finish()
                 hyp = batch.hyp.download()
-                loss = dloss.download() if dloss is not None else None
-            finally:
-                for d in (dX, dy, dnu, dloss):
+                loss = pr["loss"].download() if pr["loss"] is not None else None
+                for j, i in enumerate(idxs):
+                    dists[i] = Distribution(dim_array=_blank_array(process_models[i]),
+                                            dist_type=dx.MultivariateNormalFullCovariance, _resident=(batch, j))
+                    dists[i].hyperparameters = {"variance": float(hyp[j, 0]), "lengthscale": float(hyp[j, 1])}
+                    dists[i].losses = None if loss is None else loss[j].copy()
+        finally:
+            for pr in prepared:
+                for d in (pr["X"], pr["y"], pr["nu"], pr["loss"]):
                     if d is not None:
                         d.free()
-            for j, i in enumerate(idxs):
-                dists[i] = Distribution(dim_array=_blank_array(process_models[i]),
-                                        dist_type=dx.MultivariateNormalFullCovariance, _resident=(batch, j))
-                dists[i].hyperparameters = {"variance": float(hyp[j, 0]), "lengthscale": float(hyp[j, 1])}
-                dists[i].losses = None if loss is None else loss[j].copy()
         return dists
 
     def fit(self, model, n_optim_nits: int = 500, compile_objective: bool = False, progress_bar: bool = True):

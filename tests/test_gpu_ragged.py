@@ -131,11 +131,15 @@ def test_collections_with_ragged_members_through_the_plugin_api(ctx):
     time = np.arange(N)
     pm = lambda a, name: es.ProcessModel(DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": time}), name)
 
-    def collection(Rs, seed):
-        return es.ModelCollection([pm(go.synthetic_ensemble(1, N, R=r, seed=seed + k)[0][0], f"m{seed}_{k}") for k, r in enumerate(Rs)])
+    def collection(Rs, seed, n=N):
+        t = np.arange(n)
+        mk = lambda a, name: es.ProcessModel(DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": t}), name)
+        return es.ModelCollection([mk(go.synthetic_ensemble(1, n, R=r, seed=seed + k)[0][0], f"m{seed}_{k}") for k, r in enumerate(Rs)])
 
-    a1, b1 = collection([4, 9, 4, 6], 20), collection([3, 12], 40)
-    a2, b2 = collection([4, 9, 4, 6], 20), collection([3, 12], 40)
+    # (the second collection has ANOTHER length - a projection beside a historical period: its launch runs beside the first one's,
+    #  through a side context)
+    a1, b1 = collection([4, 9, 4, 6], 20), collection([3, 12, 5], 40, n=70)
+    a2, b2 = collection([4, 9, 4, 6], 20), collection([3, 12, 5], 40, n=70)
     es.fit_collections([a1, b1], es.GPDTW1D(), n_optim_nits=T, progress_bar=False)
     a2.fit(model=es.GPDTW1D(), n_optim_nits=T, progress_bar=False)
     b2.fit(model=es.GPDTW1D(), n_optim_nits=T, progress_bar=False)
