@@ -88,6 +88,8 @@ def load():
                                               C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_int)]
     lib.bayens_extract_diag_f32.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
     lib.bayens_widen_f32.argtypes = [_vp, C.c_int, C.c_size_t, _vp, _vp]
+    lib.bayens_narrow_f64.argtypes = [_vp, C.c_int, C.c_size_t, _vp, _vp]
+    lib.bayens_gp_fit_batch_reduced_f32.argtypes = lib.bayens_gp_fit_batch_reduced.argtypes
     lib.bayens_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_mvn_log_prob.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_normal_loglik_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
@@ -446,14 +448,17 @@ class Context:
             raise err
         return info
 
-    def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
-        """Members with N <= 254 (fused kernels), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance)."""
-        X = _f64(X)
+    def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, dtype=np.float64):
+        """Members with N <= 254 (fused kernels), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance).
+        dtype float32: the fp32 instance of the fused small-member kernel (N <= 94); mu / var / basis come back as float32."""
+        dt = np.dtype(dtype)
+        fn = self.lib.bayens_gp_fit_batch_reduced if dt == np.float64 else self.lib.bayens_gp_fit_batch_reduced_f32
+        X = np.ascontiguousarray(X, dtype=dt)
         B, N, R = X.shape
-        y_mean, y_var = _f64(y_mean).reshape(B, N), _f64(y_var).reshape(B, N)
-        mu, var, logdet, hyp = np.empty((B, N)), np.empty((B, N)), np.empty(B), np.empty((B, 2))
-        basis, info = np.empty((B, 2, N)), np.zeros(B, dtype=np.int32)
-        rc = self.lib.bayens_gp_fit_batch_reduced(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
+        y_mean, y_var = np.ascontiguousarray(y_mean, dtype=dt).reshape(B, N), np.ascontiguousarray(y_var, dtype=dt).reshape(B, N)
+        mu, var, logdet, hyp = np.empty((B, N), dtype=dt), np.empty((B, N), dtype=dt), np.empty(B), np.empty((B, 2))
+        basis, info = np.empty((B, 2, N), dtype=dt), np.zeros(B, dtype=np.int32)
+        rc = fn(self.h, HOST, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var), int(kernel),
                                                   int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var), _ptr(logdet),
                                                   _ptr(hyp), _ptr(info), _ptr(basis))
         if rc != 0:
@@ -463,9 +468,11 @@ class Context:
         return {"mu": mu, "var": var, "logdet": logdet, "hyp": hyp, "basis": basis, "info": info}
 
     def gp_fit_batch_reduced_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, var, logdet=None, hyp=None, basis=None,
-                                 kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6):
+                                 kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, f32=False):
+        """f32=True: X, y_mean, y_var, mu, var, basis are float32 buffers (N <= 94; logdet / hyp stay float64)."""
         info = np.zeros(B, dtype=np.int32)
-        rc = self.lib.bayens_gp_fit_batch_reduced(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),
+        fn = self.lib.bayens_gp_fit_batch_reduced_f32 if f32 else self.lib.bayens_gp_fit_batch_reduced
+        rc = fn(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),
                                                   int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(var),
                                                   _ptr(logdet), _ptr(hyp), _ptr(info), _ptr(basis))
         if rc != 0:
@@ -659,6 +666,9 @@ class Context:
     def extract_diag_dev(self, B, N, cov, var, f32=False):
         fn = self.lib.bayens_extract_diag_f32 if f32 else self.lib.bayens_extract_diag
         self._check(fn(self.h, DEVICE, B, N, _ptr(cov), _ptr(var)))
+
+    def narrow_f64_dev(self, n, src, dst):
+        self._check(self.lib.bayens_narrow_f64(self.h, DEVICE, int(n), _ptr(src), _ptr(dst)))
 
     def widen_f32_dev(self, n, src, dst):
         self._check(self.lib.bayens_widen_f32(self.h, DEVICE, int(n), _ptr(src), _ptr(dst)))

@@ -732,6 +732,45 @@ int bayens_gp_fit_batch_f32(bayens_ctx* c, int loc, int B, int N, int R, const f
   });
 }
 
+int bayens_gp_fit_batch_reduced_f32(bayens_ctx* c, int loc, int B, int N, int R, const float* X, const float* y_mean,
+                                    const float* y_var, int kernel, int n_iters, double gamma, double lr, double jitter,
+                                    float* mu, float* var, double* logdet, double* hyp, int* info, float* ll_basis) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !var || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: unknown kernel id");
+    if (!smalln::small_fit_supported(N, R))
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: N must be at most 94 (the fp32 instance of the fused small-member kernel; "
+                                   "the mid-size kernel is fp64 only: bayens_gp_fit_batch_reduced)");
+    if (!c->f32) c->f32 = bayens_f32_create(c->stream);
+    Stage st(c, loc);
+    BayensF32Args a;
+    a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;
+    a.gamma = gamma; a.lr = lr; a.jitter = jitter;
+    a.X = st.in(X, (size_t)B * N * R);
+    a.y_mean = st.in(y_mean, (size_t)B * N);
+    a.y_var = st.in(y_var, (size_t)B * N);
+    a.mu = st.out(mu, (size_t)B * N);
+    a.cov = nullptr;
+    a.var = st.out(var, (size_t)B * N);
+    a.chol = nullptr;
+    a.logdet = st.out(logdet, (size_t)B);
+    a.hyp = st.out(hyp, (size_t)B * 2);
+    a.loss_trace = nullptr;
+    a.basis = st.out(ll_basis, (size_t)B * 2 * N);
+    std::vector<int> hinfo(B, 0);
+    a.info_host = hinfo.data();
+    std::string err;
+    const int rc = bayens_f32_fit(c->f32, a, &err);
+    if (rc != 0) return fail(c, rc > 0 ? rc : BAYENS_E_ARG, "gp_fit_batch_reduced_f32: " + err);
+    st.finish();
+    int bad = 0;
+    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch_reduced_f32: matrix not positive definite (see info[])");
+    return 0;
+  });
+}
+
 int bayens_mvn_factor_batch(bayens_ctx* c, int loc, int B, int N, const double* cov, const double* mu, double* chol,
                             double* logdet, double* ll_basis, int* info) {
   return guarded(c, [&]() {
@@ -784,6 +823,24 @@ __global__ void extract_diag_f32_kernel(int N, const float* cov, double* var) {
   if (i < N) var[(size_t)b * N + i] = (double)cov[((size_t)b * N + i) * N + i];
 }
 }  // namespace
+
+__global__ void narrow_f64_kernel(size_t n, const double* src, float* dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
+int bayens_narrow_f64(bayens_ctx* c, int loc, size_t n, const double* src, float* dst) {
+  return guarded(c, [&]() {
+    if (n == 0 || !src || !dst) return fail(c, BAYENS_E_ARG, "narrow_f64: bad argument");
+    Stage st(c, loc);
+    const double* ds = st.in(src, n);
+    float* dd = st.out(dst, n);
+    hipLaunchKernelGGL(narrow_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, ds, dd);
+    BAYENS_HIP(hipGetLastError());
+    st.finish();
+    return 0;
+  });
+}
 
 int bayens_widen_f32(bayens_ctx* c, int loc, size_t n, const float* src, double* dst) {
   return guarded(c, [&]() {

@@ -12,13 +12,14 @@ struct BayensF32Args {
   const float* y_mean;   // device [B][N]
   const float* y_var;    // device [B][N]
   float* mu;             // device [B][N]
-  float* cov;            // device [B][N][N]
+  float* cov;            // device [B][N][N]; null with `var`: the reduced export (fused small-member kernel, N <= 94)
+  float* var = nullptr;  // device [B][N] = diag(cov), nullable
   float* chol;           // device, nullable
   double* logdet;        // device [B], nullable
   double* hyp;           // device [B][2], nullable
   double* loss_trace;    // device [B][ceil(n_iters/25)], nullable
   float* basis;          // device [B][2][N], nullable
-  int* info_host;        // host [B]
+  int* info_host = nullptr;        // host [B]
 };
 
 void* bayens_f32_create(hipStream_t stream);

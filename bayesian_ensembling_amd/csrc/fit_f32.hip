@@ -60,7 +60,7 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
         st->small_info_cap = a.B;
       }
       smalln::SmallArgs g{a.B, a.N, a.R, a.kernel, a.n_iters, a.gamma, a.lr, a.jitter, a.X, a.y_mean, a.y_var, a.mu, a.cov,
-                          nullptr, a.chol, a.logdet, a.hyp, a.basis, st->small_info};
+                          a.var, a.chol, a.logdet, a.hyp, a.basis, st->small_info};
       g.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
       g.loss = g.loss_stride > 0 ? a.loss_trace : nullptr;
       const size_t need = smalln::small_park_doubles(a.B, a.N, st->n_cus);
@@ -76,6 +76,7 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
       BAYENS_HIP(hipStreamSynchronize(st->stream));
       return 0;
     }
+    if (!a.cov) throw HipError{-1, "the reduced fp32 export needs N <= 94 (the fused small-member kernel)"};
     const int Np = pad_to_leaf(a.N);
     st->dws.ensure(a.B, Np);
     FitWorkspace w = st->dws.view(0, a.B);

@@ -75,8 +75,6 @@ class GPDTW1D:
         shapes = {tuple(pm.model_data.shape) for pm in process_models}
         if len(shapes) != 1:
             raise ValueError("per_gridpoint: every member must have the same (realisation, time, *space) shape")
-        if self.dtype != np.float64:
-            raise NotImplementedError("per_gridpoint fits run in float64 (the reduced export has no fp32 entry)")
         if self.target != "mean" and not callable(self.target):
             raise NotImplementedError("per_gridpoint: target must be 'mean' or a callable")
         R, N = next(iter(shapes))[:2]
@@ -85,11 +83,22 @@ class GPDTW1D:
         if N > 254:
             raise NotImplementedError(f"per_gridpoint: {N} time steps; the fused one-kernel-per-fit paths hold N <= 254 (the "
                                       "reference's annual horizons are 86 and 165 steps)")
+        f32 = self.dtype != np.float64
+        if f32 and N > 94:
+            raise NotImplementedError(f"per_gridpoint in float32: {N} time steps; the fp32 instance is the fused small-member kernel "
+                                      "(N <= 94, the reference's projection horizon of 86 years); the mid-size kernel is float64")
         field = ResidentField(ctx, M, G, N)
         kid = _lib.KERNEL_IDS[self.kernel]
         B = M * G
         dX, dy, dnu = ctx.empty((B, N, R)), ctx.empty((B, N)), ctx.empty((B, N))
         draw = ctx.empty((M, R, N, G))
+        # float32: the prologue and the field's tables stay float64 (they feed the float64 weight / scheme kernels); a chunk's
+        # inputs are narrowed and its outputs widened on the device around the fp32 fit (bayens_gp_fit_batch_reduced_f32)
+        chunk = min(self.FIELD_CHUNK, B)
+        sX, sy, snu, smu, svar, sbasis = ((ctx.empty((chunk, N, R), np.float32), ctx.empty((chunk, N), np.float32),
+                                           ctx.empty((chunk, N), np.float32), ctx.empty((chunk, N), np.float32),
+                                           ctx.empty((chunk, N), np.float32), ctx.empty((chunk, 2, N), np.float32))
+                                          if f32 else (None,) * 6)
         worker = None
         try:
             # The realisations go up as they lie in memory ((realisation, time, *space), grid points contiguous); the
@@ -139,6 +148,16 @@ class GPDTW1D:
                     ctx._check(ctx.lib.bayens_memcpy_h2d(ctx.h, dy.offset(f0 * N * 8), y.ctypes.data, y.nbytes))
                 for b0 in range(f0, m1 * G, self.FIELD_CHUNK):
                     nb = min(m1 * G, b0 + self.FIELD_CHUNK) - b0
+                    if f32:
+                        ctx.narrow_f64_dev(nb * N * R, dX.offset(b0 * N * R * 8), sX)
+                        ctx.narrow_f64_dev(nb * N, dy.offset(b0 * N * 8), sy)
+                        ctx.narrow_f64_dev(nb * N, dnu.offset(b0 * N * 8), snu)
+                        ctx.gp_fit_batch_reduced_dev(nb, N, R, sX, sy, snu, n_optim_nits, smu, svar, field.logdet.offset(b0 * 8),
+                                                     field.hyp.offset(b0 * 16), sbasis, kernel=kid, f32=True)
+                        ctx.widen_f32_dev(nb * N, smu, field.mu.offset(b0 * N * 8))
+                        ctx.widen_f32_dev(nb * N, svar, field.var.offset(b0 * N * 8))
+                        ctx.widen_f32_dev(nb * 2 * N, sbasis, field.basis.offset(b0 * 2 * N * 8))
+                        continue
                     ctx.gp_fit_batch_reduced_dev(nb, N, R, dX.offset(b0 * N * R * 8), dy.offset(b0 * N * 8),
                                                  dnu.offset(b0 * N * 8), n_optim_nits, field.mu.offset(b0 * N * 8),
                                                  field.var.offset(b0 * N * 8), field.logdet.offset(b0 * 8),
@@ -147,8 +166,9 @@ class GPDTW1D:
         finally:
             if worker is not None:
                 worker.join()             # (never free a buffer an upload is still writing to)
-            for d in (dX, dy, dnu, draw):
-                d.free()
+            for d in (dX, dy, dnu, draw, sX, sy, snu, smu, svar, sbasis):
+                if d is not None:
+                    d.free()
         dists = []
         blank = _blank_array(process_models[0])         # (every member has the same shape and coordinates: one template)
         for m, pm in enumerate(process_models):

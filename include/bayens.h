@@ -147,6 +147,15 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* ctx, int loc, int B, int N, int R,
                                 const double* X, const double* y_mean, const double* y_var,
                                 int kernel, int n_iters, double gamma, double lr, double jitter,
                                 double* mu, double* var, double* logdet, double* hyp, int* info, double* ll_basis);
+/* ... in fp32 (the fp32 instance of the fused small-member kernel: N <= 94 only - the mid-size kernel is fp64; BASELINE config 5
+ * x config 3's precision: per-gridpoint fields with GPDTW1D(per_gridpoint=True, dtype="float32"), 1e-3 relative).  float arrays
+ * in and out; logdet / hyp stay fp64.  bayens_narrow_f64 / bayens_widen_f32 convert the tables of the fp64 prologue and the
+ * fp64 weight / scheme entry points on the device. */
+int bayens_gp_fit_batch_reduced_f32(bayens_ctx* ctx, int loc, int B, int N, int R,
+                                    const float* X, const float* y_mean, const float* y_var,
+                                    int kernel, int n_iters, double gamma, double lr, double jitter,
+                                    float* mu, float* var, double* logdet, double* hyp, int* info, float* ll_basis);
+int bayens_narrow_f64(bayens_ctx* ctx, int loc, size_t n, const double* src, float* dst);
 
 /* The same fit in fp32 (BASELINE.json config 3; SURVEY 8(b) "dtype enum"): float arrays in and out, fp32 storage
  * and fp32 MFMA products throughout.  Kept in fp64: the hyper-parameters and Adam state (hyp), the squared

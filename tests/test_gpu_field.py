@@ -197,3 +197,46 @@ def test_model_similarity_weight_spatial_mode(ctx):
     mc1.fit(model=es.GPDTW1D(per_gridpoint=True), n_optim_nits=1)
     with pytest.warns(UserWarning), pytest.raises(NotImplementedError):
         es.ModelSimilarityWeight()(mc1, mode="spatial")
+
+
+def test_per_gridpoint_fields_in_float32(ctx):
+    """GPDTW1D(per_gridpoint=True, dtype="float32") (round 5: bayens_gp_fit_batch_reduced_f32, the fp32 instance of the fused
+    small-member kernel behind the field path): marginals, hyper-parameters, the per-gridpoint log-likelihood weights and the
+    barycentre against the float64 ORACLE at BASELINE.json's fp32 bar, 1e-3 relative; N > 94 is refused (the mid-size kernel is
+    float64); the reduced fp32 entry itself against the reduced fp64 one on a plain batch."""
+    M, R, T, n_lat, n_lon, nits = 3, 6, 40, 3, 4, 2
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=5)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True, dtype="float32"), n_optim_nits=nits, progress_bar=False)
+    w = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-2)
+    post = es.Barycentre()(mc, w)
+    G = n_lat * n_lon
+    ob = np.asarray(obs.model_data.values).reshape(-1, T, G)
+    lls = np.empty((M, T, G))
+    mus, vs = np.empty((M, T, G)), np.empty((M, T, G))
+    with threadpool_limits(2):
+        for m in range(M):
+            data = np.asarray(mc[m].model_data.values).reshape(R, T, G)
+            for g in range(G):
+                X, y, nu = go.prologue(data[:, :, g])
+                mo, co, _ = go.gp_fit(X, y, nu, nits)[:3]
+                lls[m, :, g] = go.loglik_mean_rows(go.mvn_constvec_loglik(mo, *go.mvn_factor(co), ob[:, :, g]))
+                mus[m, :, g], vs[m, :, g] = mo, np.diag(co)
+            got_mu = np.asarray(mc[m].distribution.mean.values).reshape(T, G)
+            got_var = np.asarray(mc[m].distribution.variance.values).reshape(T, G)
+            assert relerr(got_mu, mus[m]) < 1e-3 and relerr(got_var, vs[m]) < 1e-3, m
+    w_ref = np.exp(1e-2 * lls)
+    w_ref /= w_ref.sum(axis=0, keepdims=True)
+    assert relerr(np.asarray(w.values).reshape(M, T, G), w_ref) < 1e-3
+    rm, rv, _ = go.barycentre(w_ref.reshape(M, -1), mus.reshape(M, -1), vs.reshape(M, -1))
+    assert relerr(np.asarray(post.mu).ravel(), rm) < 1e-3 and relerr(np.asarray(post.covariance).ravel(), rv) < 1e-3
+    big, _ = _field_collection(2, 3, 100, 2, 2, seed=6)
+    with pytest.raises(NotImplementedError):
+        big.fit(model=es.GPDTW1D(per_gridpoint=True, dtype="float32"), n_optim_nits=1, progress_bar=False)
+    data, _ = go.synthetic_ensemble(5, 86, R=8, seed=86)
+    X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
+    r64 = ctx.gp_fit_batch_reduced(X, data.mean(axis=1), data.var(axis=1), 2)
+    r32 = ctx.gp_fit_batch_reduced(X, data.mean(axis=1), data.var(axis=1), 2, dtype=np.float32)
+    assert r32["mu"].dtype == np.float32 and not r32["info"].any()
+    for key in ("mu", "var", "hyp", "basis"):
+        assert relerr(r32[key].astype(np.float64), r64[key]) < 1e-3, key
+    assert np.max(np.abs(r32["logdet"] - r64["logdet"])) < 1e-3 * np.max(np.abs(r64["logdet"]))
