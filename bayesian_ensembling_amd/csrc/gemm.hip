@@ -356,12 +356,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
       for (int j = 0; j < 4; ++j) acc[i][j] = BAYENS_MFMA16(a[i], b[j], acc[i][j]);
   };
 
+  // the first strip of C (beta != 0) is requested BEFORE the K loop: nobody else writes this tile during the launch, and the
+  // epilogue then starts with its values in registers instead of with a memory round trip
+  real cv[2][4][4];
+  auto load_strip = [&](int i, real (&dst)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
+  };
+  const bool accumulate = g.beta != 0.0;
   if (nk > 0) {
     dl_issue<TA>(A, g.lda, row0, g.m, kbeg, lane, wave, As[0]);
     dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg, lane, wave, Bs[0]);
   }
   dl_wait();
   __syncthreads();
+  if (accumulate && active) load_strip(0, cv[0]);
   if (nk > 1) {
     dl_issue<TA>(A, g.lda, row0, g.m, kbeg + BK, lane, wave, As[1]);
     dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + BK, lane, wave, Bs[1]);
@@ -402,16 +414,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
   }
 
   if (!active) return;
-  real cv[2][4][4];
-  auto load_strip = [&](int i, real (&dst)[4][4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dst[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
-  };
-  const bool accumulate = g.beta != 0.0;
-  if (accumulate) load_strip(0, cv[0]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (accumulate && i + 1 < 4) load_strip(i + 1, cv[(i + 1) & 1]);
