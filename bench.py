@@ -233,7 +233,9 @@ class Workload:
                                "achieved": round(group, 3), "frac": round(group / peak, 4),
                                "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
                 "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
-                "note": "HIP events around every launch of the kernel in one fit batch, one stream (no overlap); achieved = "
+                "note": "HIP events around every launch of the kernel in one fit batch with ONE member group = one stream (bench.py --groups 1: "
+                        "kernels strictly one after the other; the timed headline step runs the library default, two groups on two "
+                        "streams, whose kernels overlap and cannot be priced one by one); achieved = "
                         "algorithmic flop of the UNPADDED problem / summed launch time; traffic = HBM bytes per launch of "
                         "this kernel from the rocprofv3 --pmc passes named in traffic_source (not measured in this run)"}
 

@@ -2,20 +2,26 @@
 # Regenerates the measurement artifacts of one round on the GPU box (run through gpurun from the repo root):
 #   tools/make_profiles.sh r01      -> gpurun_out/<tag>_*  (copy the ones to keep into profiles/)
 # Separate rocprofv3 passes: kernel trace, then one PMC counter per pass (never combined with other trace domains).
+# The script is long (the fuzz sweeps alone take minutes): `tools/make_profiles.sh r05 A` runs the first half (bench lines, rocprofv3
+# passes, configs 3-5), `... r05 B` the second (mid-size kernel, API paths, solves, sweeps), no second argument both.
+# The per-kernel passes (kernel trace, PMC) run `bench.py --groups 1`: one member group = one stream, kernels strictly one after the
+# other - the setting bench.py's own roofline block measures in (the headline step uses the library default, two groups).
 set -u
 TAG=${1:-r01}
+PART=${2:-AB}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
+if [[ $PART == *A* ]]; then
 BAYENS_PRINT_STAGES=1 timeout -k 10 500 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_stage_profile.txt || exit 1
 timeout -k 10 300 python3 bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err || exit 1
 timeout -k 10 300 python3 tools/small_phases.py > $OUT/${TAG}_small_phases.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_kt.log 2>&1 || exit 2
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pf.log 2>&1 || exit 3
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pw.log 2>&1 || exit 4
-timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pm.log 2>&1 || exit 5
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --groups 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_kt.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pf.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pw.log 2>&1 || exit 4
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pm.log 2>&1 || exit 5
 cd $R
 python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util.txt > /dev/null
 rm -rf $OUT/${TAG}_pm
@@ -45,6 +51,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/${TAG}_ktp -o ktp -- python3 
 cd $R
 python3 tools/rocpd_seq.py $(find $OUT/${TAG}_ktp -name "*.db" | head -1) > $OUT/${TAG}_potrf_sequence.txt
 rm -rf $OUT/${TAG}_ktp
+fi
+if [[ $PART == *B* ]]; then
+timeout -k 10 300 python3 tools/paper_script.py > $OUT/${TAG}_paper_script.json 2> $OUT/${TAG}_paper_script.err || exit 30
 # the fused mid-size kernel (csrc/medium.hip) at the reference's workload: timing table against the general path, phase stamps,
 # kernel trace and matrix-pipe utilisation of one collection fit
 (timeout -k 10 300 python3 tools/medium_check.py | grep timing; BAYENS_NO_MEDIUM=1 timeout -k 10 300 python3 tools/medium_check.py | grep timing; timeout -k 10 100 python3 tools/medium_phases.py 165 20 | tail -15) > $OUT/${TAG}_medium_kernel.txt 2>&1 || exit 14
@@ -71,4 +80,5 @@ timeout -k 10 200 python3 tools/small_phases.py 86 8 8192 reduced > $OUT/${TAG}_
 timeout -k 10 300 python3 tools/api_path_c5_profile.py > $OUT/${TAG}_api_path_c5_profile.txt 2>&1 || exit 26
 timeout -k 10 300 python3 tools/scale_check.py > $OUT/${TAG}_scale_check.txt 2>&1 || exit 27
 (timeout -k 10 100 python3 tools/worker_bench.py; python3 tools/flow_model.py) > $OUT/${TAG}_worker_bench.txt 2>&1 || exit 28
+fi
 head -8 $OUT/${TAG}_kernel_stats_final.txt; cat $OUT/${TAG}_pmc_traffic.json | head -12; cut -c1-300 $OUT/${TAG}_bench_final.json
