@@ -14,7 +14,8 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
 if [[ $PART == *A* ]]; then
-BAYENS_PRINT_STAGES=1 timeout -k 10 500 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_stage_profile.txt || exit 1
+timeout -k 10 500 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_bench_final.err || exit 1       # the plain command the driver runs
+BAYENS_PRINT_STAGES=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_stage_profile.txt || exit 1
 timeout -k 10 300 python3 bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err || exit 1
 timeout -k 10 300 python3 tools/small_phases.py > $OUT/${TAG}_small_phases.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
