@@ -433,490 +433,342 @@ __device__ __forceinline__ void staged_product(const Ctx& c, int n_out, bool squ
   GSYNC();
 }
 
-__global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
-  const int NT = g.NT, NTT = NT * (NT + 1) / 2, NP = 16 * NT;
-  double* lds = lds_base();
-  double* ssq = lds;                    // |x_i|^2
-  double* misc = ssq + NP;              // [0..7] optimiser state, [8] variance, [9] lengthscale, [10] 1/ls^2, [11] log det C, [16..47] reductions
-  double* yv = misc + 64;               // y (0 in the padding)
-  double* dv = yv + NP;                 // 1 / nu (1 in the padding)
-  double* rs = dv + NP;                 // 1 / sqrt(nu)
-  double* yd = rs + NP;                 // y / nu
-  double* th = yd + NP;                 // theta1
-  double* mv = th + NP;                 // m
-  double* av = mv + NP;                 // L m - y (loss samples); the posterior mean (prediction)
-  double* wv = av + NP;                 // L^T (y / nu) of this iteration (loss samples: diag(L S L^T))
-  double* uv = wv + NP;                 // u = G m - L^T (y / nu)
-  double* SA = uv + NP;                 // staging tiles (2 NT + 2)
-  // the workgroup's matrices: tile-packed lower triangles, accumulator-native tiles, in an L2-resident HBM scratch
-  double* sc = g.scratch + (size_t)blockIdx.x * g.scratch_stride;
-  double* Lb = sc;                              // K0 + J I -> L ; later C^-1, W
-  double* Cb = Lb + (size_t)NTT * TS;           // Lam -> C ; later Phi ; in the prediction the bordered covariance and its factor
-  double* Wb = Cb + (size_t)NTT * TS;           // L^-1
-  double* Gb = Wb + (size_t)NTT * TS;           // G = L^T D L ; in the prediction (with LamB behind it) E = A^T S, NT x NT tiles
-  double* LamB = Gb + (size_t)NTT * TS;         // Lam (the natural parameter that persists over the iterations)
-  double* Sb = LamB + (size_t)NTT * TS;         // S = C^-T C^-1
-  double* K1b = Sb + (size_t)NTT * TS;          // unit-variance kernel values k1 of this iteration's kernel matrix ...
-  double* K2b = K1b + (size_t)NTT * TS;         // ... and k2 (d/d lengthscale): kept for the hyper-gradient instead of re-evaluating sqrt / exp
-  // (the wave index is made visibly wave-uniform: everything derived from it - tile indices, slot addresses - stays scalar)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  Ctx c;
-  c.NT = NT; c.NTT = NTT; c.wave = wave; c.lane = lane; c.tid = tid; c.SA = SA;
-  lane_init(c.o, lane);
-  const Lane& o = c.o;
-  const int N = g.N;
-  const double J = g.jitter;
+// ---- the fit as a sequence of SEPARATELY COMPILED phases (round 5).  One kernel body with every phase inlined keeps dozens of
+// pointers, offsets and constants alive across all of them: 276 spilled scalar and 60 spilled vector registers, 200 bytes of private
+// segment per lane.  Each phase below is a real function (`__noinline__`) that rebuilds the few addresses it needs from the kernel
+// argument block - read where it lies, in the kernarg segment, through scalar loads - and the member index; the kernel itself holds
+// the member loop, the iteration counter and the pivot status.  (Calls are where the one code-generation defect of this compiler was
+// met, section 5c: tools/check_exec_prologue.py scans every build.)
+typedef const __attribute__((address_space(4))) MediumArgs* KArgs;
+__device__ __forceinline__ KArgs uni_k(KArgs p) { return (KArgs)uni((long)p); }
 
-  auto pargs = [&](double* A_, double* X_, double* G_) {
-    PotrfArgs e;
-    e.sc = (gdouble*)sc; e.oA = A_ - sc; e.oX = X_ - sc; e.oG = G_ - sc; e.NT = NT; e.NTT = NTT;
-    e.sa_off = (int)(SA - lds); e.rs_off = (int)(rs - lds); e.yd_off = (int)(yd - lds); e.wv_off = (int)(wv - lds);
-    e.w4idle = (g.tune & 1) ? 1 : 0;   // off: here the tile updates (through the scratch), not the chain, bound a step (288 against 279 us at N = 165)
-    return e;
-  };
-  // the "cross" of k in a symmetric triangle: slot0 + i = tile (i, k) for i >= k, tile (k, i) for i < k (the user picks
-  // the orientation: S_ik = the slot as it lies for i >= k, its transpose for i < k)
-  // (a wave stages at most two tiles of a cross, NT <= 16: both are requested before either is written to LDS - a scratch
-  //  access is ~1.5 k cycles away and the staging loops used to pay that once per tile)
-  auto stage_cross = [&](const double* Sym, int k, int slot0) {
-    const int i0 = wave, i1 = wave + NW;
-    const bool h0 = i0 < NT, h1 = i1 < NT;
-    const int c0 = h0 ? i0 : 0, c1 = h1 ? i1 : c0;
-    const v4d a0 = ldn(Sym + (size_t)(c0 >= k ? lt(c0, k) : lt(k, c0)) * TS, lane);
-    const v4d a1 = ldn(Sym + (size_t)(c1 >= k ? lt(c1, k) : lt(k, c1)) * TS, lane);
-    if (h0) st_tile(c.slot(slot0 + i0), o, a0);
-    if (h1) st_tile(c.slot(slot0 + i1), o, a1);
-  };
+#define MED_ENV(g_in, b_in) \
+  const KArgs gk_ = uni_k(g_in); \
+  const __attribute__((address_space(4))) MediumArgs& g = *gk_; \
+  [[maybe_unused]] const int b = uni(b_in); \
+  const int NT = g.NT, NTT = NT * (NT + 1) / 2, NP = 16 * NT; \
+  double* lds = lds_base(); \
+  double* ssq = lds; \
+  double* misc = ssq + NP; \
+  double* yv = misc + 64; \
+  double* dv = yv + NP; \
+  double* rs = dv + NP; \
+  double* yd = rs + NP; \
+  double* th = yd + NP; \
+  double* mv = th + NP; \
+  double* av = mv + NP; \
+  double* wv = av + NP; \
+  double* uv = wv + NP; \
+  double* SA = uv + NP; \
+  double* sc = g.scratch + (size_t)blockIdx.x * g.scratch_stride; \
+  double* Lb = sc; \
+  double* Cb = Lb + (size_t)NTT * TS; \
+  double* Wb = Cb + (size_t)NTT * TS; \
+  double* Gb = Wb + (size_t)NTT * TS; \
+  double* LamB = Gb + (size_t)NTT * TS; \
+  double* Sb = LamB + (size_t)NTT * TS; \
+  double* K1b = Sb + (size_t)NTT * TS; \
+  double* K2b = K1b + (size_t)NTT * TS; \
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); \
+  Ctx c; \
+  c.NT = NT; c.NTT = NTT; c.wave = wave; c.lane = lane; c.tid = tid; c.SA = SA; \
+  lane_init(c.o, lane); \
+  const Lane& o = c.o; \
+  const int N = g.N; \
+  const double J = g.jitter; \
+  auto lower_matvec = [&](const double* Lmat, const double* x, double beta, double* out) { \
+    double part[2] = {0.0, 0.0}; \
+  _Pragma("unroll 1") \
+    for (int k = 0; k < NT; ++k) { \
+  _Pragma("unroll 1") \
+      for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lmat + lt(i, k) * TS, lane)); \
+      GSYNC(); \
+  _Pragma("unroll") \
+      for (int u = 0; u < 2; ++u) { \
+        const int i = wave + u * NW; \
+        if (i < NT && i >= k) part[u] += tile_mv(c.slot(i), false, x + 16 * k, o); \
+      } \
+      GSYNC(); \
+    } \
+  _Pragma("unroll") \
+    for (int u = 0; u < 2; ++u) { \
+      const int i = wave + u * NW; \
+      if (i < NT && o.lk() == 0) out[16 * i + o.lr()] = part[u] + beta * yv[16 * i + o.lr()]; \
+    } \
+    GSYNC(); \
+  }; \
+  auto stage_at_col = [&](int k, int slot0) { \
+  _Pragma("unroll 1") \
+    for (int i = wave; i < NT; i += NW) { \
+      double* s = c.slot(slot0 + i); \
+      if (i > k) st_tile(s, o, ldn(Lb + lt(i, k) * TS, lane)); \
+      else { \
+        v4d x = ldn(Wb + lt(k, i) * TS, lane); \
+  _Pragma("unroll") \
+        for (int r = 0; r < 4; ++r) x[r] *= -J; \
+        st_tile_t(s, o, x); \
+        if (i == k) { \
+          const v4d l = ldn(Lb + lt(k, k) * TS, lane); \
+          LWAIT(); \
+  _Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) s[o.cr[r]] += l[r]; \
+        } \
+      } \
+    } \
+  }; \
+  auto stage_cross = [&](const double* Sym, int k, int slot0) { \
+    const int i0 = wave, i1 = wave + NW; \
+    const bool h0 = i0 < NT, h1 = i1 < NT; \
+    const int c0 = h0 ? i0 : 0, c1 = h1 ? i1 : c0; \
+    const v4d a0 = ldn(Sym + (size_t)(c0 >= k ? lt(c0, k) : lt(k, c0)) * TS, lane); \
+    const v4d a1 = ldn(Sym + (size_t)(c1 >= k ? lt(c1, k) : lt(k, c1)) * TS, lane); \
+    if (h0) st_tile(c.slot(slot0 + i0), o, a0); \
+    if (h1) st_tile(c.slot(slot0 + i1), o, a1); \
+  }; \
+  [[maybe_unused]] const int R = g.Rv ? g.Rv[b] : g.R; \
+  [[maybe_unused]] const double* X = g.X + (g.xoff ? g.xoff[b] : (long)b * N * g.R); \
+  (void)ssq; (void)misc; (void)yv; (void)dv; (void)rs; (void)yd; (void)th; (void)mv; (void)av; (void)wv; (void)uv; (void)SA; \
+  (void)Lb; (void)Cb; (void)Wb; (void)Gb; (void)LamB; (void)Sb; (void)K1b; (void)K2b; (void)J; (void)o; \
+  (void)lower_matvec; (void)stage_at_col; (void)stage_cross
 
+__device__ __noinline__ void ph_setup(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // ---- member set-up ----
+  for (int t = tid; t < NP; t += NTH) {
+    const double nu = t < N ? GLD(g.nu[(long)b * N + t]) : 1.0;
+    const double y = t < N ? GLD(g.y[(long)b * N + t]) : 0.0;
+    yv[t] = y; dv[t] = 1.0 / nu; rs[t] = 1.0 / sqrt(nu); yd[t] = y / nu;
+    th[t] = 0; mv[t] = 0;
+    double sq = 0.0;
+    if (t < N)
+      for (int d = 0; d < R; ++d) { const double v = GLD(X[(long)t * R + d]); sq = fma(v, v, sq); }
+    ssq[t] = sq;
+  }
+  if (tid < 8) misc[tid] = tid < 2 ? 0.5413248546129181 /* softplus^-1(1) */ : 0.0;
+  {
+    int i = 0, j = 0;
+    unpack_step(i, j, wave);
 #pragma unroll 1
-  for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
-    const int R = g.Rv ? g.Rv[b] : g.R;                                   // (a ragged batch: this member's own realisation count)
-    const double* X = g.X + (g.xoff ? g.xoff[b] : (long)b * N * g.R);
-    int bad = 0;
-    // ---- member set-up ----
-    for (int t = tid; t < NP; t += NTH) {
-      const double nu = t < N ? GLD(g.nu[(long)b * N + t]) : 1.0;
-      const double y = t < N ? GLD(g.y[(long)b * N + t]) : 0.0;
-      yv[t] = y; dv[t] = 1.0 / nu; rs[t] = 1.0 / sqrt(nu); yd[t] = y / nu;
-      th[t] = 0; mv[t] = 0;
-      double sq = 0.0;
-      if (t < N)
-        for (int d = 0; d < R; ++d) { const double v = GLD(X[(long)t * R + d]); sq = fma(v, v, sq); }
-      ssq[t] = sq;
-    }
-    if (tid < 8) misc[tid] = tid < 2 ? 0.5413248546129181 /* softplus^-1(1) */ : 0.0;
-    {
-      int i = 0, j = 0;
-      unpack_step(i, j, wave);
-#pragma unroll 1
-      for (int p = wave; p < NTT; p += NW) {
-        v4d id;
+    for (int p = wave; p < NTT; p += NW) {
+      v4d id;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) id[r] = (i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0;
-        stn(LamB + (size_t)p * TS, lane, id);            // Lam = I: q_sqrt = I
-        stn(Sb + (size_t)p * TS, lane, id);              // S = I until the first natural-gradient step (n_iters = 0)
-        unpack_step(i, j, NW);
-      }
+      for (int r = 0; r < 4; ++r) id[r] = (i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0;
+      stn(LamB + (size_t)p * TS, lane, id);            // Lam = I: q_sqrt = I
+      stn(Sb + (size_t)p * TS, lane, id);              // S = I until the first natural-gradient step (n_iters = 0)
+      unpack_step(i, j, NW);
+    }
+  }
+  GSYNC();
+
+}
+
+__device__ __noinline__ void ph_kmat(KArgs g_in, int b_in, int keep, int zero_wv) {
+  MED_ENV(g_in, b_in);
+  auto refresh_hypers = [&]() {
+    if (tid == 0) {
+      const double ls = softplus_d(misc[1]);
+      misc[8] = softplus_d(misc[0]); misc[9] = ls; misc[10] = 1.0 / (ls * ls);
     }
     GSYNC();
-
-    auto refresh_hypers = [&]() {
-      if (tid == 0) {
-        const double ls = softplus_d(misc[1]);
-        misc[8] = softplus_d(misc[0]); misc[9] = ls; misc[10] = 1.0 / (ls * ls);
-      }
-      GSYNC();
-    };
-    // Lb <- tril(K0) + J I (identity in the padding)
-    // `keep`: the unit-variance kernel values (k1, k2) of every tile are parked in the scratch for this iteration's hyper-gradient
-    auto kmat = [&](bool keep) {
-      const double var = misc[8], inv_ls2 = misc[10];
-      int i = 0, j = 0;
-      unpack_step(i, j, wave);
+  };
+  // Lb <- tril(K0) + J I (identity in the padding)
+  // `keep`: the unit-variance kernel values (k1, k2) of every tile are parked in the scratch for this iteration's hyper-gradient
+  auto kmat = [&](bool keep) {
+    const double var = misc[8], inv_ls2 = misc[10];
+    int i = 0, j = 0;
+    unpack_step(i, j, wave);
 #pragma unroll 1
-      for (int p = wave; p < NTT; p += NW) {
-        const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
-        v4d kt, k1t, k2t;
+    for (int p = wave; p < NTT; p += NW) {
+      const v4d r2 = r2_tile(X, N, R, inv_ls2, ssq, i, j, o);
+      v4d kt, k1t, k2t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
+        double k1, k2;
+        kern_unit<true>(g.kernel, r2[r], k1, k2);
+        double K = var * k1;
+        if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
+        else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
+        kt[r] = K;
+        k1t[r] = (row < N && col < N) ? k1 : 0.0;         // (the padding contributes no gradient)
+        k2t[r] = (row < N && col < N) ? k2 : 0.0;
+      }
+      stn(Lb + (size_t)p * TS, lane, kt);
+      if (keep) { stn(K1b + (size_t)p * TS, lane, k1t); stn(K2b + (size_t)p * TS, lane, k2t); }
+      unpack_step(i, j, NW);
+    }
+    GSYNC();
+  };
+  refresh_hypers();
+  kmat(keep != 0);
+  if (zero_wv) {
+    for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
+    GSYNC();
+  }
+}
+
+__device__ __noinline__ void ph_neg_elbo(KArgs g_in, int b_in, int slot_in, int save_wv) {
+  MED_ENV(g_in, b_in);
+  // -ELBO sample (models.py:211-215) at the hypers whose factor L is in Lb, with the (m, S) of the last natural-gradient
+  // step (S in Sb, log det C in misc[11]):
+  //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + (|m|^2 - N + 2 log det C + tr S) / 2
+  // (L S L^T)_tt = sum_j (L S)_tj L_tj over the lower tiles of L S (a staged lower x symmetric product); uses av and wv
+  auto neg_elbo = [&](int slot) {
+    lower_matvec(Lb, mv, -1.0, av);                                      // av = L m - y
+    for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
+    GSYNC();
+    staged_product(c, NTT, false, 0, NT,
+      [&](int k) {
+#pragma unroll 1
+        for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lb + lt(i, k) * TS, lane));
+        stage_cross(Sb, k, NT);
+      },
+      [&](int k, int i, int j, v4d acc) {
+        if (k > i) return acc;
+        return mma_rt(acc, c.slot(i), false, c.slot(NT + j), j > k, o);   // L_ik S_kj ; S_kj = slot j as it lies for j <= k... see stage_cross
+      },
+      [&](int p, int i, int j, v4d acc) {
+        // row sums of (L S)_ij o L_ij, one 16-vector per tile, parked in Cb (dead here: Phi of the previous iteration) and
+        // added up below in a fixed order - no atomics, the sample is reproducible bit for bit
+        const v4d lt_ = ldn(Lb + lt(i, j) * TS, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
-          double k1, k2;
-          kern_unit<true>(g.kernel, r2[r], k1, k2);
-          double K = var * k1;
-          if (row >= N || col >= N) K = row == col ? 1.0 : 0.0;
-          else K = col <= row ? K + (row == col ? J : 0.0) : 0.0;
-          kt[r] = K;
-          k1t[r] = (row < N && col < N) ? k1 : 0.0;         // (the padding contributes no gradient)
-          k2t[r] = (row < N && col < N) ? k2 : 0.0;
+          double v = acc[r] * lt_[r];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          if (o.lr() == 0) GST(Cb[(size_t)p * 16 + o.kq(r)], v);
         }
-        stn(Lb + (size_t)p * TS, lane, kt);
-        if (keep) { stn(K1b + (size_t)p * TS, lane, k1t); stn(K2b + (size_t)p * TS, lane, k2t); }
-        unpack_step(i, j, NW);
-      }
-      GSYNC();
-    };
-    // out <- L x + beta y, L a scratch triangle: one staged pass over its block columns
-    auto lower_matvec = [&](const double* Lmat, const double* x, double beta, double* out) {
-      double part[2] = {0.0, 0.0};
-#pragma unroll 1
-      for (int k = 0; k < NT; ++k) {
-#pragma unroll 1
-        for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lmat + lt(i, k) * TS, lane));
-        GSYNC();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = wave + u * NW;
-          if (i < NT && i >= k) part[u] += tile_mv(c.slot(i), false, x + 16 * k, o);
-        }
-        GSYNC();
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = wave + u * NW;
-        if (i < NT && o.lk() == 0) out[16 * i + o.lr()] = part[u] + beta * yv[16 * i + o.lr()];
-      }
-      GSYNC();
-    };
-    // -ELBO sample (models.py:211-215) at the hypers whose factor L is in Lb, with the (m, S) of the last natural-gradient
-    // step (S in Sb, log det C in misc[11]):
-    //   sum_t [ log(2 pi)/2 + log(nu_t)/2 + ((y_t - (L m)_t)^2 + (L S L^T)_tt) / (2 nu_t) ] + (|m|^2 - N + 2 log det C + tr S) / 2
-    // (L S L^T)_tt = sum_j (L S)_tj L_tj over the lower tiles of L S (a staged lower x symmetric product); uses av and wv
-    auto neg_elbo = [&](int slot) {
-      lower_matvec(Lb, mv, -1.0, av);                                      // av = L m - y
-      for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
-      GSYNC();
-      staged_product(c, NTT, false, 0, NT,
-        [&](int k) {
-#pragma unroll 1
-          for (int i = k + wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Lb + lt(i, k) * TS, lane));
-          stage_cross(Sb, k, NT);
-        },
-        [&](int k, int i, int j, v4d acc) {
-          if (k > i) return acc;
-          return mma_rt(acc, c.slot(i), false, c.slot(NT + j), j > k, o);   // L_ik S_kj ; S_kj = slot j as it lies for j <= k... see stage_cross
-        },
-        [&](int p, int i, int j, v4d acc) {
-          // row sums of (L S)_ij o L_ij, one 16-vector per tile, parked in Cb (dead here: Phi of the previous iteration) and
-          // added up below in a fixed order - no atomics, the sample is reproducible bit for bit
-          const v4d lt_ = ldn(Lb + lt(i, j) * TS, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double v = acc[r] * lt_[r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (o.lr() == 0) GST(Cb[(size_t)p * 16 + o.kq(r)], v);
-          }
-        });
-      GSYNC();
-      for (int t = tid; t < NP; t += NTH) {
-        const int i = t >> 4;
-        double f = 0.0;
-        for (int j = 0; j <= i; ++j) f += GLD(Cb[(size_t)lt(i, j) * 16 + (t & 15)]);
-        wv[t] = f;
-      }
-      GSYNC();
-      double part = 0.0;
-      for (int t = tid; t < N; t += NTH) {
-        const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
-        const double stt = GLD(Sb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
-        part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
-      }
-      part = wave_sum(part);
-      if (lane == 0) misc[16 + wave] = part;
-      GSYNC();
-      if (tid == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += misc[16 + w];
-        GST(g.loss[(long)b * g.loss_stride + slot], tot - 0.5 * N + misc[11]);
-      }
-      GSYNC();
-    };
-
-    [[maybe_unused]] int it_now = 0;
-#pragma unroll 1
-    for (int it = 0; it < g.n_iters; ++it) {
-      it_now = it;
-      MSTAMP(0);
-      refresh_hypers();
-      kmat(true);                                                          // K0 + J I at the current hypers  (models.py:209)
-      MSTAMP(1);
-      // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L and L^T (y / nu) accumulate block row by block row behind it
-      for (int t = tid; t < NP; t += NTH) wv[t] = 0.0;
-      GSYNC();
-      bad = potrf_v2<true, 1>(pargs(Lb, Wb, Gb), bad);
-      if (g.loss && it > 0 && (it - 1) % 25 == 0) {                         // after the Adam step = at these hypers
-        for (int t = tid; t < NP; t += NTH) uv[t] = wv[t];                  // (the sample uses wv as scratch: keep L^T (y / nu) aside)
-        GSYNC();
-        neg_elbo((it - 1) / 25);
-        for (int t = tid; t < NP; t += NTH) wv[t] = uv[t];
-        GSYNC();
-      }
-      MSTAMP(2);
-      // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G) -> LamB and Cb; theta1 <- (1-g) theta1 + g L^T (y / nu)
-      {
-        int i = 0, j = 0;
-        unpack_step(i, j, wave);
-#pragma unroll 1
-        for (int p = wave; p < NTT; p += NW) {
-          v4d lam = ldn(LamB + (size_t)p * TS, lane);
-          const v4d gt = ldn(Gb + (size_t)p * TS, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            lam[r] = (1.0 - g.gamma) * lam[r] + g.gamma * (gt[r] + ((i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0));
-          stn(LamB + (size_t)p * TS, lane, lam);
-          stn(Cb + (size_t)p * TS, lane, lam);
-          unpack_step(i, j, NW);
-        }
-      }
-      for (int t = tid; t < NP; t += NTH) th[t] = (1.0 - g.gamma) * th[t] + g.gamma * wv[t];
-      GSYNC();
-      MSTAMP(3);
-      // C = chol(Lam) in Cb, C^-1 in Lb (L is dead); S = C^-T C^-1 accumulates into Sb behind it
-      bad = potrf_v2<true, 2>(pargs(Cb, Lb, Sb), bad);
-      MSTAMP(4);
-      if (g.loss && it % 25 == 0) {                                         // log det C of this step, for its loss sample
-        double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
-        s = wave_sum(s);
-        if (lane == 0) misc[32 + wave] = s;
-        GSYNC();
-        if (tid == 0) {
-          double tot = 0.0;
-          for (int w = 0; w < NW; ++w) tot += misc[32 + w];
-          misc[11] = tot;
-        }
-        GSYNC();
-      }
-      // ---- m = C^-T (C^-1 theta1) through the inverse FACTOR (Lb), not S theta1: see small.hip - with a variance of ~1e-11 at
-      // one time step the rounding of the explicit S puts 1e-5 into m, which u = G m - L^T (y / nu) multiplies by |G| ~ 1e11.
-      lower_matvec(Lb, th, 0.0, uv);                                        // z = C^-1 theta1 (one pass over the block columns)
-      {
-        double part[2] = {0.0, 0.0};
-#pragma unroll 1
-        for (int k = 0; k < NT; ++k) {                                      // m_j = sum_{k >= j} X_kj^T z_k: one pass over the block rows
-#pragma unroll 1
-          for (int j = wave; j <= k; j += NW) st_tile(c.slot(j), o, ldn(Lb + lt(k, j) * TS, lane));
-          GSYNC();
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = wave + u * NW;
-            if (j < NT && j <= k) part[u] += tile_mv(c.slot(j), true, uv + 16 * k, o);
-          }
-          GSYNC();
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = wave + u * NW;
-          if (i < NT && o.lk() == 0) mv[16 * i + o.lr()] = part[u];
-        }
-        GSYNC();
-      }
-      MSTAMP(5);
-      // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal -> Cb (C is dead).  u = L^T D (L m - y) = G m - L^T (y / nu) comes
-      // out of the same pass (the crosses of G are in LDS anyway) and, like m, enters Phi only in the epilogue.
-      if (it == 0 && g.gamma > 0.0) {
-        // First iteration: Lam_old = I exactly, so Lam = I + gamma G, G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma and
-        // u = G m - L^T (y / nu) = (Lam m - m) / gamma - theta1 / gamma = -m / gamma: no product, one pass over the tiles of S.
-        // (not (theta1 - m) / gamma - L^T (y / nu): with |theta1| ~ 1e11 that difference rounds m away)
-        for (int t = tid; t < NP; t += NTH) uv[t] = -mv[t] / g.gamma;
-        GSYNC();
-        int i = 0, j = 0;
-        unpack_step(i, j, wave);
-#pragma unroll 1
-        for (int p = wave; p < NTT; p += NW) {
-          v4d a = ldn(Sb + (size_t)p * TS, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = o.kq(r);
-            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], (((i == j && rl == o.lr()) ? 1.0 : 0.0) - a[r]) / g.gamma);
-            if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
-            a[r] = v;
-          }
-          stn(Cb + (size_t)p * TS, lane, a);
-          unpack_step(i, j, NW);
-        }
-        GSYNC();
-      } else {
-        double gm[2] = {0.0, 0.0};
-#pragma unroll 1
-        for (int base = 0; base < NTT; base += PASS_TILES) {
-          v4d acc[TPW];
-          int ti[TPW], tj[TPW];
-#pragma unroll
-          for (int s = 0; s < TPW; ++s) {
-            acc[s] = v4d{0, 0, 0, 0};
-            const int p = base + wave + s * NW;
-            int i = 0, j = 0;
-            if (p < NTT) unpack_step(i, j, p);
-            ti[s] = p < NTT ? i : -1;
-            tj[s] = j;
-          }
-#pragma unroll 1
-          for (int k = 0; k < NT; ++k) {
-            stage_cross(Gb, k, 0);
-            stage_cross(Sb, k, NT);
-            GSYNC();
-#pragma unroll
-            for (int s = 0; s < TPW; ++s)
-              if (ti[s] >= 0)                                              // G_ik S_kj
-                acc[s] = mma_rt(acc[s], c.slot(ti[s]), ti[s] < k, c.slot(NT + tj[s]), tj[s] > k, o);
-            if (base == 0) {
-#pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                const int i = wave + u * NW;
-                if (i < NT) gm[u] += tile_mv(c.slot(i), i < k, mv + 16 * k, o);
-              }
-            }
-            GSYNC();
-          }
-          if (base == 0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int i = wave + u * NW;
-              if (i < NT && o.lk() == 0) uv[16 * i + o.lr()] = gm[u] - wv[16 * i + o.lr()];
-            }
-            GSYNC();
-          }
-#pragma unroll
-          for (int s = 0; s < TPW; ++s)
-            if (ti[s] >= 0) {
-              const int i = ti[s], j = tj[s];
-              v4d a = acc[s];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int rl = o.kq(r);
-                double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], a[r]);
-                if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
-                a[r] = v;
-              }
-              stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, a);
-            }
-        }
-        GSYNC();
-      }
-      MSTAMP(6);
-      // ---- W = Phi L^-1 (lower; Phi in Cb, L^-1 in Wb) -> Lb (C^-1 is dead): W_ij = sum_{k = j..i} Phi_ik Linv_kj
-      staged_product(c, NTT, false, 0, NT,
-        [&](int k) {
-#pragma unroll 1
-          for (int q = wave; q < NT + 1; q += NW) {
-            if (q < NT - k) st_tile(c.slot(k + q), o, ldn(Cb + lt(k + q, k) * TS, lane));               // Phi_ik, i >= k -> slot i
-            else st_tile(c.slot(NT + (q - (NT - k))), o, ldn(Wb + lt(k, q - (NT - k)) * TS, lane));      // Linv_kj, j <= k -> slot NT + j
-          }
-        },
-        [&](int k, int i, int j, v4d acc) {
-          if (k < j || k > i) return acc;
-          return mma_rt(acc, c.slot(i), false, c.slot(NT + j), false, o);
-        },
-        [&](int p, int, int, v4d acc) { stn(Lb + (size_t)p * TS, lane, acc); });
-      MSTAMP(7);
-      // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric: Kbar_ij and Kbar_ji^T
-      // = sum_k W_ki^T Linv_kj are accumulated together and the kernel function is evaluated once per unordered pair
-      {
-        const double var = misc[8], ls = misc[9];
-        double gv = 0.0, gl = 0.0;
-        staged_product(c, NTT, false, 0, NT,
-          [&](int k) {
-#pragma unroll 1
-            for (int q = wave; q < 2 * (k + 1); q += NW) {
-              if (q <= k) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));                          // Linv_kj -> slot j
-              else st_tile(c.slot(NT + q - (k + 1)), o, ldn(Lb + lt(k, q - (k + 1)) * TS, lane));        // W_kj -> slot NT + j
-            }
-          },
-          [&](int k, int i, int j, v4d acc) {
-            if (k < i) return acc;
-            acc = mma_rt(acc, c.slot(i), true, c.slot(NT + j), false, o);                                // Linv_ki^T W_kj
-            if (i != j) acc = mma_rt(acc, c.slot(NT + i), true, c.slot(j), false, o);                    // W_ki^T Linv_kj
-            return acc;
-          },
-          [&](int p, int, int, v4d acc) {
-            // <Kbar, k1>, <Kbar, k2> with the kernel values this iteration's kmat parked (zero in the padding)
-            const v4d k1t = ldn(K1b + (size_t)p * TS, lane), k2t = ldn(K2b + (size_t)p * TS, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { gv = fma(acc[r], k1t[r], gv); gl = fma(acc[r], k2t[r], gl); }
-          });
-        gv = wave_sum(gv);
-        gl = wave_sum(gl);
-        if (lane == 0) { misc[16 + wave] = gv; misc[24 + wave] = gl; }
-        GSYNC();
-        if (tid == 0) {
-          double sv = 0.0, sl = 0.0;
-          for (int w = 0; w < NW; ++w) { sv += misc[16 + w]; sl += misc[24 + w]; }
-          double* u = misc;
-          double gg[2];
-          gg[0] = sv * (1.0 - exp(-var));
-          gg[1] = sl * (kern_cl(g.kernel) * var / ls) * (1.0 - exp(-ls));
-          const double t = u[6] + 1.0;
-          u[6] = t;
-          const double lr_t = g.lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t));
-          for (int q = 0; q < 2; ++q) {               // TF-2.8 Keras Adam (models.py:192)
-            u[2 + q] = 0.9 * u[2 + q] + 0.1 * gg[q];
-            u[4 + q] = 0.999 * u[4 + q] + 0.001 * gg[q] * gg[q];
-            u[q] -= lr_t * u[2 + q] / (sqrt(u[4 + q]) + 1e-7);
-          }
-        }
-        GSYNC();
-      }
-      MSTAMP(8);
+      });
+    GSYNC();
+    for (int t = tid; t < NP; t += NTH) {
+      const int i = t >> 4;
+      double f = 0.0;
+      for (int j = 0; j <= i; ++j) f += GLD(Cb[(size_t)lt(i, j) * 16 + (t & 15)]);
+      wv[t] = f;
     }
+    GSYNC();
+    double part = 0.0;
+    for (int t = tid; t < N; t += NTH) {
+      const double nu = 1.0 / dv[t], a = av[t], m = mv[t];
+      const double stt = GLD(Sb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]);
+      part += 0.5 * 1.8378770664093453 + 0.5 * log(nu) + 0.5 * (a * a + wv[t]) * dv[t] + 0.5 * (m * m + stt);
+    }
+    part = wave_sum(part);
+    if (lane == 0) misc[16 + wave] = part;
+    GSYNC();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < NW; ++w) tot += misc[16 + w];
+      GST(g.loss[(long)b * g.loss_stride + slot], tot - 0.5 * N + misc[11]);
+    }
+    GSYNC();
+  };
 
-    // ---- prediction at the final hypers with the (m, S) of the last step    (models.py:217-220)
-    it_now = g.n_iters;
-    MSTAMP(9);
-    refresh_hypers();
-    kmat(false);
-    bad = potrf_v2<true, 0>(pargs(Lb, Wb, Gb), bad);                            // Lb = L, Wb = L^-1, Sb = S
-    if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) neg_elbo((g.n_iters - 1) / 25);
-    MSTAMP(10);
-    // A^T = K0 L^-T = L - J L^-T.  Its block column k as NT explicit LDS tiles (slot0 + i = A^T(i, k)):
-    // L_ik below the diagonal, -J Linv_ki^T above it, L_kk - J Linv_kk^T on it
-    auto stage_at_col = [&](int k, int slot0) {
+  const int slot = uni(slot_in);
+  if (save_wv) {                                                        // (the sample uses wv as scratch: keep L^T (y / nu) aside)
+    for (int t = tid; t < NP; t += NTH) uv[t] = wv[t];
+    GSYNC();
+  }
+  neg_elbo(slot);
+  if (save_wv) {
+    for (int t = tid; t < NP; t += NTH) wv[t] = uv[t];
+    GSYNC();
+  }
+}
+
+__device__ __noinline__ void ph_natgrad(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // ---- natural-gradient step: Lam <- (1-g) Lam + g (I + G) -> LamB and Cb; theta1 <- (1-g) theta1 + g L^T (y / nu)
+  {
+    int i = 0, j = 0;
+    unpack_step(i, j, wave);
 #pragma unroll 1
-      for (int i = wave; i < NT; i += NW) {
-        double* s = c.slot(slot0 + i);
-        if (i > k) st_tile(s, o, ldn(Lb + lt(i, k) * TS, lane));
-        else {
-          v4d x = ldn(Wb + lt(k, i) * TS, lane);
+    for (int p = wave; p < NTT; p += NW) {
+      v4d lam = ldn(LamB + (size_t)p * TS, lane);
+      const v4d gt = ldn(Gb + (size_t)p * TS, lane);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] *= -J;
-          st_tile_t(s, o, x);
-          if (i == k) {                                                    // (+ L_kk: elementwise on the same LDS tile, same wave)
-            const v4d l = ldn(Lb + lt(k, k) * TS, lane);
-            LWAIT();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[o.cr[r]] += l[r];
-          }
-        }
-      }
-    };
-    // mu = A^T m
-    {
-      double part[2] = {0.0, 0.0};
+      for (int r = 0; r < 4; ++r)
+        lam[r] = (1.0 - g.gamma) * lam[r] + g.gamma * (gt[r] + ((i == j && o.kq(r) == o.lr()) ? 1.0 : 0.0));
+      stn(LamB + (size_t)p * TS, lane, lam);
+      stn(Cb + (size_t)p * TS, lane, lam);
+      unpack_step(i, j, NW);
+    }
+  }
+  for (int t = tid; t < NP; t += NTH) th[t] = (1.0 - g.gamma) * th[t] + g.gamma * wv[t];
+  GSYNC();
+}
+
+__device__ __noinline__ void ph_logdet_c(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  double s = 0.0;
+  for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
+  s = wave_sum(s);
+  if (lane == 0) misc[32 + wave] = s;
+  GSYNC();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < NW; ++w) tot += misc[32 + w];
+    misc[11] = tot;
+  }
+  GSYNC();
+}
+
+__device__ __noinline__ void ph_m(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // ---- m = C^-T (C^-1 theta1) through the inverse FACTOR (Lb), not S theta1: see small.hip - with a variance of ~1e-11 at
+  // one time step the rounding of the explicit S puts 1e-5 into m, which u = G m - L^T (y / nu) multiplies by |G| ~ 1e11.
+  lower_matvec(Lb, th, 0.0, uv);                                        // z = C^-1 theta1 (one pass over the block columns)
+  {
+    double part[2] = {0.0, 0.0};
 #pragma unroll 1
-      for (int k = 0; k < NT; ++k) {
-        stage_at_col(k, 0);
-        GSYNC();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = wave + u * NW;
-          if (i < NT) part[u] += tile_mv(c.slot(i), false, mv + 16 * k, o);
-        }
-        GSYNC();
-      }
+    for (int k = 0; k < NT; ++k) {                                      // m_j = sum_{k >= j} X_kj^T z_k: one pass over the block rows
+#pragma unroll 1
+      for (int j = wave; j <= k; j += NW) st_tile(c.slot(j), o, ldn(Lb + lt(k, j) * TS, lane));
+      GSYNC();
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int i = wave + u * NW;
-        if (i < NT && o.lk() == 0) av[16 * i + o.lr()] = part[u];              // av = mu (padded part 0)
+        const int j = wave + u * NW;
+        if (j < NT && j <= k) part[u] += tile_mv(c.slot(j), true, uv + 16 * k, o);
       }
       GSYNC();
     }
-    // E = A^T S, all NT x NT tiles -> the square buffer at Gb (G and Lam are dead): E_il = sum_k A^T(i, k) S_kl
-    double* Eb = Gb;
-    staged_product(c, NT * NT, true, 0, NT,
-      [&](int k) { stage_at_col(k, 0); stage_cross(Sb, k, NT); },
-      [&](int k, int i, int l, v4d acc) { return mma_rt(acc, c.slot(i), false, c.slot(NT + l), l > k, o); },
-      [&](int p, int, int, v4d acc) { stn(Eb + (size_t)p * TS, lane, acc); });
-    // cov = diag(nu + J) - J^2 L^-T L^-1 + E A: lower tiles (i, j): -J^2 sum_{k >= i} Linv_ki^T Linv_kj, then sum_l E_il A^T(j, l)^T.
-    // The finished tiles go, bordered by the rows (1^T, mu^T) in the padding, into Cb for the factorisation that follows.
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = wave + u * NW;
+      if (i < NT && o.lk() == 0) mv[16 * i + o.lr()] = part[u];
+    }
+    GSYNC();
+  }
+}
+
+__device__ __noinline__ void ph_phi(KArgs g_in, int b_in, int first_in) {
+  MED_ENV(g_in, b_in);
+  const int first = uni(first_in);
+  // ---- Phi(L^T Lbar) = tril(u m^T + G S), half the diagonal -> Cb (C is dead).  u = L^T D (L m - y) = G m - L^T (y / nu) comes
+  // out of the same pass (the crosses of G are in LDS anyway) and, like m, enters Phi only in the epilogue.
+  if (first && g.gamma > 0.0) {
+    // First iteration: Lam_old = I exactly, so Lam = I + gamma G, G S = (Lam - I) Lam^-1 / gamma = (I - S) / gamma and
+    // u = G m - L^T (y / nu) = (Lam m - m) / gamma - theta1 / gamma = -m / gamma: no product, one pass over the tiles of S.
+    // (not (theta1 - m) / gamma - L^T (y / nu): with |theta1| ~ 1e11 that difference rounds m away)
+    for (int t = tid; t < NP; t += NTH) uv[t] = -mv[t] / g.gamma;
+    GSYNC();
+    int i = 0, j = 0;
+    unpack_step(i, j, wave);
+#pragma unroll 1
+    for (int p = wave; p < NTT; p += NW) {
+      v4d a = ldn(Sb + (size_t)p * TS, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = o.kq(r);
+        double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], (((i == j && rl == o.lr()) ? 1.0 : 0.0) - a[r]) / g.gamma);
+        if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
+        a[r] = v;
+      }
+      stn(Cb + (size_t)p * TS, lane, a);
+      unpack_step(i, j, NW);
+    }
+    GSYNC();
+  } else {
+    double gm[2] = {0.0, 0.0};
 #pragma unroll 1
     for (int base = 0; base < NTT; base += PASS_TILES) {
       v4d acc[TPW];
@@ -931,105 +783,332 @@ __global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs g) {
         tj[s] = j;
       }
 #pragma unroll 1
-      for (int k = 0; k < NT; ++k) {                                       // block row k of L^-1 -> slots j <= k
-#pragma unroll 1
-        for (int q = wave; q <= k; q += NW) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));
+      for (int k = 0; k < NT; ++k) {
+        stage_cross(Gb, k, 0);
+        stage_cross(Sb, k, NT);
         GSYNC();
 #pragma unroll
         for (int s = 0; s < TPW; ++s)
-          if (ti[s] >= 0 && k >= ti[s]) acc[s] = mma_rt(acc[s], c.slot(ti[s]), true, c.slot(tj[s]), false, o);
+          if (ti[s] >= 0)                                              // G_ik S_kj
+            acc[s] = mma_rt(acc[s], c.slot(ti[s]), ti[s] < k, c.slot(NT + tj[s]), tj[s] > k, o);
+        if (base == 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = wave + u * NW;
+            if (i < NT) gm[u] += tile_mv(c.slot(i), i < k, mv + 16 * k, o);
+          }
+        }
         GSYNC();
       }
+      if (base == 0) {
 #pragma unroll
-      for (int s = 0; s < TPW; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[s][r] *= -J * J;
-#pragma unroll 1
-      for (int l = 0; l < NT; ++l) {                                       // block column l of E (slots i) and of A^T (slots NT + j)
-#pragma unroll 1
-        for (int i = wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Eb + (size_t)(i * NT + l) * TS, lane));
-        stage_at_col(l, NT);
-        GSYNC();
-#pragma unroll
-        for (int s = 0; s < TPW; ++s)
-          if (ti[s] >= 0) acc[s] = mma_rt(acc[s], c.slot(ti[s]), false, c.slot(NT + tj[s]), true, o);
+        for (int u = 0; u < 2; ++u) {
+          const int i = wave + u * NW;
+          if (i < NT && o.lk() == 0) uv[16 * i + o.lr()] = gm[u] - wv[16 * i + o.lr()];
+        }
         GSYNC();
       }
 #pragma unroll
       for (int s = 0; s < TPW; ++s)
         if (ti[s] >= 0) {
           const int i = ti[s], j = tj[s];
-          v4d a = acc[s], t;
+          v4d a = acc[s];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
-            if (row == col) a[r] = a[r] + (1.0 / dv[row] + J);
-            t[r] = a[r];
-            if (row < N && col < N) {
-              // (a diagonal tile is a full 16x16 accumulation: its lower half is exported and mirrored, so that cov is exactly symmetric)
-              if (g.cov && (i != j || col <= row)) {
-                GST(g.cov[((long)b * N + row) * N + col], a[r]);
-                GST(g.cov[((long)b * N + col) * N + row], a[r]);
-              }
-              if (g.var && row == col) GST(g.var[(long)b * N + row], a[r]);
-            } else {
-              // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
-              double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
-              if (col < N && row == N) v = 1.0;
-              if (col < N && row == N + 1) v = av[col];
-              t[r] = v;
-            }
+            const int rl = o.kq(r);
+            double v = fma(uv[16 * i + rl], mv[16 * j + o.lr()], a[r]);
+            if (i == j) v = rl < o.lr() ? 0.0 : (rl == o.lr() ? 0.5 * v : v);
+            a[r] = v;
           }
-          stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, t);
+          stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, a);
         }
     }
-    if (g.mu)
-      for (int t = tid; t < N; t += NTH) GST(g.mu[(long)b * N + t], av[t]);
     GSYNC();
-    MSTAMP(11);
-    if (g.chol || g.logdet || g.basis) {
-      bad = potrf_v2<false, 0>(pargs(Cb, Cb, Gb), bad);                       // Distribution.__post_init__ (data.py:38-39)
-      if (g.chol) {
-        // every tile (i, j) of the N x N factor, the tiles dealt over the waves: the lower ones are read as they lie in the scratch (one
-        // coalesced 2 KB load), the upper ones are zeros; a wave instruction stores four 128-byte row segments
-        int i = 0, j = wave;
-        while (j >= NT) { j -= NT; ++i; }
+  }
+}
+
+__device__ __noinline__ void ph_w(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // ---- W = Phi L^-1 (lower; Phi in Cb, L^-1 in Wb) -> Lb (C^-1 is dead): W_ij = sum_{k = j..i} Phi_ik Linv_kj
+  staged_product(c, NTT, false, 0, NT,
+    [&](int k) {
 #pragma unroll 1
-        for (int p = wave; p < NT * NT; p += NW) {
-          v4d t = {0, 0, 0, 0};
-          if (j <= i) t = ldn(Cb + (size_t)lt(i, j) * TS, lane);
+      for (int q = wave; q < NT + 1; q += NW) {
+        if (q < NT - k) st_tile(c.slot(k + q), o, ldn(Cb + lt(k + q, k) * TS, lane));               // Phi_ik, i >= k -> slot i
+        else st_tile(c.slot(NT + (q - (NT - k))), o, ldn(Wb + lt(k, q - (NT - k)) * TS, lane));      // Linv_kj, j <= k -> slot NT + j
+      }
+    },
+    [&](int k, int i, int j, v4d acc) {
+      if (k < j || k > i) return acc;
+      return mma_rt(acc, c.slot(i), false, c.slot(NT + j), false, o);
+    },
+    [&](int p, int, int, v4d acc) { stn(Lb + (size_t)p * TS, lane, acc); });
+}
+
+__device__ __noinline__ void ph_kbar_adam(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // ---- Kbar = L^-T W ; g = <Kbar, dK/dtheta> over the real part ; Adam   (models.py:210).  dK is symmetric: Kbar_ij and Kbar_ji^T
+  // = sum_k W_ki^T Linv_kj are accumulated together and the kernel function is evaluated once per unordered pair
+  {
+    const double var = misc[8], ls = misc[9];
+    double gv = 0.0, gl = 0.0;
+    staged_product(c, NTT, false, 0, NT,
+      [&](int k) {
+#pragma unroll 1
+        for (int q = wave; q < 2 * (k + 1); q += NW) {
+          if (q <= k) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));                          // Linv_kj -> slot j
+          else st_tile(c.slot(NT + q - (k + 1)), o, ldn(Lb + lt(k, q - (k + 1)) * TS, lane));        // W_kj -> slot NT + j
+        }
+      },
+      [&](int k, int i, int j, v4d acc) {
+        if (k < i) return acc;
+        acc = mma_rt(acc, c.slot(i), true, c.slot(NT + j), false, o);                                // Linv_ki^T W_kj
+        if (i != j) acc = mma_rt(acc, c.slot(NT + i), true, c.slot(j), false, o);                    // W_ki^T Linv_kj
+        return acc;
+      },
+      [&](int p, int, int, v4d acc) {
+        // <Kbar, k1>, <Kbar, k2> with the kernel values this iteration's kmat parked (zero in the padding)
+        const v4d k1t = ldn(K1b + (size_t)p * TS, lane), k2t = ldn(K2b + (size_t)p * TS, lane);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
-            if (row < N && col < N) GST(g.chol[((long)b * N + row) * N + col], col <= row ? t[r] : 0.0);
-          }
-          j += NW;
-          while (j >= NT) { j -= NT; ++i; }
-        }
-      }
-      if (g.basis) {
-        for (int e = tid; e < 2 * N; e += NTH) {
-          const int which = e >= N ? 1 : 0, cc = e - which * N, row = N + which;
-          GST(g.basis[((long)b * 2 + which) * N + cc], GLD(Cb[lt(row >> 4, cc >> 4) * TS + nidx(row & 15, cc & 15)]));
-        }
-      }
-      if (g.logdet) {
-        double s = 0.0;
-        for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
-        s = wave_sum(s);
-        if (lane == 0) misc[16 + wave] = s;
-        GSYNC();
-        if (tid == 0) {
-          double tot = 0.0;
-          for (int w = 0; w < NW; ++w) tot += misc[16 + w];
-          GST(g.logdet[b], tot);
-        }
+        for (int r = 0; r < 4; ++r) { gv = fma(acc[r], k1t[r], gv); gl = fma(acc[r], k2t[r], gl); }
+      });
+    gv = wave_sum(gv);
+    gl = wave_sum(gl);
+    if (lane == 0) { misc[16 + wave] = gv; misc[24 + wave] = gl; }
+    GSYNC();
+    if (tid == 0) {
+      double sv = 0.0, sl = 0.0;
+      for (int w = 0; w < NW; ++w) { sv += misc[16 + w]; sl += misc[24 + w]; }
+      double* u = misc;
+      double gg[2];
+      gg[0] = sv * (1.0 - exp(-var));
+      gg[1] = sl * (kern_cl(g.kernel) * var / ls) * (1.0 - exp(-ls));
+      const double t = u[6] + 1.0;
+      u[6] = t;
+      const double lr_t = g.lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t));
+      for (int q = 0; q < 2; ++q) {               // TF-2.8 Keras Adam (models.py:192)
+        u[2 + q] = 0.9 * u[2 + q] + 0.1 * gg[q];
+        u[4 + q] = 0.999 * u[4 + q] + 0.001 * gg[q] * gg[q];
+        u[q] -= lr_t * u[2 + q] / (sqrt(u[4 + q]) + 1e-7);
       }
     }
-    if (tid == 0 && g.hyp) { GST(g.hyp[(long)b * 2], misc[8]); GST(g.hyp[(long)b * 2 + 1], misc[9]); }
-    if (wave == 0 && lane == 0) GST(g.info[b], bad);
+    GSYNC();
+  }
+}
+
+__device__ __noinline__ void ph_mu_e(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  // mu = A^T m
+  {
+    double part[2] = {0.0, 0.0};
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {
+      stage_at_col(k, 0);
+      GSYNC();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = wave + u * NW;
+        if (i < NT) part[u] += tile_mv(c.slot(i), false, mv + 16 * k, o);
+      }
+      GSYNC();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = wave + u * NW;
+      if (i < NT && o.lk() == 0) av[16 * i + o.lr()] = part[u];              // av = mu (padded part 0)
+    }
+    GSYNC();
+  }
+  // E = A^T S, all NT x NT tiles -> the square buffer at Gb (G and Lam are dead): E_il = sum_k A^T(i, k) S_kl
+  double* Eb = Gb;
+  staged_product(c, NT * NT, true, 0, NT,
+    [&](int k) { stage_at_col(k, 0); stage_cross(Sb, k, NT); },
+    [&](int k, int i, int l, v4d acc) { return mma_rt(acc, c.slot(i), false, c.slot(NT + l), l > k, o); },
+    [&](int p, int, int, v4d acc) { stn(Eb + (size_t)p * TS, lane, acc); });
+}
+
+__device__ __noinline__ void ph_cov(KArgs g_in, int b_in) {
+  MED_ENV(g_in, b_in);
+  double* Eb = Gb;
+  // cov = diag(nu + J) - J^2 L^-T L^-1 + E A: lower tiles (i, j): -J^2 sum_{k >= i} Linv_ki^T Linv_kj, then sum_l E_il A^T(j, l)^T.
+  // The finished tiles go, bordered by the rows (1^T, mu^T) in the padding, into Cb for the factorisation that follows.
+#pragma unroll 1
+  for (int base = 0; base < NTT; base += PASS_TILES) {
+    v4d acc[TPW];
+    int ti[TPW], tj[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      acc[s] = v4d{0, 0, 0, 0};
+      const int p = base + wave + s * NW;
+      int i = 0, j = 0;
+      if (p < NTT) unpack_step(i, j, p);
+      ti[s] = p < NTT ? i : -1;
+      tj[s] = j;
+    }
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {                                       // block row k of L^-1 -> slots j <= k
+#pragma unroll 1
+      for (int q = wave; q <= k; q += NW) st_tile(c.slot(q), o, ldn(Wb + lt(k, q) * TS, lane));
+      GSYNC();
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+        if (ti[s] >= 0 && k >= ti[s]) acc[s] = mma_rt(acc[s], c.slot(ti[s]), true, c.slot(tj[s]), false, o);
+      GSYNC();
+    }
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[s][r] *= -J * J;
+#pragma unroll 1
+    for (int l = 0; l < NT; ++l) {                                       // block column l of E (slots i) and of A^T (slots NT + j)
+#pragma unroll 1
+      for (int i = wave; i < NT; i += NW) st_tile(c.slot(i), o, ldn(Eb + (size_t)(i * NT + l) * TS, lane));
+      stage_at_col(l, NT);
+      GSYNC();
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+        if (ti[s] >= 0) acc[s] = mma_rt(acc[s], c.slot(ti[s]), false, c.slot(NT + tj[s]), true, o);
+      GSYNC();
+    }
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+      if (ti[s] >= 0) {
+        const int i = ti[s], j = tj[s];
+        v4d a = acc[s], t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
+          if (row == col) a[r] = a[r] + (1.0 / dv[row] + J);
+          t[r] = a[r];
+          if (row < N && col < N) {
+            // (a diagonal tile is a full 16x16 accumulation: its lower half is exported and mirrored, so that cov is exactly symmetric)
+            if (g.cov && (i != j || col <= row)) {
+              GST(g.cov[((long)b * N + row) * N + col], a[r]);
+              GST(g.cov[((long)b * N + col) * N + row], a[r]);
+            }
+            if (g.var && row == col) GST(g.var[(long)b * N + row], a[r]);
+          } else {
+            // bordered matrix for chol(cov): rows N (1^T) and N+1 (mu^T) in the padding, huge pivots there, identity elsewhere
+            double v = row == col ? ((row == N || row == N + 1) ? 1e30 : 1.0) : 0.0;
+            if (col < N && row == N) v = 1.0;
+            if (col < N && row == N + 1) v = av[col];
+            t[r] = v;
+          }
+        }
+        stn(Cb + (size_t)(base + wave + s * NW) * TS, lane, t);
+      }
+  }
+  if (g.mu)
+    for (int t = tid; t < N; t += NTH) GST(g.mu[(long)b * N + t], av[t]);
+  GSYNC();
+}
+
+__device__ __noinline__ void ph_export(KArgs g_in, int b_in, int factored, int bad_in) {
+  MED_ENV(g_in, b_in);
+  if (factored) {
+    if (g.chol) {
+      // every tile (i, j) of the N x N factor, the tiles dealt over the waves: the lower ones are read as they lie in the scratch (one
+      // coalesced 2 KB load), the upper ones are zeros; a wave instruction stores four 128-byte row segments
+      int i = 0, j = wave;
+      while (j >= NT) { j -= NT; ++i; }
+  #pragma unroll 1
+      for (int p = wave; p < NT * NT; p += NW) {
+        v4d t = {0, 0, 0, 0};
+        if (j <= i) t = ldn(Cb + (size_t)lt(i, j) * TS, lane);
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * i + o.kq(r), col = 16 * j + o.lr();
+          if (row < N && col < N) GST(g.chol[((long)b * N + row) * N + col], col <= row ? t[r] : 0.0);
+        }
+        j += NW;
+        while (j >= NT) { j -= NT; ++i; }
+      }
+    }
+    if (g.basis) {
+      for (int e = tid; e < 2 * N; e += NTH) {
+        const int which = e >= N ? 1 : 0, cc = e - which * N, row = N + which;
+        GST(g.basis[((long)b * 2 + which) * N + cc], GLD(Cb[lt(row >> 4, cc >> 4) * TS + nidx(row & 15, cc & 15)]));
+      }
+    }
+    if (g.logdet) {
+      double s = 0.0;
+      for (int t = tid; t < N; t += NTH) s += log(GLD(Cb[lt(t >> 4, t >> 4) * TS + nidx(t & 15, t & 15)]));
+      s = wave_sum(s);
+      if (lane == 0) misc[16 + wave] = s;
+      GSYNC();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += misc[16 + w];
+        GST(g.logdet[b], tot);
+      }
+    }
+  }
+  if (tid == 0 && g.hyp) { GST(g.hyp[(long)b * 2], misc[8]); GST(g.hyp[(long)b * 2 + 1], misc[9]); }
+  if (wave == 0 && lane == 0) GST(g.info[b], uni(bad_in));
+  GSYNC();                                                                // LDS and the scratch are re-initialised for the next member
+}
+
+__global__ __launch_bounds__(NTH, 2) void medium_fit_kernel(MediumArgs) {
+  // the argument block where it lies (the kernel's one by-value parameter sits at the start of the kernarg segment)
+  const KArgs gk = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const __attribute__((address_space(4))) MediumArgs& g = *gk;
+  const int tid = threadIdx.x;
+  const int NT = g.NT, NTT = NT * (NT + 1) / 2, NP = 16 * NT;
+  // what the factorisation (potrf_v2, a function of its own since round 3) is told: the workgroup's scratch, the triangles by
+  // their index (0 Lb, 1 Cb, 2 Wb, 3 Gb, 4 LamB, 5 Sb) and the LDS offsets of the vectors it uses (layout: MED_ENV)
+  auto pargs = [&](int a, int x, int gm) {
+    PotrfArgs e;
+    e.sc = (gdouble*)(g.scratch + (size_t)blockIdx.x * g.scratch_stride);
+    e.oA = (long)a * NTT * TS; e.oX = (long)x * NTT * TS; e.oG = (long)gm * NTT * TS; e.NT = NT; e.NTT = NTT;
+    e.rs_off = NP + 64 + 2 * NP; e.yd_off = e.rs_off + NP; e.wv_off = NP + 64 + 7 * NP; e.sa_off = NP + 64 + 9 * NP;
+    e.w4idle = (g.tune & 1) ? 1 : 0;   // off: here the tile updates (through the scratch), not the chain, bound a step (288 against 279 us at N = 165)
+    return e;
+  };
+#pragma unroll 1
+  for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+    int bad = 0;
+    ph_setup(gk, b);
+    [[maybe_unused]] int it_now = 0;
+#pragma unroll 1
+    for (int it = 0; it < g.n_iters; ++it) {
+      it_now = it;
+      MSTAMP(0);
+      ph_kmat(gk, b, 1, 1);                                                // K0 + J I at the current hypers  (models.py:209); wv = 0
+      MSTAMP(1);
+      // L = chol(K0 + J I), L^-1 rides along into Wb; G = L^T D L and L^T (y / nu) accumulate block row by block row behind it
+      bad = potrf_v2<true, 1>(pargs(0, 2, 3), bad);
+      if (g.loss && it > 0 && (it - 1) % 25 == 0) ph_neg_elbo(gk, b, (it - 1) / 25, 1);   // after the Adam step = at these hypers
+      MSTAMP(2);
+      ph_natgrad(gk, b);
+      MSTAMP(3);
+      // C = chol(Lam) in Cb, C^-1 in Lb (L is dead); S = C^-T C^-1 accumulates into Sb behind it
+      bad = potrf_v2<true, 2>(pargs(1, 0, 5), bad);
+      MSTAMP(4);
+      if (g.loss && it % 25 == 0) ph_logdet_c(gk, b);                       // log det C of this step, for its loss sample
+      ph_m(gk, b);
+      MSTAMP(5);
+      ph_phi(gk, b, it == 0 ? 1 : 0);
+      MSTAMP(6);
+      ph_w(gk, b);
+      MSTAMP(7);
+      ph_kbar_adam(gk, b);
+      MSTAMP(8);
+    }
+
+    // ---- prediction at the final hypers with the (m, S) of the last step    (models.py:217-220)
+    it_now = g.n_iters;
+    MSTAMP(9);
+    ph_kmat(gk, b, 0, 0);
+    bad = potrf_v2<true, 0>(pargs(0, 2, 3), bad);                              // Lb = L, Wb = L^-1, Sb = S
+    if (g.loss && g.n_iters > 0 && (g.n_iters - 1) % 25 == 0) ph_neg_elbo(gk, b, (g.n_iters - 1) / 25, 0);
+    MSTAMP(10);
+    ph_mu_e(gk, b);
+    ph_cov(gk, b);
+    MSTAMP(11);
+    const bool factor = g.chol || g.logdet || g.basis;
+    if (factor) bad = potrf_v2<false, 0>(pargs(1, 1, 3), bad);                 // Distribution.__post_init__ (data.py:38-39)
+    ph_export(gk, b, factor ? 1 : 0, bad);
     MSTAMP(12);
-    GSYNC();                                                                // LDS and the scratch are re-initialised for the next member
   }
 }
 
