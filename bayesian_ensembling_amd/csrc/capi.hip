@@ -169,12 +169,11 @@ FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) { return c->dws.view(b0, nb)
 void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
                    double* dmu, double* dcov, double* dchol, double* dld, double* dhyp, double* dbasis) {
   const int N = fp.N, R = fp.R;
-  // Two groups of members on two streams (each with its look-ahead side stream) let one half's latency-bound steps - the 256-wide
-  // diagonal factorisations, the narrow panel solves: a few CUs busy - run beside the other half's large products: 58.9 against
-  // 60.4 ms per 32 x 2000 step (profiles/r05_groups_sweep.txt; four groups: 69 ms, the products no longer fill the chip).  By
-  // default (bayens_set_groups(ctx, 0)) a batch of at least 32 members that splits into halves of a multiple of 8 members - what
-  // the GEMM's XCD-aware tile dealing wants - runs as two groups, anything else as one.
-  const int want = c->ngroups > 0 ? c->ngroups : ((B >= 32 && B % 16 == 0) ? 2 : 1);
+  // One group by default: with a group's stream and its look-ahead stream on different hardware queues (bayens_ctx_create) the
+  // trailing updates really run beside the next diagonal block and panel solve, and one group of 32 members is the fastest
+  // arrangement - 57.7 ms per 32 x 2000 step against 58.6 with two groups on four queues (one half's latency-bound steps beside
+  // the other half's products) and 69 with four (profiles/r05_hw_queues.txt).  bayens_set_groups(ctx, n > 0) overrides.
+  const int want = c->ngroups > 0 ? c->ngroups : 1;
   const int G = std::max(1, std::min(std::min(want, (int)c->gstreams.size()), B));
   BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
   if (G == 1) {                                      // one group: no host thread, run on the first group stream
@@ -280,17 +279,38 @@ int bayens_ctx_create(int device, bayens_ctx** out) {
   (void)hipEventCreate(&c->t0);
   (void)hipEventCreate(&c->t1);
   c->prims = new HipPrims(c->stream);
+  try {
+    c->prims->ensure_side_stream();          // (its look-ahead stream right behind it: see the group streams below)
+  } catch (const HipError& err) {
+    bayens_ctx_destroy(c);
+    return err.code ? err.code : BAYENS_E_INTERNAL;
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
   }
   if (const char* env = getenv("BAYENS_STREAMS")) c->ngroups = std::max(1, std::min(16, atoi(env)));
+  // The HIP runtime deals its streams over a handful of hardware queues (four by default) in the order they are created, and
+  // kernels of two streams only run beside each other when the streams sit on DIFFERENT queues.  Round 5 measured what that does
+  // to a 32 x 2000 step when the look-ahead streams were created on first use, by whichever host thread got there first: 58.7 ms
+  // in most processes, 60.4 in some, and the one-group batch 60.1 or 57.7 - the same kernels (profiles/r05_hw_queues.txt).  So
+  // the streams a fit uses are created HERE, in a fixed order: group g's stream, then its look-ahead stream, group by group - a
+  // group's two streams never share a queue, and neither do those of groups 0 and 1.
+  if (const char* sk = getenv("BAYENS_STREAM_SKEW")) {      // (measurement switch: shifts which hardware queues the fit's streams get)
+    for (int k = 0; k < atoi(sk); ++k) { hipStream_t d = nullptr; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
+  }
   for (int g = 0; g < 16; ++g) {
     hipStream_t s = nullptr;
     e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     if (e != hipSuccess) { bayens_ctx_destroy(c); return (int)e; }
     c->gstreams.push_back(s);
     c->gprims.push_back(new HipPrims(s));
+    try {
+      c->gprims.back()->ensure_side_stream();
+    } catch (const HipError& err) {
+      bayens_ctx_destroy(c);
+      return err.code ? err.code : BAYENS_E_INTERNAL;
+    }
   }
   *out = c;
   return 0;

@@ -233,9 +233,8 @@ class Workload:
                                "achieved": round(group, 3), "frac": round(group / peak, 4),
                                "launches": p_all["launches"], "ms_per_fit_batch": round(p_all["ms"], 3)},
                 "fit_batch_ms_one_stream": round(fit_serial_ms, 3),
-                "note": "HIP events around every launch of the kernel in one fit batch with ONE member group = one stream (bench.py --groups 1: "
-                        "kernels strictly one after the other; the timed headline step runs the library default, two groups on two "
-                        "streams, whose kernels overlap and cannot be priced one by one); achieved = "
+                "note": "HIP events around every launch of the kernel in one fit batch, look-ahead stream off (kernels strictly one after the "
+                        "other; the timed step runs with the look-ahead, whose kernels overlap and cannot be priced one by one); achieved = "
                         "algorithmic flop of the UNPADDED problem / summed launch time; traffic = HBM bytes per launch of "
                         "this kernel from the rocprofv3 --pmc passes named in traffic_source (not measured in this run)"}
 
@@ -802,7 +801,7 @@ def main():
                                " + Barycentre",
                    "preset": args.config, "members_per_gpu": M, "members_total": M * world, "timesteps": N,
                    "realisations": R, "n_optim_nits": T, "kernel": args.kernel, "obs_realisations": wl.R_obs,
-                   "member_groups": args.groups if args.groups else "library default: two groups (streams) for a batch of >= 32 members, else one",
+                   "member_groups": args.groups if args.groups else 1,
                    "parallelism": (f"member-sharded x{world}, one RCCL all-gather of packed [M_loc,3,N] rows per step"
                                    if world > 1 else "single GPU"),
                    "exchange": (args.exchange if world > 1 else None), "rccl_library": rccl_lib, "rccl_ranks": rccl_ranks,

@@ -72,12 +72,12 @@ int bayens_profile_shapes(bayens_ctx* ctx, char* buf, int buf_len);
 /* text table "stage  ms" of the fit stages recorded (HIP events) while profiling was enabled, one stream */
 int bayens_profile_stages(bayens_ctx* ctx, char* buf, int buf_len);
 
-/* Number of member groups (HIP streams + host threads) a fit batch of the general route is split over; 1 = one stream, kernels
- * run strictly one after the other (what the per-kernel roofline measurement uses); 0 (the default; env BAYENS_STREAMS at
- * context creation overrides) = by batch size: two groups for a batch of >= 32 members that halves into multiples of 8, else
- * one.  At most 16.  Measured on MI355X at 32 x 2000 (profiles/r05_groups_sweep.txt): 60.4 / 58.9 / 69.1 ms per step with
- * 1 / 2 / 4 groups - one half's latency-bound diagonal factorisations run beside the other half's large products.  The result
- * does not depend on the grouping (tests/test_gpu_fit_parity.py::test_member_groups_do_not_change_the_result). */
+/* Number of member groups (HIP streams + host threads) a fit batch of the general route is split over; 1 = one stream (plus its
+ * look-ahead stream); 0 (the default; env BAYENS_STREAMS at context creation overrides) = the library's choice, which is one
+ * group.  At most 16.  Measured on MI355X at 32 x 2000 (profiles/r05_hw_queues.txt): 57.7 / 58.6 / 69 ms per step with 1 / 2 / 4
+ * groups once every stream and its look-ahead stream sit on different hardware queues (the context creates them in a fixed
+ * order for that).  The result does not depend on the grouping (tests/test_gpu_fit_parity.py::
+ * test_member_groups_do_not_change_the_result). */
 int bayens_set_groups(bayens_ctx* ctx, int n_groups);
 
 /* ---- the hot path ------------------------------------------------------------------------- */

@@ -444,9 +444,9 @@ def test_config3_full_size_against_the_fp64_oracle(ctx):
 
 
 def test_member_groups_do_not_change_the_result(ctx):
-    """The general route splits a batch over member groups = streams (two by default from 32 members on, include/bayens.h
-    bayens_set_groups): one, three and the default number of groups give the same bits (N = 130 is forced onto the general route;
-    N = 320 with 32 members takes it - and the default split - by size)."""
+    """The general route can split a batch over member groups = streams (include/bayens.h bayens_set_groups; one group by
+    default): one, two, three groups and the default give the same bits (N = 130 is forced onto the general route; N = 320 with 32
+    members takes it by size)."""
     data, _ = go.synthetic_ensemble(5, 130, R=4, seed=31)
     X, y, nu = member_inputs(data)
     ctx.set_fit_route(1)
@@ -463,13 +463,13 @@ def test_member_groups_do_not_change_the_result(ctx):
     data, _ = go.synthetic_ensemble(32, 320, R=3, seed=32)
     X, y, nu = member_inputs(data)
     auto = ctx.gp_fit_batch(X, y, nu, 2, want_chol=False)
-    ctx.set_groups(1)
+    ctx.set_groups(2)
     try:
-        single = ctx.gp_fit_batch(X, y, nu, 2, want_chol=False)
+        halves = ctx.gp_fit_batch(X, y, nu, 2, want_chol=False)
     finally:
         ctx.set_groups(0)
     for k in ("mu", "cov", "hyp"):
-        assert np.array_equal(auto[k], single[k]), k
+        assert np.array_equal(auto[k], halves[k]), k
 
 
 def test_bench_contract_line(ctx):
