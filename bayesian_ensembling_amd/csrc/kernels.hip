@@ -1609,7 +1609,10 @@ void HipPrims::ensure_side_stream() {
 }
 // The per-launch accounting (prof.enabled) wants kernels one after another on one stream: no side stream then.
 void HipPrims::side_begin() {
-  if (prof.enabled || in_side) return;
+  // (BAYENS_NO_LOOKAHEAD=1: measurement switch - the kernel-trace and counter passes of tools/make_profiles.sh run with it, so that
+  //  a kernel's recorded duration is its own and not the time it shared the device with the look-ahead stream's kernel)
+  static const bool no_lookahead = std::getenv("BAYENS_NO_LOOKAHEAD") != nullptr;
+  if (prof.enabled || in_side || no_lookahead) return;
   ensure_side_stream();
   BAYENS_HIP(hipEventRecord(ev_fork, stream));
   BAYENS_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));

@@ -4,8 +4,10 @@
 # Separate rocprofv3 passes: kernel trace, then one PMC counter per pass (never combined with other trace domains).
 # The script is long (the fuzz sweeps alone take minutes): `tools/make_profiles.sh r05 A` runs the first half (bench lines, rocprofv3
 # passes, configs 3-5), `... r05 B` the second (mid-size kernel, API paths, solves, sweeps), no second argument both.
-# The per-kernel passes (kernel trace, PMC) run `bench.py --groups 1`: one member group = one stream, kernels strictly one after the
-# other - the setting bench.py's own roofline block measures in (the headline step uses the library default, two groups).
+# The per-kernel passes (kernel trace, PMC) run `BAYENS_NO_LOOKAHEAD=1 bench.py`: kernels strictly one after the other - the setting
+# bench.py's own roofline block measures in (the timed headline step runs the look-ahead stream beside the main one, on another
+# hardware queue: two kernels at a time, whose recorded durations include the time they share the device).  The trace of the plain
+# command is kept beside it (<tag>_kernel_stats_overlapped.txt).
 set -u
 TAG=${1:-r01}
 PART=${2:-AB}
@@ -19,11 +21,16 @@ BAYENS_PRINT_STAGES=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > /de
 timeout -k 10 300 python3 bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err || exit 1
 timeout -k 10 300 python3 tools/small_phases.py > $OUT/${TAG}_small_phases.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --groups 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_kt.log 2>&1 || exit 2
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pf.log 2>&1 || exit 3
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pw.log 2>&1 || exit 4
-timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --groups 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pm.log 2>&1 || exit 5
+export BAYENS_NO_LOOKAHEAD=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_kt.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pf -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pf.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pw -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pw.log 2>&1 || exit 4
+timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace -d $OUT/${TAG}_pm -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_pm.log 2>&1 || exit 5
+unset BAYENS_NO_LOOKAHEAD
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kto -o kto -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_kto.log 2>&1 || exit 2
 cd $R
+python3 tools/rocpd_stats.py $(find $OUT/${TAG}_kto -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_overlapped.txt > /dev/null
+rm -rf $OUT/${TAG}_kto
 python3 tools/rocpd_mfma_util.py $(find $OUT/${TAG}_pm -name "*.db" | head -1) $OUT/${TAG}_pmc_mfma_util.txt > /dev/null
 rm -rf $OUT/${TAG}_pm
 KT=$(find $OUT/${TAG}_kt -name "*.db" | head -1); PF=$(find $OUT/${TAG}_pf -name "*.db" | head -1); PW=$(find $OUT/${TAG}_pw -name "*.db" | head -1)
