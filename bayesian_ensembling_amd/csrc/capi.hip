@@ -399,7 +399,7 @@ int bayens_profile_enable(bayens_ctx* c, int on) {
     std::vector<HipPrims*> all = c->gprims;
     all.push_back(c->prims);
     for (HipPrims* hp : all) hp->profile_reset(on != 0);
-    if (on && !c->f32) c->f32 = bayens_f32_create(c->stream);
+    if (on && !c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
     if (c->f32) bayens_f32_profile_enable(c->f32, on);
     return 0;
   });
@@ -723,7 +723,7 @@ int bayens_gp_fit_batch_f32(bayens_ctx* c, int loc, int B, int N, int R, const f
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: unknown kernel id");
-    if (!c->f32) c->f32 = bayens_f32_create(c->stream);
+    if (!c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
     Stage st(c, loc);
     BayensF32Args a;
     a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;
@@ -762,7 +762,7 @@ int bayens_gp_fit_batch_reduced_f32(bayens_ctx* c, int loc, int B, int N, int R,
     if (!smalln::small_fit_supported(N, R))
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: N must be at most 94 (the fp32 instance of the fused small-member kernel; "
                                    "the mid-size kernel is fp64 only: bayens_gp_fit_batch_reduced)");
-    if (!c->f32) c->f32 = bayens_f32_create(c->stream);
+    if (!c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
     Stage st(c, loc);
     BayensF32Args a;
     a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;

@@ -22,7 +22,8 @@ struct BayensF32Args {
   int* info_host = nullptr;        // host [B]
 };
 
-void* bayens_f32_create(hipStream_t stream);
+// `side`: look-ahead stream to borrow (the context's; may be null: the instance then creates its own on first use)
+void* bayens_f32_create(hipStream_t stream, hipStream_t side);
 void bayens_f32_destroy(void* state);
 // returns 0 or a HIP error code / negative argument error; message in *err
 int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err);

@@ -24,7 +24,8 @@ struct State {
   int small_info_cap = 0, n_cus = 256;
   double* kpark = nullptr;         // kernel-value park of the fused small-member kernel
   size_t kpark_cap = 0;
-  explicit State(hipStream_t s) : stream(s), prims(s) {
+  State(hipStream_t s, hipStream_t side) : stream(s), prims(s) {
+    prims.borrow_side_stream(side);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -36,7 +37,7 @@ struct State {
 
 using namespace bayens_f32;
 
-void* bayens_f32_create(hipStream_t stream) { return new State(stream); }
+void* bayens_f32_create(hipStream_t stream, hipStream_t side) { return new State(stream, side); }
 void bayens_f32_destroy(void* state) { delete static_cast<State*>(state); }
 
 void bayens_f32_profile_enable(void* state, int on) { static_cast<State*>(state)->prims.profile_reset(on != 0); }

@@ -54,7 +54,7 @@ struct HipPrims : Prims {
   // look-ahead stream of the blocked Cholesky (side_begin / side_end / side_join); created on first use
   hipStream_t side_stream = nullptr, main_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool in_side = false, side_pending = false;
+  bool in_side = false, side_pending = false, owns_side = true;
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
   // per-launch accounting on/off: recorded events go back to the pool, counters are cleared
@@ -79,6 +79,9 @@ struct HipPrims : Prims {
   void ensure_scratch(int nb, int Np, int R4);
   void mark(const char* phase) override;
   void ensure_side_stream();
+  // use another instance's look-ahead stream (the fp32 instance of a context borrows the fp64 one's: the two never run
+  // together, and the stream's hardware queue was chosen at context creation - profiles/r05_hw_queues.txt)
+  void borrow_side_stream(hipStream_t s);
   void side_begin() override;
   void side_end() override;
   void side_join() override;

@@ -1594,7 +1594,7 @@ HipPrims::~HipPrims() {
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
-  if (side_stream) (void)hipStreamDestroy(side_stream);
+  if (side_stream && owns_side) (void)hipStreamDestroy(side_stream);
 }
 
 void HipPrims::ensure_side_stream() {
@@ -1606,6 +1606,13 @@ void HipPrims::ensure_side_stream() {
     BAYENS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     BAYENS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }
+}
+void HipPrims::borrow_side_stream(hipStream_t s) {
+  if (side_stream || !s) return;
+  side_stream = s;
+  owns_side = false;
+  BAYENS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  BAYENS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 }
 // The per-launch accounting (prof.enabled) wants kernels one after another on one stream: no side stream then.
 void HipPrims::side_begin() {
