@@ -449,8 +449,9 @@ class Context:
         return info
 
     def gp_fit_batch_reduced(self, X, y_mean, y_var, n_iters, kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, dtype=np.float64):
-        """Members with N <= 254 (fused kernels), reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance).
-        dtype float32: the fp32 instance of the fused small-member kernel (N <= 94); mu / var / basis come back as float32."""
+        """Reduced export: mu, var = diag(cov), logdet, hyp, basis (no covariance leaves the device).  N <= 254: the fused kernels;
+        above that the general path.  dtype float32: the fp32 instance (fused small-member kernel for N <= 94, the fp32 general
+        path above that); mu / var / basis come back as float32."""
         dt = np.dtype(dtype)
         fn = self.lib.bayens_gp_fit_batch_reduced if dt == np.float64 else self.lib.bayens_gp_fit_batch_reduced_f32
         X = np.ascontiguousarray(X, dtype=dt)
@@ -469,7 +470,7 @@ class Context:
 
     def gp_fit_batch_reduced_dev(self, B, N, R, X, y_mean, y_var, n_iters, mu, var, logdet=None, hyp=None, basis=None,
                                  kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, f32=False):
-        """f32=True: X, y_mean, y_var, mu, var, basis are float32 buffers (N <= 94; logdet / hyp stay float64)."""
+        """f32=True: X, y_mean, y_var, mu, var, basis are float32 buffers (logdet / hyp stay float64)."""
         info = np.zeros(B, dtype=np.int32)
         fn = self.lib.bayens_gp_fit_batch_reduced_f32 if f32 else self.lib.bayens_gp_fit_batch_reduced
         rc = fn(self.h, DEVICE, B, N, R, _ptr(X), _ptr(y_mean), _ptr(y_var),

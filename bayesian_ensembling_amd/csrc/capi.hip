@@ -167,7 +167,7 @@ FitWorkspace ws_view(bayens_ctx* c, int b0, int nb) { return c->dws.view(b0, nb)
 
 // Runs the fit of B resident members split into groups, one HIP stream + host thread per group.
 void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, const double* dy, const double* dnu,
-                   double* dmu, double* dcov, double* dchol, double* dld, double* dhyp, double* dbasis) {
+                   double* dmu, double* dcov, double* dchol, double* dld, double* dhyp, double* dbasis, double* dvar = nullptr) {
   const int N = fp.N, R = fp.R;
   // One group by default: with a group's stream and its look-ahead stream on different hardware queues (bayens_ctx_create) the
   // trailing updates really run beside the next diagonal block and panel solve, and one group of 32 members is the fastest
@@ -178,7 +178,7 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
   BAYENS_HIP(hipStreamSynchronize(c->stream));       // staged inputs are in HBM before any group starts
   if (G == 1) {                                      // one group: no host thread, run on the first group stream
     FitWorkspace w = ws_view(c, 0, B);
-    gp_fit(*c->gprims[0], w, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
+    gp_fit(*c->gprims[0], w, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis, dvar);
     BAYENS_HIP(hipStreamSynchronize(c->gstreams[0]));
     return;
   }
@@ -195,9 +195,9 @@ void fit_in_groups(bayens_ctx* c, int B, const FitParams& fp, const double* dX, 
         if (fg.loss_trace) fg.loss_trace += (size_t)b0 * fg.loss_stride;
         if (fg.Rv) { fg.Rv += b0; fg.xoff += b0; }          // (a ragged batch: the offsets are absolute, X's base stays)
         gp_fit(*c->gprims[g], w, fg, fg.Rv ? dX : dX + (size_t)b0 * N * R, dy + (size_t)b0 * N, dnu + (size_t)b0 * N,
-               dmu + (size_t)b0 * N, dcov + (size_t)b0 * N * N, dchol ? dchol + (size_t)b0 * N * N : nullptr,
+               dmu + (size_t)b0 * N, dcov ? dcov + (size_t)b0 * N * N : nullptr, dchol ? dchol + (size_t)b0 * N * N : nullptr,
                dld ? dld + b0 : nullptr, dhyp ? dhyp + (size_t)b0 * 2 : nullptr,
-               dbasis ? dbasis + (size_t)b0 * 2 * N : nullptr);
+               dbasis ? dbasis + (size_t)b0 * 2 * N : nullptr, dvar ? dvar + (size_t)b0 * N : nullptr);
         BAYENS_HIP(hipStreamSynchronize(c->gstreams[g]));
       } catch (const HipError& e) {
         errs[g] = e;
@@ -680,8 +680,8 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, con
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: unknown kernel id");
     const bool medium = !smalln::small_fit_supported(N, R) && mediumn::medium_fit_supported(N, R);
-    if (!smalln::small_fit_supported(N, R) && !medium)
-      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced: N must be at most 254 (larger members: bayens_gp_fit_batch + bayens_extract_diag)");
+    const bool general = !smalln::small_fit_supported(N, R) && !medium;
+    if (general) ensure_ws(c, B, pad_to_leaf(N));
     Stage st(c, loc);
     const double* dX = st.in(X, (size_t)B * N * R);
     const double* dy = st.in(y_mean, (size_t)B * N);
@@ -691,8 +691,13 @@ int bayens_gp_fit_batch_reduced(bayens_ctx* c, int loc, int B, int N, int R, con
     double* dld = st.out(logdet, (size_t)B);
     double* dhyp = st.out(hyp, (size_t)B * 2);
     double* dbasis = st.out(ll_basis, (size_t)B * 2 * N);
-    int* dinfo = st.scratch<int>((size_t)B);
-    if (medium) {
+    int* dinfo = general ? c->dws.ws.info : st.scratch<int>((size_t)B);
+    if (general) {
+      // N > 254 (the reference's monthly series, N = 1032 / 1980: experiments/data): the general path, whose covariance stays in
+      // the workspace - its diagonal, log-determinant and log-likelihood basis are what leaves
+      FitParams fp{N, R, kernel, n_iters, gamma, lr, jitter};
+      fit_in_groups(c, B, fp, dX, dy, dnu, dmu, nullptr, nullptr, dld, dhyp, dbasis, dvar);
+    } else if (medium) {
       // 94 < N <= 254 (the reference's historical annual horizon, N = 165: experiments/full_experiment_script.py:57): the fused
       // mid-size kernel with the same reduced export - no covariance, no factor leaves the kernel
       mediumn::MediumArgs a{B, N, R, kernel, n_iters, gamma, lr, jitter, dX, dy, dnu, dmu, nullptr, dvar, nullptr, dld, dhyp, dbasis, dinfo,
@@ -759,9 +764,6 @@ int bayens_gp_fit_batch_reduced_f32(bayens_ctx* c, int loc, int B, int N, int R,
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !var || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: unknown kernel id");
-    if (!smalln::small_fit_supported(N, R))
-      return fail(c, BAYENS_E_ARG, "gp_fit_batch_reduced_f32: N must be at most 94 (the fp32 instance of the fused small-member kernel; "
-                                   "the mid-size kernel is fp64 only: bayens_gp_fit_batch_reduced)");
     if (!c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
     Stage st(c, loc);
     BayensF32Args a;

@@ -224,7 +224,7 @@ static void neg_elbo(Prims& P, FitWorkspace& ws, const FitParams& fp, int slot, 
 
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, const real* y_in,
             const real* nu_in, real* mu, real* cov, real* chol, double* logdet, double* hyp,
-            real* basis) {
+            real* basis, real* var) {
   const int nb = ws.nb, Np = ws.Np, N = fp.N;
   const long is = ws.inv_stride();
   // (Lam = I is only stored when something reads it: no iteration, or a first iteration in the general form)
@@ -360,7 +360,8 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   P.gemm(nb, Np, Np, Np, -fp.jitter * fp.jitter, ws.T2, ws.T2, 1.0, ws.Lam,
          GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
   P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);
-  P.extract(nb, N, ws.Lam, cov, 1);
+  if (cov) P.extract(nb, N, ws.Lam, cov, 1);
+  if (var) P.extract_diagonal(nb, N, ws.Lam, var);     // (the reduced export of a per-gridpoint field: no N x N table leaves the fit)
   P.mark("chol(cov)");
   if (chol || logdet || basis) {
     // Distribution.__post_init__ : distrax caches chol(cov) and its log-determinant  (data.py:38-39)

@@ -71,12 +71,12 @@ struct FitParams {
 constexpr int LOSS_EVERY = 25;   // models.py:211
 
 // Runs the whole fit on resident inputs.  X [nb][N][R], y_in/nu_in [nb][N] (compact, device).
-// Outputs (device, compact): mu [nb][N], cov [nb][N][N], chol (nullable), logdet (nullable, [nb]),
+// Outputs (device, compact): mu [nb][N], cov [nb][N][N] (nullable: the reduced export), chol (nullable), logdet (nullable, [nb]),
 // hyp (nullable, [nb][2]), basis (nullable, [nb][2][N]: L_c^-1 1 and L_c^-1 mu, the two vectors every
-// constant-vector log-likelihood of the posterior needs).  info: ws.info (device).
+// constant-vector log-likelihood of the posterior needs), var (nullable, [nb][N]: diag(cov)).  info: ws.info (device).
 void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, const real* y_in,
             const real* nu_in, real* mu, real* cov, real* chol, double* logdet, double* hyp,
-            real* basis);
+            real* basis, real* var = nullptr);
 
 // chol/logdet/basis of caller-supplied covariances already placed (padded, full) in ws.T2; mu_pad [nb][Np].
 void mvn_factor(Prims& P, FitWorkspace& ws, int N, const real* mu_pad, real* chol, double* logdet,

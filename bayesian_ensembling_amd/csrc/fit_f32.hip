@@ -77,14 +77,13 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
       BAYENS_HIP(hipStreamSynchronize(st->stream));
       return 0;
     }
-    if (!a.cov) throw HipError{-1, "the reduced fp32 export needs N <= 94 (the fused small-member kernel)"};
     const int Np = pad_to_leaf(a.N);
     st->dws.ensure(a.B, Np);
     FitWorkspace w = st->dws.view(0, a.B);
     FitParams fp{a.N, a.R, a.kernel, a.n_iters, a.gamma, a.lr, a.jitter};
     fp.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
     fp.loss_trace = fp.loss_stride > 0 ? a.loss_trace : nullptr;
-    gp_fit(st->prims, w, fp, a.X, a.y_mean, a.y_var, a.mu, a.cov, a.chol, a.logdet, a.hyp, a.basis);
+    gp_fit(st->prims, w, fp, a.X, a.y_mean, a.y_var, a.mu, a.cov, a.chol, a.logdet, a.hyp, a.basis, a.var);
     BAYENS_HIP(hipMemcpyAsync(a.info_host, w.info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
     BAYENS_HIP(hipStreamSynchronize(st->stream));
     return 0;

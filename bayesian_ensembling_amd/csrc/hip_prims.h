@@ -124,6 +124,7 @@ struct HipPrims : Prims {
   void diag_init(int nb, int n, const real* nu, double add, Mat dst) override;
   void extract(int nb, int N, Mat src, real* dst, int mode) override;
   void extract_vec(int nb, int N, int Np, const real* src, real* dst) override;
+  void extract_diagonal(int nb, int N, Mat src, real* dst) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
   void info_fold(int nb, int* pair, int* info) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;

@@ -354,6 +354,12 @@ __global__ void extract_vec_kernel(int N, int Np, const real* src, real* dst) {
   if (i < N) dst[(long)b * N + i] = src[(long)b * Np + i];
 }
 
+__global__ void extract_diagonal_kernel(int N, Mat src, real* dst) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) dst[(long)b * N + i] = src.p[b * src.stride + (long)i * src.ld + i];
+}
+
 __global__ void logdet_kernel(int N, Mat Lc, double* out) {
   __shared__ double part[4];
   const int b = blockIdx.x;
@@ -1808,6 +1814,10 @@ void HipPrims::extract(int nb, int N, Mat src, real* dst, int mode) {
 }
 void HipPrims::extract_vec(int nb, int N, int Np, const real* src, real* dst) {
   hipLaunchKernelGGL(extract_vec_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::extract_diagonal(int nb, int N, Mat src, real* dst) {
+  hipLaunchKernelGGL(extract_diagonal_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, src, dst);
   LAUNCH_CHECK();
 }
 void HipPrims::info_fold(int nb, int* pair, int* info) {

@@ -169,6 +169,8 @@ struct Prims {
   // 2 lower triangle with zeros above
   virtual void extract(int nb, int N, Mat src, real* dst, int mode) = 0;
   virtual void extract_vec(int nb, int N, int Np, const real* src, real* dst) = 0;
+  // dst[b][i] = src_b[i][i], i < N (the reduced export: marginal variances without the N x N table)
+  virtual void extract_diagonal(int nb, int N, Mat src, real* dst) = 0;
   virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii
   // info[b] = its own non-zero value, else the first non-zero of pair[2b], pair[2b+1]; pair is cleared
   virtual void info_fold(int nb, int* pair, int* info) = 0;

@@ -65,12 +65,15 @@ class GPDTW1D:
     # -- per-gridpoint fields (BASELINE config 5) -------------------------------------------------------
     FIELD_CHUNK = 65536          # fits per launch of the fused small-member kernel
     FIELD_STAGES = 8             # upload / fit pipeline stages of a collection
+    FIELD_WS_BYTES = 48 << 30    # general path (N > 254): workspace budget of one launch ...
+    FIELD_WS_MATRICES = 8        # ... at this many padded N x N matrices per fit (csrc/fit_ws.h)
 
     def fit_field(self, process_models, n_optim_nits: int = 500):
         """Every (member, grid point) of a collection of (realisation, time, *space) models as an independent GP over
         time - models.py:175-220 applied to `model_data[:, :, lat, lon]` - in batched launches of the fused small-member
-        kernel (N <= 94; 94 < N <= 254, the reference's historical horizon N = 165, through the fused mid-size kernel) with
-        the reduced export, resident in HBM as ONE ResidentField [M][G].  Members must share (R, T, space)."""
+        kernel (N <= 94; 94 < N <= 254, the reference's historical horizon N = 165, through the fused mid-size kernel; longer
+        series - the reference's monthly data, N = 1032 / 1980 - through the general path, a workspace-sized chunk of fits per
+        launch) with the reduced export, resident in HBM as ONE ResidentField [M][G].  Members must share (R, T, space)."""
         ctx = _lib.default_context()
         shapes = {tuple(pm.model_data.shape) for pm in process_models}
         if len(shapes) != 1:
@@ -80,13 +83,7 @@ class GPDTW1D:
         R, N = next(iter(shapes))[:2]
         G = int(np.prod(next(iter(shapes))[2:]))
         M = len(process_models)
-        if N > 254:
-            raise NotImplementedError(f"per_gridpoint: {N} time steps; the fused one-kernel-per-fit paths hold N <= 254 (the "
-                                      "reference's annual horizons are 86 and 165 steps)")
         f32 = self.dtype != np.float64
-        if f32 and N > 94:
-            raise NotImplementedError(f"per_gridpoint in float32: {N} time steps; the fp32 instance is the fused small-member kernel "
-                                      "(N <= 94, the reference's projection horizon of 86 years); the mid-size kernel is float64")
         field = ResidentField(ctx, M, G, N)
         kid = _lib.KERNEL_IDS[self.kernel]
         B = M * G
@@ -94,7 +91,11 @@ class GPDTW1D:
         draw = ctx.empty((M, R, N, G))
         # float32: the prologue and the field's tables stay float64 (they feed the float64 weight / scheme kernels); a chunk's
         # inputs are narrowed and its outputs widened on the device around the fp32 fit (bayens_gp_fit_batch_reduced_f32)
-        chunk = min(self.FIELD_CHUNK, B)
+        # (general path: every fit of a chunk holds FIELD_WS_MATRICES padded N x N matrices of workspace)
+        fused = N <= 254 and not (f32 and N > 94)
+        Np = -(-N // 64) * 64
+        per_launch = self.FIELD_CHUNK if fused else max(1, int(self.FIELD_WS_BYTES // (self.FIELD_WS_MATRICES * Np * Np * (4 if f32 else 8))))
+        chunk = min(per_launch, B)
         sX, sy, snu, smu, svar, sbasis = ((ctx.empty((chunk, N, R), np.float32), ctx.empty((chunk, N), np.float32),
                                            ctx.empty((chunk, N), np.float32), ctx.empty((chunk, N), np.float32),
                                            ctx.empty((chunk, N), np.float32), ctx.empty((chunk, 2, N), np.float32))
@@ -146,8 +147,8 @@ class GPDTW1D:
                         for g in range(G):
                             y[(m - m0) * G + g] = np.asarray(self.target(data[:, :, g]), dtype=np.float64).reshape(-1)
                     ctx._check(ctx.lib.bayens_memcpy_h2d(ctx.h, dy.offset(f0 * N * 8), y.ctypes.data, y.nbytes))
-                for b0 in range(f0, m1 * G, self.FIELD_CHUNK):
-                    nb = min(m1 * G, b0 + self.FIELD_CHUNK) - b0
+                for b0 in range(f0, m1 * G, chunk):
+                    nb = min(m1 * G, b0 + chunk) - b0
                     if f32:
                         ctx.narrow_f64_dev(nb * N * R, dX.offset(b0 * N * R * 8), sX)
                         ctx.narrow_f64_dev(nb * N, dy.offset(b0 * N * 8), sy)

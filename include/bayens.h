@@ -142,12 +142,15 @@ int bayens_field_prologue(bayens_ctx* ctx, int loc, int M, int R, int N, int G, 
  * (_dist.variance(), ensemble_scheme.py:64-65), logdet [B], hyp [B][2], ll_basis [B][2][N] (weights.py:98-100) - 2.8 KB
  * per member instead of the 59.9 KB of a full covariance.  Members with 94 < N <= 254 (the
  * reference's historical annual horizon N = 165, full_experiment_script.py:57) take the fused mid-size kernel (csrc/medium.hip)
- * with the same export; N > 254: BAYENS_E_ARG (bayens_gp_fit_batch + bayens_extract_diag serve those). */
+ * with the same export; N > 254 (the reference's monthly series, N = 1032 / 1980: experiments/data) the general path - the
+ * covariance is formed and factored in the fit's workspace (the log-determinant and the log-likelihood basis need it) and only
+ * its diagonal leaves. */
 int bayens_gp_fit_batch_reduced(bayens_ctx* ctx, int loc, int B, int N, int R,
                                 const double* X, const double* y_mean, const double* y_var,
                                 int kernel, int n_iters, double gamma, double lr, double jitter,
                                 double* mu, double* var, double* logdet, double* hyp, int* info, double* ll_basis);
-/* ... in fp32 (the fp32 instance of the fused small-member kernel: N <= 94 only - the mid-size kernel is fp64; BASELINE config 5
+/* ... in fp32 (N <= 94: the fp32 instance of the fused small-member kernel; above that the fp32 general path - the mid-size kernel
+ * is fp64; BASELINE config 5
  * x config 3's precision: per-gridpoint fields with GPDTW1D(per_gridpoint=True, dtype="float32"), 1e-3 relative).  float arrays
  * in and out; logdet / hyp stay fp64.  bayens_narrow_f64 / bayens_widen_f32 convert the tables of the fp64 prologue and the
  * fp64 weight / scheme entry points on the device. */

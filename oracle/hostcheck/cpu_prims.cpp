@@ -354,6 +354,10 @@ struct CpuPrims : Prims {
   void extract_vec(int nb, int N, int Np, const double* src, double* dst) override {
     for (int b = 0; b < nb; ++b) std::memcpy(dst + (size_t)b * N, src + (size_t)b * Np, N * sizeof(double));
   }
+  void extract_diagonal(int nb, int N, Mat src, double* dst) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < N; ++i) dst[(size_t)b * N + i] = src.p[b * src.stride + (size_t)i * src.ld + i];
+  }
   void logdet(int nb, int N, Mat Lc, double* out) override {
     for (int b = 0; b < nb; ++b) {
       double s = 0;

@@ -202,8 +202,8 @@ def test_model_similarity_weight_spatial_mode(ctx):
 def test_per_gridpoint_fields_in_float32(ctx):
     """GPDTW1D(per_gridpoint=True, dtype="float32") (round 5: bayens_gp_fit_batch_reduced_f32, the fp32 instance of the fused
     small-member kernel behind the field path): marginals, hyper-parameters, the per-gridpoint log-likelihood weights and the
-    barycentre against the float64 ORACLE at BASELINE.json's fp32 bar, 1e-3 relative; N > 94 is refused (the mid-size kernel is
-    float64); the reduced fp32 entry itself against the reduced fp64 one on a plain batch."""
+    barycentre against the float64 ORACLE at BASELINE.json's fp32 bar, 1e-3 relative; the reduced fp32 entry itself against the
+    reduced fp64 one on a plain batch (N > 94 in float32: test_fields_longer_than_the_fused_kernels)."""
     M, R, T, n_lat, n_lon, nits = 3, 6, 40, 3, 4, 2
     mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=5)
     mc.fit(model=es.GPDTW1D(per_gridpoint=True, dtype="float32"), n_optim_nits=nits, progress_bar=False)
@@ -229,9 +229,6 @@ def test_per_gridpoint_fields_in_float32(ctx):
     assert relerr(np.asarray(w.values).reshape(M, T, G), w_ref) < 1e-3
     rm, rv, _ = go.barycentre(w_ref.reshape(M, -1), mus.reshape(M, -1), vs.reshape(M, -1))
     assert relerr(np.asarray(post.mu).ravel(), rm) < 1e-3 and relerr(np.asarray(post.covariance).ravel(), rv) < 1e-3
-    big, _ = _field_collection(2, 3, 100, 2, 2, seed=6)
-    with pytest.raises(NotImplementedError):
-        big.fit(model=es.GPDTW1D(per_gridpoint=True, dtype="float32"), n_optim_nits=1, progress_bar=False)
     data, _ = go.synthetic_ensemble(5, 86, R=8, seed=86)
     X = np.ascontiguousarray(np.swapaxes(data, 1, 2))
     r64 = ctx.gp_fit_batch_reduced(X, data.mean(axis=1), data.var(axis=1), 2)
@@ -240,3 +237,41 @@ def test_per_gridpoint_fields_in_float32(ctx):
     for key in ("mu", "var", "hyp", "basis"):
         assert relerr(r32[key].astype(np.float64), r64[key]) < 1e-3, key
     assert np.max(np.abs(r32["logdet"] - r64["logdet"])) < 1e-3 * np.max(np.abs(r64["logdet"]))
+
+
+@pytest.mark.parametrize("dtype,T,tol", [("float64", 300, 1e-9), ("float32", 300, 1e-3), ("float32", 100, 1e-3)])
+def test_fields_longer_than_the_fused_kernels(ctx, dtype, T, tol):
+    """Per-gridpoint fields with more time steps than the fused kernels hold (N > 254; in float32 N > 94) - the reference's monthly
+    series are N = 1032 / 1980 (experiments/data) - go through the general path with the reduced export (the covariance stays in
+    the fit's workspace, bayens_gp_fit_batch_reduced{,_f32}), a workspace-sized chunk of fits per launch: marginals, weights and
+    barycentre against the oracle at every grid point; and the same field cut into launches of three fits, bit for bit."""
+    M, R, n_lat, n_lon, nits = 2, 4, 2, 2, 2
+    mc, obs = _field_collection(M, R, T, n_lat, n_lon, seed=T)
+    mc.fit(model=es.GPDTW1D(per_gridpoint=True, dtype=dtype), n_optim_nits=nits, progress_bar=False)
+    w = es.LogLikelihoodWeight()(mc, obs, standardisation_constant=1e-3)
+    post = es.Barycentre()(mc, w)
+    G = n_lat * n_lon
+    ob = np.asarray(obs.model_data.values).reshape(-1, T, G)
+    lls, mus, vs = np.empty((M, T, G)), np.empty((M, T, G)), np.empty((M, T, G))
+    with threadpool_limits(4):
+        for m in range(M):
+            data = np.asarray(mc[m].model_data.values).reshape(R, T, G)
+            for g in range(G):
+                X, y, nu = go.prologue(data[:, :, g])
+                mo, co, _ = go.gp_fit(X, y, nu, nits)[:3]
+                lls[m, :, g] = go.loglik_mean_rows(go.mvn_constvec_loglik(mo, *go.mvn_factor(co), ob[:, :, g]))
+                mus[m, :, g], vs[m, :, g] = mo, np.diag(co)
+            assert relerr(np.asarray(mc[m].distribution.mean.values).reshape(T, G), mus[m]) < tol, m
+            assert relerr(np.asarray(mc[m].distribution.variance.values).reshape(T, G), vs[m]) < tol, m
+    w_ref = np.exp(1e-3 * lls)
+    w_ref /= w_ref.sum(axis=0, keepdims=True)
+    assert relerr(np.asarray(w.values).reshape(M, T, G), w_ref) < max(tol, 1e-8)
+    rm, rv, _ = go.barycentre(w_ref.reshape(M, -1), mus.reshape(M, -1), vs.reshape(M, -1))
+    assert relerr(np.asarray(post.mu).ravel(), rm) < max(tol, 1e-8) and relerr(np.asarray(post.covariance).ravel(), rv) < max(tol, 1e-8)
+    one = [np.array(m.distribution.mean.values) for m in mc.models]
+    model = es.GPDTW1D(per_gridpoint=True, dtype=dtype)
+    Np = -(-T // 64) * 64
+    model.FIELD_WS_BYTES = 3 * model.FIELD_WS_MATRICES * Np * Np * (8 if dtype == "float64" else 4)
+    mc.fit(model=model, n_optim_nits=nits, progress_bar=False)
+    for a, m in zip(one, mc.models):
+        assert np.array_equal(a, m.distribution.mean.values)
