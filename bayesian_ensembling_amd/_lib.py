@@ -76,6 +76,7 @@ def load():
     lib.bayens_gp_fit_batch_f32.argtypes = lib.bayens_gp_fit_batch.argtypes
     lib.bayens_gp_fit_batch_ragged.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                                C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bayens_gp_fit_batch_ragged_f32.argtypes = lib.bayens_gp_fit_batch_ragged.argtypes
     lib.bayens_gp_fit_batch_reduced.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                                 C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bayens_transpose_rows.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -419,12 +420,14 @@ class Context:
         return {"mu": mu, "cov": cov, "chol": chol, "logdet": logdet, "hyp": hyp, "info": info, "basis": basis, "loss": loss}
 
     def gp_fit_batch_ragged_dev(self, B, N, R, x_off, X, y_mean, y_var, n_iters, mu, cov, chol=None, logdet=None, hyp=None,
-                                kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, loss=None):
-        """Device-resident buffers (X: the concatenated blocks); R / x_off are HOST arrays (int32 / uint64, see ragged_layout)."""
+                                kernel=MATERN32, gamma=0.5, lr=0.01, jitter=1e-6, basis=None, loss=None, f32=False):
+        """Device-resident buffers (X: the concatenated blocks); R / x_off are HOST arrays (int32 / uint64, see ragged_layout).
+        f32=True: X, y_mean, y_var, mu, cov, chol, basis are float32 buffers (bayens_gp_fit_batch_ragged_f32)."""
         R = np.ascontiguousarray(R, dtype=np.int32)
         x_off = np.ascontiguousarray(x_off, dtype=np.uint64)
         info = np.zeros(B, dtype=np.int32)
-        rc = self.lib.bayens_gp_fit_batch_ragged(self.h, DEVICE, B, N, _ptr(R), _ptr(x_off), _ptr(X), _ptr(y_mean), _ptr(y_var),
+        fn = self.lib.bayens_gp_fit_batch_ragged_f32 if f32 else self.lib.bayens_gp_fit_batch_ragged
+        rc = fn(self.h, DEVICE, B, N, _ptr(R), _ptr(x_off), _ptr(X), _ptr(y_mean), _ptr(y_var),
                                                  int(kernel), int(n_iters), gamma, lr, jitter, _ptr(mu), _ptr(cov), _ptr(chol),
                                                  _ptr(logdet), _ptr(hyp), _ptr(loss), _ptr(info), _ptr(basis))
         if rc != 0:

@@ -604,6 +604,51 @@ int fit_batch_impl(bayens_ctx* c, const char* who, int loc, int B, int N, int R,
   fit_in_groups(c, B, fp, dX, dy, dnu, dmu, dcov, dchol, dld, dhyp, dbasis);
   return report(c->dws.ws.info);
 }
+
+// bayens_gp_fit_batch_f32 / bayens_gp_fit_batch_ragged_f32 (Rv / x_off as in fit_batch_impl)
+int fit_batch_f32_impl(bayens_ctx* c, const char* who, int loc, int B, int N, int R, const int* Rv, const size_t* x_off, size_t x_total,
+                       const float* X, const float* y_mean, const float* y_var, int kernel, int n_iters, double gamma, double lr,
+                       double jitter, float* mu, float* cov, float* cov_chol, double* logdet, double* hyp, double* loss_trace,
+                       int* info, float* ll_basis) {
+  const std::string tag = std::string(who) + ": ";
+  if (!c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
+  Stage st(c, loc);
+  BayensF32Args a;
+  a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;
+  a.gamma = gamma; a.lr = lr; a.jitter = jitter;
+  a.X = st.in(X, x_total);
+  a.y_mean = st.in(y_mean, (size_t)B * N);
+  a.y_var = st.in(y_var, (size_t)B * N);
+  a.mu = st.out(mu, (size_t)B * N);
+  a.cov = st.out(cov, (size_t)B * N * N);
+  a.chol = st.out(cov_chol, (size_t)B * N * N);
+  a.logdet = st.out(logdet, (size_t)B);
+  a.hyp = st.out(hyp, (size_t)B * 2);
+  const int ntrace = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
+  a.loss_trace = ntrace > 0 ? st.out(loss_trace, (size_t)B * ntrace) : nullptr;
+  a.basis = st.out(ll_basis, (size_t)B * 2 * N);
+  std::vector<long> hoff;
+  if (Rv) {
+    int* r = st.scratch<int>((size_t)B);
+    long* o = st.scratch<long>((size_t)B);
+    hoff.resize(B);
+    for (int b = 0; b < B; ++b) hoff[b] = (long)x_off[b];
+    BAYENS_HIP(hipMemcpyAsync(r, Rv, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    BAYENS_HIP(hipMemcpyAsync(o, hoff.data(), (size_t)B * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    a.Rv = r;
+    a.xoff = o;
+  }
+  std::vector<int> hinfo(B, 0);
+  a.info_host = hinfo.data();
+  std::string err;
+  const int rc = bayens_f32_fit(c->f32, a, &err);
+  if (rc != 0) return fail(c, rc > 0 ? rc : BAYENS_E_ARG, tag + err);
+  st.finish();
+  int bad = 0;
+  for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
+  if (bad) return fail(c, BAYENS_E_NOTPD, tag + "matrix not positive definite (see info[])");
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -728,32 +773,30 @@ int bayens_gp_fit_batch_f32(bayens_ctx* c, int loc, int B, int N, int R, const f
     if (B <= 0 || N <= 0 || R <= 0 || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
       return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: bad argument");
     if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_f32: unknown kernel id");
-    if (!c->f32) c->f32 = bayens_f32_create(c->stream, c->prims->side_stream);
-    Stage st(c, loc);
-    BayensF32Args a;
-    a.B = B; a.N = N; a.R = R; a.kernel = kernel; a.n_iters = n_iters;
-    a.gamma = gamma; a.lr = lr; a.jitter = jitter;
-    a.X = st.in(X, (size_t)B * N * R);
-    a.y_mean = st.in(y_mean, (size_t)B * N);
-    a.y_var = st.in(y_var, (size_t)B * N);
-    a.mu = st.out(mu, (size_t)B * N);
-    a.cov = st.out(cov, (size_t)B * N * N);
-    a.chol = st.out(cov_chol, (size_t)B * N * N);
-    a.logdet = st.out(logdet, (size_t)B);
-    a.hyp = st.out(hyp, (size_t)B * 2);
-    const int ntrace = (n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
-    a.loss_trace = ntrace > 0 ? st.out(loss_trace, (size_t)B * ntrace) : nullptr;
-    a.basis = st.out(ll_basis, (size_t)B * 2 * N);
-    std::vector<int> hinfo(B, 0);
-    a.info_host = hinfo.data();
-    std::string err;
-    const int rc = bayens_f32_fit(c->f32, a, &err);
-    if (rc != 0) return fail(c, rc > 0 ? rc : BAYENS_E_ARG, "gp_fit_batch_f32: " + err);
-    st.finish();
-    int bad = 0;
-    for (int b = 0; b < B; ++b) { if (info) info[b] = hinfo[b]; if (hinfo[b]) bad = hinfo[b]; }
-    if (bad) return fail(c, BAYENS_E_NOTPD, "gp_fit_batch_f32: matrix not positive definite (see info[])");
-    return 0;
+    return fit_batch_f32_impl(c, "gp_fit_batch_f32", loc, B, N, R, nullptr, nullptr, (size_t)B * N * R, X, y_mean, y_var, kernel, n_iters,
+                              gamma, lr, jitter, mu, cov, cov_chol, logdet, hyp, loss_trace, info, ll_basis);
+  });
+}
+
+int bayens_gp_fit_batch_ragged_f32(bayens_ctx* c, int loc, int B, int N, const int* R, const size_t* x_off, const float* X,
+                                   const float* y_mean, const float* y_var, int kernel, int n_iters, double gamma, double lr,
+                                   double jitter, float* mu, float* cov, float* cov_chol, double* logdet, double* hyp,
+                                   double* loss_trace, int* info, float* ll_basis) {
+  return guarded(c, [&]() {
+    if (B <= 0 || N <= 0 || !R || !X || !y_mean || !y_var || !mu || !cov || n_iters < 0)
+      return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged_f32: bad argument");
+    if (kernel < 0 || kernel > 2) return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged_f32: unknown kernel id");
+    int Rmax = 0;
+    std::vector<size_t> off(B);
+    size_t total = 0;
+    for (int b = 0; b < B; ++b) {
+      if (R[b] <= 0) return fail(c, BAYENS_E_ARG, "gp_fit_batch_ragged_f32: every member needs at least one realisation");
+      Rmax = std::max(Rmax, R[b]);
+      off[b] = x_off ? x_off[b] : total;
+      total = std::max(total, off[b] + (size_t)N * R[b]);
+    }
+    return fit_batch_f32_impl(c, "gp_fit_batch_ragged_f32", loc, B, N, Rmax, R, off.data(), total, X, y_mean, y_var, kernel, n_iters,
+                              gamma, lr, jitter, mu, cov, cov_chol, logdet, hyp, loss_trace, info, ll_basis);
   });
 }
 

@@ -8,7 +8,7 @@
 struct BayensF32Args {
   int B, N, R, kernel, n_iters;
   double gamma, lr, jitter;
-  const float* X;        // device [B][N][R]
+  const float* X;        // device [B][N][R] (ragged: member b's [N][Rv[b]] block xoff[b] elements in)
   const float* y_mean;   // device [B][N]
   const float* y_var;    // device [B][N]
   float* mu;             // device [B][N]
@@ -20,6 +20,9 @@ struct BayensF32Args {
   double* loss_trace;    // device [B][ceil(n_iters/25)], nullable
   float* basis;          // device [B][2][N], nullable
   int* info_host = nullptr;        // host [B]
+  // a ragged batch (device arrays [B], null: uniform R): see FitParams in driver.h
+  const int* Rv = nullptr;
+  const long* xoff = nullptr;
 };
 
 // `side`: look-ahead stream to borrow (the context's; may be null: the instance then creates its own on first use)

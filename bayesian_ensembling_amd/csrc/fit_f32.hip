@@ -72,6 +72,8 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
         st->kpark_cap = need;
       }
       g.kpark = st->kpark;
+      g.Rv = a.Rv;
+      g.xoff = a.xoff;
       smalln::small_fit(st->stream, g, st->n_cus);
       BAYENS_HIP(hipMemcpyAsync(a.info_host, st->small_info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
       BAYENS_HIP(hipStreamSynchronize(st->stream));
@@ -83,6 +85,8 @@ int bayens_f32_fit(void* state, const BayensF32Args& a, std::string* err) {
     FitParams fp{a.N, a.R, a.kernel, a.n_iters, a.gamma, a.lr, a.jitter};
     fp.loss_stride = (a.n_iters + LOSS_EVERY - 1) / LOSS_EVERY;
     fp.loss_trace = fp.loss_stride > 0 ? a.loss_trace : nullptr;
+    fp.Rv = a.Rv;
+    fp.xoff = a.xoff;
     gp_fit(st->prims, w, fp, a.X, a.y_mean, a.y_var, a.mu, a.cov, a.chol, a.logdet, a.hyp, a.basis, a.var);
     BAYENS_HIP(hipMemcpyAsync(a.info_host, w.info, (size_t)a.B * sizeof(int), hipMemcpyDeviceToHost, st->stream));
     BAYENS_HIP(hipStreamSynchronize(st->stream));

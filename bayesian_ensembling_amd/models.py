@@ -207,14 +207,13 @@ class GPDTW1D:
                                   b.hyp, kernel=kid, basis=b.basis, f32=f32, loss=pr["loss"])
         else:
             fctx.gp_fit_batch_ragged_dev(pr["B"], pr["N"], pr["Rs"], pr["off"], pr["X"], pr["y"], pr["nu"], n_optim_nits, b.mu, b.cov,
-                                         b.chol, b.logdet, b.hyp, kernel=kid, basis=b.basis, loss=pr["loss"])
+                                         b.chol, b.logdet, b.hyp, kernel=kid, basis=b.basis, loss=pr["loss"], f32=f32)
 
     def fit_collection(self, process_models, n_optim_nits: int = 500, compile_objective: bool = False,
                        progress_bar: bool = True):
         """All members at once.  The reference fits them one after the other (ensembles/data.py:385-395); their realisation
         counts differ (its pickled collections: R in {25, 9, 16}, {25, 25, 5, 6, 3, 5}; experiments/data: 3 ... 50).  Every
-        member of equal length N goes into ONE launch whatever its R (bayens_gp_fit_batch_ragged); the fp32 mode keeps one
-        launch per distinct realisation count."""
+        member of equal length N goes into ONE launch whatever its R (bayens_gp_fit_batch_ragged{,_f32})."""
         del compile_objective   # accepted for signature compatibility (a tf.function knob)
         if self.per_gridpoint and all(pm.model_data.ndim > 2 for pm in process_models):
             return self.fit_field(process_models, n_optim_nits)
@@ -233,14 +232,14 @@ class GPDTW1D:
         f32 = self.dtype != np.float64
         groups = {}
         for i, (X, _, _) in enumerate(pro):
-            groups.setdefault(X.shape if f32 else X.shape[0], []).append(i)
+            groups.setdefault(X.shape[0], []).append(i)
         dists = [None] * len(process_models)
         kid = _lib.KERNEL_IDS[self.kernel]
         n_loss = (int(n_optim_nits) + 24) // 25 if progress_bar else 0
         # set-up of every group on the calling thread (allocation cache and uploads of `ctx`), then the launches
         prepared = [self._prepare_group(ctx, pro, idxs, n_loss) for idxs in groups.values()]
         try:
-            if len(prepared) > 1 and not f32:
+            if len(prepared) > 1:
                 # Groups of different length are independent launches: a script's historical N = 165 and projection N = 86
                 # collections (experiments/full_experiment_script.py:87-113) run BESIDE each other, each through its own context
                 # = stream, driven by a helper thread (the blocking C call releases the GIL), so that the workgroups of one and of

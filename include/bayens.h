@@ -169,6 +169,12 @@ int bayens_gp_fit_batch_f32(bayens_ctx* ctx, int loc, int B, int N, int R,
                             int kernel, int n_iters, double gamma, double lr, double jitter,
                             float* mu, float* cov, float* cov_chol, double* logdet,
                             double* hyp, double* loss_trace, int* info, float* ll_basis);
+/* ... and for members whose realisation counts differ (bayens_gp_fit_batch_ragged in fp32; x_off in floats). */
+int bayens_gp_fit_batch_ragged_f32(bayens_ctx* ctx, int loc, int B, int N, const int* R, const size_t* x_off,
+                                   const float* X, const float* y_mean, const float* y_var,
+                                   int kernel, int n_iters, double gamma, double lr, double jitter,
+                                   float* mu, float* cov, float* cov_chol, double* logdet, double* hyp,
+                                   double* loss_trace, int* info, float* ll_basis);
 
 /* Distribution.__post_init__ for a caller-supplied full covariance (ensembles/data.py:38-39):
  * chol [B][N][N] lower, logdet [B]; with mu [B][N] given, ll_basis [B][2][N] as above (both may be NULL). */

@@ -162,3 +162,31 @@ def test_collections_with_ragged_members_through_the_plugin_api(ctx):
     assert relerr(w.values, w_ref) < 1e-8
     rm, rv, _ = go.barycentre(w_ref, np.stack(mus), np.stack(vs))
     assert relerr(post.mu, rm) < 1e-8 and relerr(post.covariance, rv) < 1e-8
+
+
+@pytest.mark.parametrize("N", [60, 300])
+def test_ragged_collection_in_float32(ctx, N):
+    """GPDTW1D(dtype="float32") on members of R = 4, 9, 4, 6: ONE launch of bayens_gp_fit_batch_ragged_f32 (fused small-member kernel at
+    N = 60, the fp32 general path at N = 300) - bit for bit what uniform fp32 batches of each R give, and within BASELINE.json's fp32
+    bar (1e-3 relative) of the float64 oracle."""
+    import bayesian_ensembling_amd as es
+    from bayesian_ensembling_amd.labelled import DataArray
+    T, Rs = 3, [4, 9, 4, 6]
+    t = np.arange(N)
+    datas = [go.synthetic_ensemble(1, N, R=r, seed=300 + k)[0][0] for k, r in enumerate(Rs)]
+    mk = lambda a, name: es.ProcessModel(DataArray(a, ("realisation", "time"), {"realisation": np.arange(a.shape[0]), "time": t}), name)
+    mc = es.ModelCollection([mk(d, f"m{k}") for k, d in enumerate(datas)])
+    mc.fit(model=es.GPDTW1D(dtype="float32"), n_optim_nits=T, progress_bar=False)
+    for r in sorted(set(Rs)):
+        idx = [k for k, rr in enumerate(Rs) if rr == r]
+        X = np.stack([datas[k].T for k in idx])
+        ref = ctx.gp_fit_batch(X, np.stack([datas[k].mean(axis=0) for k in idx]), np.stack([datas[k].var(axis=0) for k in idx]), T,
+                               dtype=np.float32)
+        for j, k in enumerate(idx):
+            assert np.array_equal(np.asarray(mc[k].distribution.mean.values), ref["mu"][j].astype(np.float64)), (r, k)
+            assert np.array_equal(np.asarray(mc[k].distribution.covariance), ref["cov"][j].astype(np.float64)), (r, k)
+    with threadpool_limits(2):
+        for k in (0, 1):
+            X, yv, nu = go.prologue(datas[k])
+            mo, co, _ = go.gp_fit(X, yv, nu, T)[:3]
+            assert relerr(mc[k].distribution.mean.values, mo) < 1e-3 and relerr(np.asarray(mc[k].distribution.covariance), co) < 1e-3
