@@ -12,11 +12,17 @@ constexpr int PANEL_MAX = 256;   // widest diagonal block the fused panel solve 
 // A side section (Prims::side_begin / side_end) that cannot leave the back end on the side stream when a launch
 // inside it throws.
 namespace {
+constexpr int SIDE_PASSES = 1;      // the side channel of the fit's O(N^2) passes (prims.h side_end / side_join)
 struct SideSection {
   Prims& P;
   bool open = true;
-  explicit SideSection(Prims& p) : P(p) { P.side_begin(); }
-  void end() { open = false; P.side_end(); }
+  int ch;
+  explicit SideSection(Prims& p, int channel = 0) : P(p), ch(channel) {
+    static const bool no_passes = std::getenv("BAYENS_NO_SIDE_PASSES") != nullptr;      // (measurement switch)
+    if (ch == SIDE_PASSES && no_passes) open = false;
+    else P.side_begin();
+  }
+  void end() { if (open) { open = false; P.side_end(ch); } }
   ~SideSection() { if (open) P.side_cancel(); }
 };
 }  // namespace
@@ -136,22 +142,31 @@ static void potrf_left(Prims& P, int nb, int n, Mat A, real* inv, long inv_strid
   }
 }
 
-void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows) {
+void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows, real* lower_out, int n_out) {
   const int NB = potrf_block_width();
-  if (n <= NB) {
-    potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+  if (n <= NB || potrf_left_looking()) {
+    if (n <= NB) potrf_rec(P, nb, n, A, inv, inv_stride, info, 0, extra_rows);
+    else potrf_left(P, nb, n, A, inv, inv_stride, info, extra_rows);
+    if (lower_out) P.extract(nb, n_out, A, lower_out, 2);
     return;
   }
-  if (potrf_left_looking()) {
-    potrf_left(P, nb, n, A, inv, inv_stride, info, extra_rows);
-    return;
-  }
+  // the finished block column [c0, c1) of the factor -> the compact output, on the side queue (a pass bound by HBM, beside
+  // products bound by the matrix pipes and a chain bound by latency)
+  auto export_cols = [&](int c0, int c1) {
+    if (!lower_out || c0 >= n_out) return;
+    SideSection side(P, SIDE_PASSES);
+    P.extract_cols(nb, n_out, A, lower_out, c0, c1 < n_out ? c1 : n_out);
+    side.end();
+  };
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int w = n - k0 < NB ? n - k0 : NB;
     const int below = n - k0 - w;
     real* invk = inv_at(inv, k0 / LEAF);
     potrf_rec(P, nb, w, A.sub(k0, k0), invk, inv_stride, info, k0, below == 0 ? extra_rows : 0);
-    if (below == 0) break;
+    if (below == 0) {
+      export_cols(k0, k0 + w);
+      break;
+    }
     const int m = below + extra_rows;
     trsm_rlt(P, nb, m, w, A.sub(k0, k0), invk, inv_stride, A.sub(k0 + w, k0));
     // Look-ahead: the next block column is updated first, on the main stream; the rest of the trailing part is
@@ -168,8 +183,10 @@ void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info
              GEMM_TB | GEMM_TRI_OUT, 0.0);
       side.end();
     }
+    export_cols(k0, c1);              // (behind the trailing update on the side queue: that one is waited for first)
   }
   P.side_join();
+  if (lower_out) P.side_join(SIDE_PASSES);
 }
 
 // chol(cov) + logdet + the log-likelihood basis (L_c^-1 1, L_c^-1 mu), covariance (lower part valid) in `src`
@@ -187,8 +204,7 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
   if (!in_place) P.tri_copy(nb, Np, src, ws.T1);
   Mat rows = F.sub(in_pad ? N : Np, 0);
   if (basis) P.basis_rows_set(nb, N, Np, rows, mu_pad, in_pad ? 1 : 0);
-  potrf(P, nb, Np, F, ws.invL, ws.inv_stride(), ws.info, extra);
-  if (chol) P.extract(nb, N, F, chol, 2);
+  potrf(P, nb, Np, F, ws.invL, ws.inv_stride(), ws.info, extra, chol, N);
   if (logdet) P.logdet(nb, N, F, logdet);
   if (basis) P.basis_rows_get(nb, N, Np, rows, basis);
 }
@@ -257,6 +273,14 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
     const bool woodbury = it0 && fp.n_iters >= 2;
     const bool first = it0 && !woodbury && sizeof(real) == sizeof(double);
     const bool lam_direct = woodbury || first;
+    // O(N^2) passes that nothing on the way waits for run on the side queue, beside the products and the factorisation's chain
+    // (they are bound by HBM, those by the matrix pipes and by latency): woodbury - the identity the triangular inverse starts from;
+    // every iteration - theta1's update; a general iteration - the mirror image of G the solves take as their right-hand side.
+    if (woodbury) {
+      SideSection side(P, SIDE_PASSES);
+      P.identity(nb, Np, ws.T2);
+      side.end();
+    }
     // K0 and L = chol(K0 + jitter I) at the CURRENT hypers                       (models.py:209)
     P.mark("kmat");
     // (the blocks above the block diagonal of Lb are cleared by the first call of the fit and stay clear; woodbury: the same
@@ -288,14 +312,19 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
       if (!woodbury) P.tri_copy(nb, Np, ws.Lam, ws.Cb);
     } else {
       P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 0.0, ws.T2, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
-      P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1);   // Lam, Cb = tril(Lam), T1 = G (full)
+      P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1, 1);   // Lam, Cb = tril(Lam)
     }
-    P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
+    {
+      SideSection side(P, SIDE_PASSES);
+      if (!lam_direct) P.lam_update(nb, Np, ws.T2, fp.gamma, ws.Lam, ws.Cb, ws.T1, 2);   // T1 = G (full)
+      P.lt_dvec(nb, Np, ws.Lb, ws.y, ws.nu, fp.gamma, 1.0 - fp.gamma, ws.theta1);
+      side.end();
+    }
     P.mark("potrf Lam");
     if (!pair) potrf(P, nb, Np, ws.Cb, ws.invC, is, ws.info);         // C = chol(Lam)   (woodbury: chol(diag(nu) + gamma K))
     if (woodbury) {
       P.mark("P = (nu + gamma K)^-1");
-      P.identity(nb, Np, ws.T2);
+      P.side_join(SIDE_PASSES);
       trsm_rln(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T2, true);       // triangular inverse (lower)
       P.gemm(nb, Np, Np, Np, 1.0, ws.T2, ws.T2, 0.0, ws.T1, GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);   // P (lower blocks)
       P.symv_lower(nb, Np, ws.T1, ws.y, ws.avec);                     // p = P y
@@ -306,6 +335,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
       continue;
     }
     P.mark("G S solves");
+    P.side_join(SIDE_PASSES);
     // G S is all the Adam step (models.py:210) needs of S: for i >= j
     //   (L^T Lbar)_ij = u_i m_j + (G S)_ij,  Lbar = tril(D ((L m - y) m^T + L S)),  u = L^T D (L m - y),
     // because row k of Lbar only meets L_ki with k >= i >= j, where the tril() does not cut.
@@ -340,15 +370,24 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   P.mark("predict: kmat+potrf");
 
   // prediction at the FINAL hypers with the (m, C) of the last natgrad step       (models.py:217-220)
+  // (T2 is free from here on unless the loss is sampled below: the identity the triangular inverse starts from is written
+  //  beside the kernel matrix and its factorisation)
+  const bool sample_last = fp.loss_trace && fp.n_iters > 0 && (fp.n_iters - 1) % LOSS_EVERY == 0;
+  if (!sample_last) {
+    SideSection side(P, SIDE_PASSES);
+    P.identity(nb, Np, ws.T2);
+    P.diag_init(nb, Np, ws.nu, fp.jitter, ws.Lam);                    // Lam reused: diag(nu + J), the first term of the covariance
+    side.end();
+  }
   P.kmat(nb, N, Np, fp.R, X, ws.ustate, fp.kernel, fp.jitter, ws.Lb, fp.n_iters == 0, Mat{nullptr, 0, 0}, 0.0, nullptr, fp.Rv, fp.xoff);
   potrf(P, nb, Np, ws.Lb, ws.invL, is, ws.info);
-  if (fp.loss_trace && fp.n_iters > 0 && (fp.n_iters - 1) % LOSS_EVERY == 0)
-    neg_elbo(P, ws, fp, (fp.n_iters - 1) / LOSS_EVERY);
+  if (sample_last) neg_elbo(P, ws, fp, (fp.n_iters - 1) / LOSS_EVERY);
   // With K0 = L L^T - J I (J the jitter):  A^T = K0 L^-T = L - J L^-T  and  K0 - A^T A = J I - J^2 L^-T L^-1,
   // so the full solve K0 L^-T and the rank-N update A^T A shrink to the triangular inverse (a lower-rhs solve on I,
   // N^3/3) and the lower x lower product L^-T L^-1 (N^3/3):  cov = diag(nu + J) - J^2 L^-T L^-1 + (A^T C^-T)(A^T C^-T)^T.
   P.mark("predict: L^-1, A^T");
-  P.identity(nb, Np, ws.T2);
+  if (sample_last) P.identity(nb, Np, ws.T2);
+  P.side_join(SIDE_PASSES);
   trsm_rln(P, nb, Np, Np, ws.Lb, ws.invL, is, ws.T2, true);           // L^-1 (lower)
   P.at_from_linv(nb, Np, ws.Lb, ws.T2, fp.jitter, ws.T1);             // A^T = L - J L^-T
   P.gemv_n(nb, Np, ws.T1, ws.mvec, ws.muvec);                         // mu = A^T m
@@ -356,7 +395,7 @@ void gp_fit(Prims& P, FitWorkspace& ws, const FitParams& fp, const real* X, cons
   P.mark("predict: A^T C^-T");
   trsm_rlt(P, nb, Np, Np, ws.Cb, ws.invC, is, ws.T1);                 // A^T C^-T (in place)
   P.mark("predict: cov products");
-  P.diag_init(nb, Np, ws.nu, fp.jitter, ws.Lam);                      // Lam reused: diag(nu + J)
+  if (sample_last) P.diag_init(nb, Np, ws.nu, fp.jitter, ws.Lam);     // Lam reused: diag(nu + J)
   P.gemm(nb, Np, Np, Np, -fp.jitter * fp.jitter, ws.T2, ws.T2, 1.0, ws.Lam,
          GEMM_TA | GEMM_TRI_OUT | GEMM_KTRIM_TN_LOWER, 0.0);
   P.gemm(nb, Np, Np, Np, 1.0, ws.T1, ws.T1, 1.0, ws.Lam, GEMM_TB | GEMM_TRI_OUT, 0.0);

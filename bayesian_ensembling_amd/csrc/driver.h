@@ -48,7 +48,10 @@ struct FitWorkspace {
 // ([leaf][64][64] per member, leaf index relative to A's first row).  A's strictly-upper 64-blocks are
 // never touched (callers keep them zero).
 // extra_rows (0 or a multiple of 64) rows stored directly below A in the same buffer are carried to E L^-T.
-void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows = 0);
+// lower_out (nullable): compact [nb][n_out][n_out] copy of the factor's leading n_out rows / columns, zeros above the diagonal
+// (Prims::extract mode 2) - written block column by block column as the columns become final, beside the rest of the factorisation.
+void potrf(Prims& P, int nb, int n, Mat A, real* inv, long inv_stride, int* info, int extra_rows = 0,
+           real* lower_out = nullptr, int n_out = 0);
 
 // B[m x n] <- B * L^-T  (solve X L^T = B), L n x n lower with inverted diagonal blocks in inv.
 void trsm_rlt(Prims& P, int nb, int m, int n, Mat L, const real* inv, long inv_stride, Mat B);

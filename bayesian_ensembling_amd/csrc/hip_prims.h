@@ -53,8 +53,8 @@ struct HipPrims : Prims {
   unsigned long long* leaf_stamps = nullptr;   // diagnostic only (bayens_bench_leaf)
   // look-ahead stream of the blocked Cholesky (side_begin / side_end / side_join); created on first use
   hipStream_t side_stream = nullptr, main_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool in_side = false, side_pending = false, owns_side = true;
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool in_side = false, side_pending[2] = {false, false}, owns_side = true;
 
   explicit HipPrims(hipStream_t s) : stream(s) {}
   // per-launch accounting on/off: recorded events go back to the pool, counters are cleared
@@ -83,8 +83,8 @@ struct HipPrims : Prims {
   // together, and the stream's hardware queue was chosen at context creation - profiles/r05_hw_queues.txt)
   void borrow_side_stream(hipStream_t s);
   void side_begin() override;
-  void side_end() override;
-  void side_join() override;
+  void side_end(int ch = 0) override;
+  void side_join(int ch = 0) override;
   void side_cancel() noexcept override { if (in_side) { stream = main_stream; in_side = false; } }
 
   void gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
@@ -104,7 +104,7 @@ struct HipPrims : Prims {
   void scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) override;
   void lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta,
                real* out) override;
-  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override;
+  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts = 3) override;
   void form_phi(int nb, int n, Mat M, const real* u, const real* mvec, Mat Phi, double scale, double diag_add,
                 double u_scale) override;
   void symv_lower(int nb, int n, Mat S, const real* v, real* out) override;
@@ -125,6 +125,7 @@ struct HipPrims : Prims {
   void extract(int nb, int N, Mat src, real* dst, int mode) override;
   void extract_vec(int nb, int N, int Np, const real* src, real* dst) override;
   void extract_diagonal(int nb, int N, Mat src, real* dst) override;
+  void extract_cols(int nb, int N, Mat src, real* dst, int c0, int c1) override;
   void logdet(int nb, int N, Mat Lc, double* out) override;
   void info_fold(int nb, int* pair, int* info) override;
   void hyp_out(int nb, const double* ustate, double* hyp) override;

@@ -205,7 +205,7 @@ __global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, 
 
 // natural-gradient precision update (prims.h lam_update): one workgroup per lower 64x64 block (bi >= bj) updates
 // Lam, seeds Cb (lower; the mirrored block of Cb is cleared) and mirrors G into the full symmetric Gfull.
-__global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
+__global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts) {
   __shared__ real tile[64][65];
   const int b = blockIdx.z, bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi) return;
@@ -222,14 +222,15 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   for (int q = 0; q < 16; ++q) {
     const int i = bi * 64 + r0 + 4 * q;
     gv[q] = g[(long)i * G.ld + j];
-    lv[q] = j <= i ? lam[(long)i * Lam.ld + j] : (real)0;
+    lv[q] = (j <= i && (parts & 1)) ? lam[(long)i * Lam.ld + j] : (real)0;
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
     const int i = bi * 64 + r;
     tile[r][c] = gv[q];
-    gf[(long)i * Gfull.ld + j] = gv[q];                   // the diagonal block of G is complete (both triangles)
+    if (parts & 2) gf[(long)i * Gfull.ld + j] = gv[q];    // the diagonal block of G is complete (both triangles)
+    if (!(parts & 1)) continue;
     if (j <= i) {
       const double v = (1.0 - gamma) * lv[q] + gamma * (gv[q] + (i == j ? 1.0 : 0.0));
       lam[(long)i * Lam.ld + j] = v;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
       cb[(long)i * Cb.ld + j] = 0.0;                      // strict upper part inside a diagonal block
     }
   }
-  if (bi == bj) return;
+  if (bi == bj || !(parts & 2)) return;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) {                           // mirrored block (bj, bi): G^T into Gfull
@@ -352,6 +353,26 @@ __global__ void extract_vec_kernel(int N, int Np, const real* src, real* dst) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) dst[(long)b * N + i] = src[(long)b * Np + i];
+}
+
+__global__ void extract_cols_kernel(int N, Mat src, real* dst, int c0, int c1) {
+  const int b = blockIdx.z;
+  const int j = c0 + blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const real* s = src.p + b * src.stride;
+  real* d = dst + (long)b * N * N;
+  if (j >= c1) return;
+  real v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    v[q] = (i < N && j <= i) ? s[(long)i * src.ld + j] : (real)0;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    if (i < N) d[(long)i * N + j] = v[q];
+  }
 }
 
 __global__ void extract_diagonal_kernel(int N, Mat src, real* dst) {
@@ -1599,7 +1620,7 @@ HipPrims::~HipPrims() {
   for (auto& e : prof.events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : prof.pool) (void)hipEventDestroy(e);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
-  if (ev_join) (void)hipEventDestroy(ev_join);
+  for (hipEvent_t e : ev_join) if (e) (void)hipEventDestroy(e);
   if (side_stream && owns_side) (void)hipStreamDestroy(side_stream);
 }
 
@@ -1610,7 +1631,7 @@ void HipPrims::ensure_side_stream() {
     // DESIGN.md section 6); the latency-bound side of the overlap raises its wave priority instead (s_setprio).
     BAYENS_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     BAYENS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    BAYENS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (hipEvent_t& e : ev_join) BAYENS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
 }
 void HipPrims::borrow_side_stream(hipStream_t s) {
@@ -1618,7 +1639,7 @@ void HipPrims::borrow_side_stream(hipStream_t s) {
   side_stream = s;
   owns_side = false;
   BAYENS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-  BAYENS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  for (hipEvent_t& e : ev_join) BAYENS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }
 // The per-launch accounting (prof.enabled) wants kernels one after another on one stream: no side stream then.
 void HipPrims::side_begin() {
@@ -1633,17 +1654,17 @@ void HipPrims::side_begin() {
   stream = side_stream;
   in_side = true;
 }
-void HipPrims::side_end() {
+void HipPrims::side_end(int ch) {
   if (!in_side) return;
-  BAYENS_HIP(hipEventRecord(ev_join, stream));
+  BAYENS_HIP(hipEventRecord(ev_join[ch], stream));
   stream = main_stream;
   in_side = false;
-  side_pending = true;
+  side_pending[ch] = true;
 }
-void HipPrims::side_join() {
-  if (!side_pending) return;
-  BAYENS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
-  side_pending = false;
+void HipPrims::side_join(int ch) {
+  if (!side_pending[ch]) return;
+  BAYENS_HIP(hipStreamWaitEvent(stream, ev_join[ch], 0));
+  side_pending[ch] = false;
 }
 
 void HipPrims::mark(const char* phase) {
@@ -1730,8 +1751,8 @@ void HipPrims::symv_lower(int nb, int n, Mat S, const real* v, real* out) {
   hipLaunchKernelGGL(symv_lower_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, S, v, out);
   LAUNCH_CHECK();
 }
-void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) {
-  hipLaunchKernelGGL(lam_update_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, G, gamma, Lam, Cb, Gfull);
+void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts) {
+  hipLaunchKernelGGL(lam_update_kernel, tile_grid(n, nb), dim3(256), 0, stream, n, G, gamma, Lam, Cb, Gfull, parts);
   LAUNCH_CHECK();
 }
 void HipPrims::aug_set(int nb, int n, Mat rows, const real* vec, int zero_rows) {
@@ -1814,6 +1835,11 @@ void HipPrims::extract(int nb, int N, Mat src, real* dst, int mode) {
 }
 void HipPrims::extract_vec(int nb, int N, int Np, const real* src, real* dst) {
   hipLaunchKernelGGL(extract_vec_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, stream, N, Np, src, dst);
+  LAUNCH_CHECK();
+}
+void HipPrims::extract_cols(int nb, int N, Mat src, real* dst, int c0, int c1) {
+  if (c1 <= c0) return;
+  hipLaunchKernelGGL(extract_cols_kernel, dim3((c1 - c0 + 63) / 64, (N + 63) / 64, nb), dim3(256), 0, stream, N, src, dst, c0, c1);
   LAUNCH_CHECK();
 }
 void HipPrims::extract_diagonal(int nb, int N, Mat src, real* dst) {

@@ -66,9 +66,12 @@ struct Prims {
   // Concurrency hints.  Work issued between side_begin() and side_end() starts after everything issued before
   // side_begin() and may overlap whatever the caller issues after side_end(); side_join() makes everything issued
   // after it wait for that side work.  Program order (these defaults) is always a valid schedule.
+  // `ch`: two independent join points over the same side queue - 0 the look-ahead of the blocked factorisation, 1 the O(N^2)
+  // passes the fit moves out of the way of its products (SIDE_PASSES); joining one channel does not wait for the other's work.
+  // (A queue of its own for channel 1 was measured: no faster, profiles/r05_side_passes.txt.)
   virtual void side_begin() {}
-  virtual void side_end() {}
-  virtual void side_join() {}
+  virtual void side_end(int ch = 0) { (void)ch; }
+  virtual void side_join(int ch = 0) { (void)ch; }
   // leaves a side section without publishing it (error path: a launch inside the section threw); never throws
   virtual void side_cancel() noexcept {}
 
@@ -118,7 +121,8 @@ struct Prims {
   //   Lam <- (1-gamma) Lam + gamma (I + G) on the lower triangle;  Cb <- tril(Lam) (zeros above the diagonal inside
   //   the diagonal 64-blocks; the blocks above the block diagonal are neither written nor ever read);
   //   Gfull <- G mirrored to a full symmetric matrix
-  virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) = 0;
+  // parts: 1 = Lam and Cb, 2 = Gfull, 3 = both (the two halves touch disjoint outputs and may run on different queues)
+  virtual void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts = 3) = 0;
   // Phi(L^T Lbar) without forming Lbar: for i >= j, (L^T Lbar)_ij = u_i m_j + (G S)_ij with u = L^T D (L m - y)
   //   Phi_ij = u_i m_j + GS_ij (i > j), half of it on the diagonal, 0 above,   GS_ij = scale * M_ij + diag_add * delta_ij.
   // (scale, diag_add) = (1, 0): M is G S itself.  In the FIRST iteration Lam_old = I, so Lam = I + gamma G and
@@ -169,6 +173,9 @@ struct Prims {
   // 2 lower triangle with zeros above
   virtual void extract(int nb, int N, Mat src, real* dst, int mode) = 0;
   virtual void extract_vec(int nb, int N, int Np, const real* src, real* dst) = 0;
+  // columns [c0, c1) of extract(mode 2): dst[b][i][j] = j <= i ? src_b[i][j] : 0 for i < N, c0 <= j < c1 <= N - a factor's block
+  // column leaves for the compact output as soon as it is final, beside the rest of the factorisation
+  virtual void extract_cols(int nb, int N, Mat src, real* dst, int c0, int c1) = 0;
   // dst[b][i] = src_b[i][i], i < N (the reduced export: marginal variances without the N x N table)
   virtual void extract_diagonal(int nb, int N, Mat src, real* dst) = 0;
   virtual void logdet(int nb, int N, Mat Lc, double* out) = 0;   // sum_{i<N} log Lc_ii

@@ -192,19 +192,23 @@ struct CpuPrims : Prims {
         out[(size_t)b * n + j] = (beta != 0.0 ? beta * out[(size_t)b * n + j] : 0.0) + alpha * s;
       }
   }
-  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull) override {
+  void lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts = 3) override {
     for (int b = 0; b < nb; ++b)
       for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) {
           const double g = G.p[b * G.stride + (size_t)i * G.ld + j];
-          double& lam = Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j];
-          lam = (1 - gamma) * lam + gamma * (g + (i == j ? 1.0 : 0.0));
-          Cb.p[b * Cb.stride + (size_t)i * Cb.ld + j] = lam;
-          // zeros only inside the diagonal 64-block; blocks above the block diagonal are never read (and stay
-          // NaN-poisoned here, so a read would show up)
-          if (j < i && j / 64 == i / 64) Cb.p[b * Cb.stride + (size_t)j * Cb.ld + i] = 0.0;
-          Gfull.p[b * Gfull.stride + (size_t)i * Gfull.ld + j] = g;
-          Gfull.p[b * Gfull.stride + (size_t)j * Gfull.ld + i] = g;
+          if (parts & 1) {
+            double& lam = Lam.p[b * Lam.stride + (size_t)i * Lam.ld + j];
+            lam = (1 - gamma) * lam + gamma * (g + (i == j ? 1.0 : 0.0));
+            Cb.p[b * Cb.stride + (size_t)i * Cb.ld + j] = lam;
+            // zeros only inside the diagonal 64-block; blocks above the block diagonal are never read (and stay
+            // NaN-poisoned here, so a read would show up)
+            if (j < i && j / 64 == i / 64) Cb.p[b * Cb.stride + (size_t)j * Cb.ld + i] = 0.0;
+          }
+          if (parts & 2) {
+            Gfull.p[b * Gfull.stride + (size_t)i * Gfull.ld + j] = g;
+            Gfull.p[b * Gfull.stride + (size_t)j * Gfull.ld + i] = g;
+          }
         }
   }
   void symv_lower(int nb, int n, Mat S, const double* v, double* out) override {
@@ -353,6 +357,12 @@ struct CpuPrims : Prims {
   }
   void extract_vec(int nb, int N, int Np, const double* src, double* dst) override {
     for (int b = 0; b < nb; ++b) std::memcpy(dst + (size_t)b * N, src + (size_t)b * Np, N * sizeof(double));
+  }
+  void extract_cols(int nb, int N, Mat src, double* dst, int c0, int c1) override {
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < N; ++i)
+        for (int j = c0; j < c1; ++j)
+          dst[((size_t)b * N + i) * N + j] = j <= i ? src.p[b * src.stride + (size_t)i * src.ld + j] : 0.0;
   }
   void extract_diagonal(int nb, int N, Mat src, double* dst) override {
     for (int b = 0; b < nb; ++b)

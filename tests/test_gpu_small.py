@@ -97,11 +97,17 @@ def test_failed_pivot_is_reported_per_member(ctx):
     assert e.value.code == -2 and e.value.info[1] > 0 and e.value.info[0] == 0 and e.value.info[2] == 0
 
 
-def test_reduced_export_rejects_large_members(ctx):
-    X = np.zeros((1, 255, 2))
-    with pytest.raises(L.BayensError) as e:
-        ctx.gp_fit_batch_reduced(X, np.zeros((1, 255)), np.ones((1, 255)), 1)
-    assert e.value.code == -1
+def test_reduced_export_of_large_members_through_the_general_path(ctx):
+    """N > 254 (round 5; rounds 1-4 refused it): the reduced export comes from the general path - the same mu / diag(cov) /
+    logdet / hypers / basis as the full export of the same fit, bit for bit, with no N x N table leaving the device."""
+    data, _ = go.synthetic_ensemble(3, 255, R=4, seed=255)
+    X, y, nu = member_inputs(data)
+    red = ctx.gp_fit_batch_reduced(X, y, nu, 2)
+    full = ctx.gp_fit_batch(X, y, nu, 2)
+    assert not red["info"].any()
+    assert np.array_equal(red["mu"], full["mu"]) and np.array_equal(red["var"], np.diagonal(full["cov"], axis1=1, axis2=2))
+    for key in ("logdet", "hyp", "basis"):
+        assert np.array_equal(red[key], full[key]), key
 
 
 def test_reduced_export_of_mid_size_members_through_the_fused_mid_size_kernel(ctx):
