@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "hip_prims.h"
 
 namespace BAYENS_NS {
@@ -36,22 +38,49 @@ __device__ __forceinline__ double wave_max(double v) {
 // degree-13 Taylor polynomial + v_ldexp_f64; v_rsq_f64 seed + two Goldschmidt corrections): the kernel-matrix passes are bound by
 // the fp64 vector rate, and the library's exp / sqrt cost half as much again for range and special-case handling these arguments
 // never need (round 4)
+// A double constant held in a scalar register pair.  Left to itself the compiler turns every coefficient of a Horner chain into
+// two v_mov_b32 in front of a v_fmac_f64 (the accumulator form wants the addend in the destination register): 26 extra vector
+// instructions per exponential, in kernels that are bound by the vector issue rate (VALUBusy 50 % = the fp64 rate, round 5).  An
+// opaque s_mov pair (scalar unit, beside the vector work; identical asm statements are merged) makes the addend the one scalar
+// operand a v_fma_f64 may take.
+#define BAYENS_SCONST(name, hi, lo)                                \
+  int name##_h, name##_l;                                          \
+  asm("s_mov_b32 %0, " #lo : "=s"(name##_l));                      \
+  asm("s_mov_b32 %0, " #hi : "=s"(name##_h));                      \
+  const double name = __hiloint2double(name##_h, name##_l)
+// p t + c with c in scalar registers, as the three-operand v_fma_f64 (the compiler prefers the accumulator form and copies the
+// scalar pair into vector registers for it)
+__device__ __forceinline__ double fma_sc(double p, double t, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(t), "s"(c));
+  return r;
+}
 __device__ __forceinline__ double exp_neg(double x) {
   x = x < -745.0 ? -745.0 : x;
   const double n = rint(x * 1.4426950408889634);
   double t = fma(n, -0.6931471803691238, x);
   t = fma(n, -1.9082149292705877e-10, t);
-  double p = 1.6059043836821613e-10;
-  p = fma(p, t, 2.08767569878681e-09);
-  p = fma(p, t, 2.505210838544172e-08);
-  p = fma(p, t, 2.755731922398589e-07);
-  p = fma(p, t, 2.7557319223985893e-06);
-  p = fma(p, t, 2.48015873015873e-05);
-  p = fma(p, t, 0.0001984126984126984);
-  p = fma(p, t, 0.001388888888888889);
-  p = fma(p, t, 0.008333333333333333);
-  p = fma(p, t, 0.041666666666666664);
-  p = fma(p, t, 0.16666666666666666);
+  const double c0v = 1.6059043836821613e-10;
+  BAYENS_SCONST(c1, 0x3e21eed8, 0xeff8d898);   // 2.08767569878681e-09
+  BAYENS_SCONST(c2, 0x3e5ae645, 0x67f544e4);   // 2.505210838544172e-08
+  BAYENS_SCONST(c3, 0x3e927e4f, 0xb7789f5c);   // 2.755731922398589e-07
+  BAYENS_SCONST(c4, 0x3ec71de3, 0xa556c734);   // 2.7557319223985893e-06
+  BAYENS_SCONST(c5, 0x3efa01a0, 0x1a01a01a);   // 2.48015873015873e-05
+  BAYENS_SCONST(c6, 0x3f2a01a0, 0x1a01a01a);   // 0.0001984126984126984
+  BAYENS_SCONST(c7, 0x3f56c16c, 0x16c16c17);   // 0.001388888888888889
+  BAYENS_SCONST(c8, 0x3f811111, 0x11111111);   // 0.008333333333333333
+  BAYENS_SCONST(c9, 0x3fa55555, 0x55555555);   // 0.041666666666666664
+  BAYENS_SCONST(c10, 0x3fc55555, 0x55555555);   // 0.16666666666666666
+  double p = fma_sc(c0v, t, c1);
+  p = fma_sc(p, t, c2);
+  p = fma_sc(p, t, c3);
+  p = fma_sc(p, t, c4);
+  p = fma_sc(p, t, c5);
+  p = fma_sc(p, t, c6);
+  p = fma_sc(p, t, c7);
+  p = fma_sc(p, t, c8);
+  p = fma_sc(p, t, c9);
+  p = fma_sc(p, t, c10);
   p = fma(p, t, 0.5);
   p = fma(p, t, 1.0);
   p = fma(p, t, 1.0);
@@ -67,7 +96,12 @@ __device__ __forceinline__ double sqrt_pos(double d) {
 }
 // K(r2) and dK/dlengthscale for the three stationary kernels (GPflow 2.1.5 forms; Matern-3/2 is the only
 // one the reference instantiates, models.py:186).
-__device__ __forceinline__ void kern_eval(int kernel, double var, double ls, double r2, double& K, double& dK) {
+// (KERNEL is a template parameter of the passes that evaluate it: with a run-time switch inside the element loop every element
+//  was a chain of its own behind a branch - sqrt, exp, product, store, one after the other - and the independent elements of a
+//  thread never overlapped)
+template <int KERNEL>
+__device__ __forceinline__ void kern_eval(double var, double ls, double r2, double& K, double& dK) {
+  constexpr int kernel = KERNEL;
   if (kernel == 2) {
     double r2c = r2 > 0.0 ? r2 : 0.0;
     K = var * exp_neg(-0.5 * r2c);
@@ -446,9 +480,9 @@ __global__ void xprep_kernel(int N, int Np, int R_all, int R4, const real* X_all
 
 // one workgroup = one 64x64 output tile; wave w owns rows 16w..16w+15, four 16x16 MFMA tiles across.
 // GRAD=false: write K0 and Lb.  GRAD=true: accumulate <Kbt, K0> and <Kbt, dK/dl> over the real part.
-template <bool GRAD>
+template <bool GRAD, int KERNEL>
 __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
-                                                   const double* ustate, int kernel, double jitter, Mat Lb,
+                                                   const double* ustate, double jitter, Mat Lb,
                                                    Mat Kbt, double* gpart, const real* pvec, double sym_gamma,
                                                    int clear_upper, Mat Mb, double m_scale, const real* m_diag) {
   const int b = blockIdx.z;
@@ -472,14 +506,17 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   // diagonal contribute through their mirror images (pairs counted once, twice the weight)
   const bool sym = GRAD && pvec != nullptr;
   const int njt = (sym && blockIdx.x > blockIdx.y) ? 0 : 4;
-  // the weights of this thread's 16 elements are requested up front (inside the guarded accumulation below every load
-  // would be issued, and waited for, on its own); the padded rows / columns are valid memory and are masked by a select
-  double kbv[4][4], pi[4] = {0, 0, 0, 0}, pj[4] = {0, 0, 0, 0};
+  // the weights of a 16-column strip (four per thread) are requested together, one strip ahead of the one being evaluated; the
+  // padded rows / columns are valid memory and are masked by a select
+  double pi[4] = {0, 0, 0, 0}, pj[4] = {0, 0, 0, 0};
+  const real* krow = GRAD ? Kbt.p + b * Kbt.stride + (long)(i0 + lk) * Kbt.ld + j0 + lr : nullptr;
+  auto load_kb = [&](int jt, double (&dst)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = krow[(long)(4 * r) * Kbt.ld + jt * 16];
+  };
+  double kbn[4] = {0, 0, 0, 0};
   if (GRAD && njt) {
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) kbv[jt][r] = Kbt.p[b * Kbt.stride + (long)(i0 + lk + 4 * r) * Kbt.ld + j0 + jt * 16 + lr];
+    load_kb(0, kbn);
     if (sym) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -488,40 +525,69 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
       }
     }
   }
+  // Tiles that meet neither the diagonal nor the padding (all but ~1/16 of them at N = 2000) need no masking: no select for the
+  // padded rows / columns, the triangle or the jitter, and no per-element address arithmetic (row pointers + immediate offsets).
+  const bool edge_tile = blockIdx.x == blockIdx.y || (int)blockIdx.y * 64 + 64 > N || (int)blockIdx.x * 64 + 64 > N;
+  real* lrow[4];
+  real* mrow[4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    if (jt >= njt) break;
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < R4; kk += 4) {
-      const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
-      const double bb = xb[(long)(j0 + jt * 16 + lr) * R4 + kk + lk];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-    }
-    const int j = j0 + jt * 16 + lr;
-    const double sj = sb[j];
+  for (int r = 0; r < 4; ++r) {
+    lrow[r] = GRAD ? nullptr : Lb.p + b * Lb.stride + (long)(i0 + lk + 4 * r) * Lb.ld + j0 + lr;
+    mrow[r] = (GRAD || !Mb.p) ? nullptr : Mb.p + b * Mb.stride + (long)(i0 + lk + 4 * r) * Mb.ld + j0 + lr;
+  }
+  auto tile_body = [&](auto EDGE_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + lk + 4 * r;
-      const double r2 = (-2.0 * acc[r] + sb[i]) + sj;
-      double K, dK;
-      kern_eval(kernel, var, ls, r2, K, dK);
+    for (int jt = 0; jt < 4; ++jt) {
+      if (jt >= njt) break;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < R4; kk += 4) {
+        const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
+        const double bb = xb[(long)(j0 + jt * 16 + lr) * R4 + kk + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+      }
+      const int j = j0 + jt * 16 + lr;
+      const double sj = sb[j];
+      double kbc[4];
       if (GRAD) {
-        double kb = kbv[jt][r];
-        if (sym) {
-          kb = fma(-sym_gamma * pi[r], pj[jt], kb);
-          kb = i == j ? 0.5 * kb : kb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kbc[r] = kbn[r];
+        if (jt + 1 < 4) load_kb(jt + 1, kbn);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + lk + 4 * r;
+        const double r2 = (-2.0 * acc[r] + sb[i]) + sj;
+        double K, dK;
+        kern_eval<KERNEL>(var, ls, r2, K, dK);
+        if (GRAD) {
+          double kb = kbc[r];
+          if (sym) {
+            kb = fma(-sym_gamma * pi[r], pj[jt], kb);
+            if (EDGE) kb = i == j ? 0.5 * kb : kb;
+          }
+          if (EDGE) {
+            const bool use = i < N && j < N && !(sym && j > i);
+            gv = fma(use ? kb : 0.0, use ? K : 0.0, gv);
+            gl = fma(use ? kb : 0.0, use ? dK : 0.0, gl);
+          } else {
+            gv = fma(kb, K, gv);
+            gl = fma(kb, dK, gl);
+          }
+        } else if (EDGE) {
+          if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
+          const double kj = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
+          lrow[r][jt * 16] = kj;
+          if (Mb.p) mrow[r][jt * 16] = m_scale * kj + (i == j ? (double)m_diag[(long)b * Np + i] : 0.0);
+        } else {
+          lrow[r][jt * 16] = K;
+          if (Mb.p) mrow[r][jt * 16] = m_scale * K;
         }
-        const bool use = i < N && j < N && !(sym && j > i);
-        gv = fma(use ? kb : 0.0, use ? K : 0.0, gv);
-        gl = fma(use ? kb : 0.0, use ? dK : 0.0, gl);
-      } else {
-        if (i >= N || j >= N) K = i == j ? 1.0 : 0.0;
-        const double kj = j <= i ? K + (i == j ? jitter : 0.0) : 0.0;
-        Lb.p[b * Lb.stride + (long)i * Lb.ld + j] = kj;
-        if (Mb.p) Mb.p[b * Mb.stride + (long)i * Mb.ld + j] = m_scale * kj + (i == j ? (double)m_diag[(long)b * Np + i] : 0.0);
       }
     }
-  }
+  };
+  if (edge_tile) tile_body(std::true_type());
+  else tile_body(std::false_type());
   if (GRAD) {
     __shared__ double red[2][4];
     gv = wave_sum(gv);
@@ -1734,9 +1800,14 @@ void HipPrims::kmat(int nb, int N, int Np, int R, const real* X, const double* u
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   hipLaunchKernelGGL(xprep_kernel, dim3((Np + 255) / 256, nb), dim3(256), 0, stream, N, Np, R, R4, X, ustate, xs, ssq, Rv, xoff);
-  hipLaunchKernelGGL((kmat_kernel<false>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
-                     kernel, jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0, clear_upper ? 1 : 0, Mb,
-                     m_scale, m_diag);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
+                       jitter, Lb, Mat{nullptr, 0, 0}, (double*)nullptr, (const real*)nullptr, 0.0, clear_upper ? 1 : 0, Mb,
+                       m_scale, m_diag);
+  };
+  if (kernel == 0) launch(kmat_kernel<false, 0>);
+  else if (kernel == 1) launch(kmat_kernel<false, 1>);
+  else launch(kmat_kernel<false, 2>);
   LAUNCH_CHECK();
 }
 void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst) {
@@ -1797,8 +1868,13 @@ void HipPrims::grad_adam(int nb, int N, int Np, int R, const real* X, int kernel
   const int R4 = ((R + 3) / 4) * 4;
   ensure_scratch(nb, Np, R4);
   // xs / ssq still hold X / lengthscale of the hypers this iteration's kmat used (ustate not yet updated)
-  hipLaunchKernelGGL((kmat_kernel<true>), tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate, kernel,
-                     0.0, Mat{nullptr, 0, 0}, Kbt, gpart, pvec, sym_gamma, 1, Mat{nullptr, 0, 0}, 0.0, (const real*)nullptr);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, tile_grid(Np, nb), dim3(256), 0, stream, N, Np, R4, xs, ssq, ustate,
+                       0.0, Mat{nullptr, 0, 0}, Kbt, gpart, pvec, sym_gamma, 1, Mat{nullptr, 0, 0}, 0.0, (const real*)nullptr);
+  };
+  if (kernel == 0) launch(kmat_kernel<true, 0>);
+  else if (kernel == 1) launch(kmat_kernel<true, 1>);
+  else launch(kmat_kernel<true, 2>);
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, stream, (Np / 64) * (Np / 64), gpart, ustate, lr);
   LAUNCH_CHECK();
 }
