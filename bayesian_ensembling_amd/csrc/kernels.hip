@@ -505,18 +505,31 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
   // GRAD with pvec: the weights are the symmetric (P - sym_gamma p p^T) / 2, P's lower triangle in Kbt: tiles above the
   // diagonal contribute through their mirror images (pairs counted once, twice the weight)
   const bool sym = GRAD && pvec != nullptr;
-  const int njt = (sym && blockIdx.x > blockIdx.y) ? 0 : 4;
-  // the weights of a 16-column strip (four per thread) are requested together, one strip ahead of the one being evaluated; the
-  // padded rows / columns are valid memory and are masked by a select
-  double pi[4] = {0, 0, 0, 0}, pj[4] = {0, 0, 0, 0};
-  const real* krow = GRAD ? Kbt.p + b * Kbt.stride + (long)(i0 + lk) * Kbt.ld + j0 + lr : nullptr;
-  auto load_kb = [&](int jt, double (&dst)[4]) {
+  // GRAD without pvec (a general iteration: Kbt = Kbar^T, not symmetric): K and dK/dl ARE symmetric, so sum_ij Kbt_ij K_ij runs
+  // over the lower tiles only with the weights Kbt_ij + Kbt_ji - the mirror tile (bj, bi) comes in through LDS, read transposed -
+  // and the kernel is evaluated for half of the elements (diagonal tiles: every element, plain weights).
+  const bool mirror = GRAD && !sym && blockIdx.x < blockIdx.y;
+  const int njt = (GRAD && blockIdx.x > blockIdx.y) ? 0 : 4;
+  __shared__ real tmir[GRAD ? 64 : 1][GRAD ? 65 : 1];
+  if (mirror) {
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const real* src = Kbt.p + b * Kbt.stride + (long)j0 * Kbt.ld + blockIdx.y * 64 + c;
+    real v[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[r] = krow[(long)(4 * r) * Kbt.ld + jt * 16];
-  };
-  double kbn[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 16; ++q) v[q] = src[(long)(r0 + 4 * q) * Kbt.ld];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tmir[r0 + 4 * q][c] = v[q];
+    __syncthreads();
+  }
+  // the weights of this thread's 16 elements are requested up front (one memory round trip; inside the guarded accumulation below
+  // every load would be issued, and waited for, on its own); the padded rows / columns are valid memory and are masked by a select
+  double kbv[4][4], pi[4] = {0, 0, 0, 0}, pj[4] = {0, 0, 0, 0};
   if (GRAD && njt) {
-    load_kb(0, kbn);
+    const real* krow = Kbt.p + b * Kbt.stride + (long)(i0 + lk) * Kbt.ld + j0 + lr;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbv[jt][r] = krow[(long)(4 * r) * Kbt.ld + jt * 16];
     if (sym) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -535,39 +548,56 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
     lrow[r] = GRAD ? nullptr : Lb.p + b * Lb.stride + (long)(i0 + lk + 4 * r) * Lb.ld + j0 + lr;
     mrow[r] = (GRAD || !Mb.p) ? nullptr : Mb.p + b * Mb.stride + (long)(i0 + lk + 4 * r) * Mb.ld + j0 + lr;
   }
-  auto tile_body = [&](auto EDGE_T) {
-    constexpr bool EDGE = decltype(EDGE_T)::value;
+  // The scaled inputs' products X~ X~^T of all four strips first, k-outer: the five operand loads of a k step (and, unrolled, of
+  // two) are in flight together.  (Strip by strip - two dependent loads, a wait and an MFMA per k step - a workgroup spent 8 serial
+  // memory round trips here before it evaluated anything: 13-20 us of its life, the whole pass latency-bound.)
+  v4d accs[4];
+  double si[4], sjv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    accs[q] = v4d{0.0, 0.0, 0.0, 0.0};
+    si[q] = sb[i0 + lk + 4 * q];
+    sjv[q] = sb[j0 + q * 16 + lr];
+  }
+  if (njt) {
+    const double* pa = xb + (long)(i0 + lr) * R4 + lk;
+    const double* pb = xb + (long)(j0 + lr) * R4 + lk;
+    const long strip = 16L * R4;
+#pragma unroll 2
+    for (int kk = 0; kk < R4; kk += 4) {
+      const double a = pa[kk];
+      double bb[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) bb[jt] = pb[jt * strip + kk];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) accs[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb[jt], accs[jt], 0, 0, 0);
+    }
+  }
+  // (EDGE, and for the gradient pass SYM / MIRROR, are compile-time flags of the body: a uniform run-time test per element is a
+  //  branch per element, and the elements of a thread then run one behind the other)
+  auto tile_body = [&](auto EDGE_T, auto SYM_T, auto MIRROR_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value, SYM = decltype(SYM_T)::value, MIRROR = decltype(MIRROR_T)::value;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       if (jt >= njt) break;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int kk = 0; kk < R4; kk += 4) {
-        const double a = xb[(long)(i0 + lr) * R4 + kk + lk];
-        const double bb = xb[(long)(j0 + jt * 16 + lr) * R4 + kk + lk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-      }
+      const v4d acc = accs[jt];
       const int j = j0 + jt * 16 + lr;
-      const double sj = sb[j];
-      double kbc[4];
-      if (GRAD) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kbc[r] = kbn[r];
-        if (jt + 1 < 4) load_kb(jt + 1, kbn);
-      }
+      const double sj = sjv[jt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + lk + 4 * r;
-        const double r2 = (-2.0 * acc[r] + sb[i]) + sj;
+        const double r2 = (-2.0 * acc[r] + si[r]) + sj;
         double K, dK;
         kern_eval<KERNEL>(var, ls, r2, K, dK);
         if (GRAD) {
-          double kb = kbc[r];
-          if (sym) {
+          double kb = kbv[jt][r];
+          if (MIRROR) kb += (double)tmir[jt * 16 + lr][wave * 16 + lk + 4 * r];
+          if (SYM) {
             kb = fma(-sym_gamma * pi[r], pj[jt], kb);
             if (EDGE) kb = i == j ? 0.5 * kb : kb;
           }
           if (EDGE) {
-            const bool use = i < N && j < N && !(sym && j > i);
+            const bool use = i < N && j < N && !(SYM && j > i);
             gv = fma(use ? kb : 0.0, use ? K : 0.0, gv);
             gl = fma(use ? kb : 0.0, use ? dK : 0.0, gl);
           } else {
@@ -586,8 +616,20 @@ __global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const 
       }
     }
   };
-  if (edge_tile) tile_body(std::true_type());
-  else tile_body(std::false_type());
+  using T = std::true_type;
+  using F = std::false_type;
+  if (!GRAD) {
+    if (edge_tile) tile_body(T(), F(), F());
+    else tile_body(F(), F(), F());
+  } else if (sym) {
+    if (edge_tile) tile_body(T(), T(), F());
+    else tile_body(F(), T(), F());
+  } else if (mirror) {
+    if (edge_tile) tile_body(T(), F(), T());
+    else tile_body(F(), F(), T());
+  } else {
+    tile_body(T(), F(), F());         // (diagonal tiles of a general iteration; the tiles above the diagonal have njt = 0)
+  }
   if (GRAD) {
     __shared__ double red[2][4];
     gv = wave_sum(gv);
