@@ -980,21 +980,32 @@ __global__ __launch_bounds__(64 * LTD_WAVES) void lt_dvec_kernel(int n, Mat L, c
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const real* l = L.p + b * L.stride;
-  // rows j0 .. n-1 of the 64-column strip, 4 waves x 4 rows in flight (the strip of column block 0 is n rows long:
-  // one row per wave and trip leaves the load latency exposed)
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // rows j0 .. n-1 of the 64-column strip, 16 waves x 8 rows in flight (the strip of column block 0 is n rows long: the pass is
+  // bound by how many loads a workgroup keeps in flight, so the row weights v / nu - one division per row, the same in every lane -
+  // are formed once, in LDS, and the loop is loads and multiply-adds only)
+  extern __shared__ double dvec[];        // [n - j0]
   const long vb = (long)b * n;
+  for (int i = j0 + (int)threadIdx.x; i < n; i += 64 * LTD_WAVES)
+    dvec[i - j0] = (double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0);
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   constexpr int W = LTD_WAVES;
+  const real* lc = l + j0 + c;
   int i = j0 + w;
-  for (; i + 3 * W < n; i += 4 * W) {
-    const double a0 = l[(long)i * L.ld + j0 + c], a1 = l[(long)(i + W) * L.ld + j0 + c];
-    const double a2 = l[(long)(i + 2 * W) * L.ld + j0 + c], a3 = l[(long)(i + 3 * W) * L.ld + j0 + c];
-    s0 += a0 * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
-    s1 += a1 * ((double)y[vb + i + W] / (nu ? (double)nu[vb + i + W] : 1.0));
-    s2 += a2 * ((double)y[vb + i + 2 * W] / (nu ? (double)nu[vb + i + 2 * W] : 1.0));
-    s3 += a3 * ((double)y[vb + i + 3 * W] / (nu ? (double)nu[vb + i + 3 * W] : 1.0));
+  for (; i + 7 * W < n; i += 8 * W) {
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = lc[(long)(i + q * W) * L.ld];
+    s0 += a[0] * dvec[i - j0];
+    s1 += a[1] * dvec[i + W - j0];
+    s2 += a[2] * dvec[i + 2 * W - j0];
+    s3 += a[3] * dvec[i + 3 * W - j0];
+    s0 += a[4] * dvec[i + 4 * W - j0];
+    s1 += a[5] * dvec[i + 5 * W - j0];
+    s2 += a[6] * dvec[i + 6 * W - j0];
+    s3 += a[7] * dvec[i + 7 * W - j0];
   }
-  for (; i < n; i += W) s0 += l[(long)i * L.ld + j0 + c] * ((double)y[vb + i] / (nu ? (double)nu[vb + i] : 1.0));
+  for (; i < n; i += W) s0 += lc[(long)i * L.ld] * dvec[i - j0];
   const double s = (s0 + s1) + (s2 + s3);
   part[w][c] = s;
   __syncthreads();
@@ -1010,36 +1021,57 @@ __global__ __launch_bounds__(64 * LTD_WAVES) void lt_dvec_kernel(int n, Mat L, c
 // out = S v, S symmetric, elements on and below the diagonal read only: one workgroup per 64 columns j0..j0+63 sums the
 // column part sum_{i >= j} S_ij v_i (lanes = columns, the 4 waves split the rows, as in lt_dvec_kernel) and the row part
 // sum_{k < j} S_jk v_k (16 rows per wave, lanes stride k): 64 n elements per workgroup wherever the strip lies.
-__global__ __launch_bounds__(256) void symv_lower_kernel(int n, Mat S, const real* v, real* out) {
-  __shared__ double part[4][64];
+constexpr int SYMV_WAVES = 16;
+__global__ __launch_bounds__(64 * SYMV_WAVES) void symv_lower_kernel(int n, Mat S, const real* v, real* out) {
+  constexpr int W = SYMV_WAVES;
+  __shared__ double part[W][64];
   __shared__ double rowp[64];
   const int b = blockIdx.y, j0 = blockIdx.x * 64;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const real* s = S.p + b * S.stride;
   const long vb = (long)b * n;
+  // column part: rows i >= j0 of the strip, 16 waves x 8 rows in flight (as lt_dvec_kernel: the loads in flight bound the rate)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const real* sc = s + j0 + c;
   int i = j0 + w;
-  for (; i + 12 < n; i += 16) {
-    const double a0 = s[(long)i * S.ld + j0 + c], a1 = s[(long)(i + 4) * S.ld + j0 + c];
-    const double a2 = s[(long)(i + 8) * S.ld + j0 + c], a3 = s[(long)(i + 12) * S.ld + j0 + c];
-    s0 += (i >= j0 + c ? a0 : 0.0) * (double)v[vb + i];
-    s1 += (i + 4 >= j0 + c ? a1 : 0.0) * (double)v[vb + i + 4];
-    s2 += (i + 8 >= j0 + c ? a2 : 0.0) * (double)v[vb + i + 8];
-    s3 += (i + 12 >= j0 + c ? a3 : 0.0) * (double)v[vb + i + 12];
+  for (; i + 7 * W < n; i += 8 * W) {
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = sc[(long)(i + q * W) * S.ld];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double t = (i + q * W >= j0 + c ? a[q] : 0.0) * (double)v[vb + i + q * W];
+      if ((q & 3) == 0) s0 += t;
+      else if ((q & 3) == 1) s1 += t;
+      else if ((q & 3) == 2) s2 += t;
+      else s3 += t;
+    }
   }
-  for (; i < n; i += 4) s0 += (i >= j0 + c ? (double)s[(long)i * S.ld + j0 + c] : 0.0) * (double)v[vb + i];
+  for (; i < n; i += W) s0 += (i >= j0 + c ? (double)sc[(long)i * S.ld] : 0.0) * (double)v[vb + i];
   part[w][c] = (s0 + s1) + (s2 + s3);
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int j = j0 + 16 * w + q;
-    const real* row = s + (long)j * S.ld;
-    double t = 0.0;
-    for (int k = c; k < j; k += 64) t += (double)row[k] * (double)v[vb + k];
-    t = wave_sum(t);
-    if (c == 0) rowp[16 * w + q] = t;
+  // row part: rows j0 + 4 w .. + 3 of the strip, the four rows of a wave side by side (lanes stride k)
+  {
+    const int jb = j0 + 4 * w;
+    const real* row = s + (long)jb * S.ld;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    for (int k = c; k < jb + 3; k += 64) {
+      const double vk = (double)v[vb + k];
+      const double r0 = row[k], r1 = row[S.ld + k], r2 = row[2L * S.ld + k], r3 = row[3L * S.ld + k];
+      t0 += (k < jb ? r0 : 0.0) * vk;
+      t1 += (k < jb + 1 ? r1 : 0.0) * vk;
+      t2 += (k < jb + 2 ? r2 : 0.0) * vk;
+      t3 += r3 * vk;
+    }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3);
+    if (c == 0) { rowp[4 * w] = t0; rowp[4 * w + 1] = t1; rowp[4 * w + 2] = t2; rowp[4 * w + 3] = t3; }
   }
   __syncthreads();
-  if (w == 0) out[vb + j0 + c] = (real)(((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + rowp[c]);
+  if (w == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) tot += part[q][c];
+    out[vb + j0 + c] = (real)(tot + rowp[c]);
+  }
 }
 
 // out_i = sum_{k < klim(i)} A_ik x_k - (sub ? sub_i : 0); one wave per row, lanes stride k.
@@ -1857,11 +1889,11 @@ void HipPrims::scale_rows_rsqrt(int nb, int n, Mat src, const real* nu, Mat dst)
   LAUNCH_CHECK();
 }
 void HipPrims::lt_dvec(int nb, int n, Mat L, const real* v, const real* nu, double alpha, double beta, real* out) {
-  hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(64 * LTD_WAVES), 0, stream, n, L, v, nu, alpha, beta, out);
+  hipLaunchKernelGGL(lt_dvec_kernel, dim3(n / 64, nb), dim3(64 * LTD_WAVES), (size_t)n * sizeof(double), stream, n, L, v, nu, alpha, beta, out);
   LAUNCH_CHECK();
 }
 void HipPrims::symv_lower(int nb, int n, Mat S, const real* v, real* out) {
-  hipLaunchKernelGGL(symv_lower_kernel, dim3(n / 64, nb), dim3(256), 0, stream, n, S, v, out);
+  hipLaunchKernelGGL(symv_lower_kernel, dim3(n / 64, nb), dim3(64 * SYMV_WAVES), 0, stream, n, S, v, out);
   LAUNCH_CHECK();
 }
 void HipPrims::lam_update(int nb, int n, Mat G, double gamma, Mat Lam, Mat Cb, Mat Gfull, int parts) {
