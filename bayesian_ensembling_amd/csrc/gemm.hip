@@ -503,6 +503,110 @@ __global__ __launch_bounds__(256) void gemm_panel64(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small outputs: 64 x 64 tiles.  The last block columns of a factorisation and the inner levels of the blocked solves
+// multiply into outputs of a few 128 x 128 tiles per member - 96 to 500 workgroups on 256 CUs, each a serial chain of K steps
+// (profiles/r05_gemm_shapes.txt: 11-35 TFLOP/s below m = 768).  For those the same product runs on four times as many
+// workgroups of a quarter of the work: a workgroup owns a 64 x 64 tile, wave w its rows 16 w .. 16 w + 15 (four MFMA tiles
+// across), K in chunks of 32 staged through registers into padded LDS images (the next chunk's global loads fly under the
+// current chunk's 32 MFMAs per wave).  Same flags, same arithmetic order along k as gemm_f64_mfma.
+// ------------------------------------------------------------------------------------------------
+constexpr int TK = 32, TLA = TK + 2, TLB = 64 + 2;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_tile64(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) real As[64][TLA];   // [row][k]
+  __shared__ __attribute__((aligned(16))) real Bs[TK][TLB];   // [k][col]
+  const int tiles_m = g.m / 64, tiles_n = g.n / 64;
+  const int tiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  const int total = tiles * g.nb;
+  if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);      // an XCD walks a contiguous range of (member, tile)
+  const int batch = bid / tiles;
+  const int t = bid - batch * tiles;
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const int row0 = tm * 64, col0 = tn * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  real* C = g.C + batch * g.sC + (long)row0 * g.ldc + col0;
+  if ((g.flags & GEMM_TRI_OUT) && col0 > row0) {
+    if (g.flags & GEMM_ZERO_SKIPPED)
+      for (int e = tid; e < 64 * 64; e += 256) C[(long)(e >> 6) * g.ldc + (e & 63)] = 0.0;
+    return;
+  }
+  const real* A = g.A + batch * g.sA;
+  const real* B = g.B + batch * g.sB;
+  int kbeg = 0, kend = g.k;
+  if (g.flags & GEMM_KTRIM_TN_LOWER) kbeg = row0 > col0 ? row0 : col0;
+  if ((g.flags & GEMM_KTRIM_A_LOWER) && row0 + 64 < kend) kend = row0 + 64;
+  const int nchunk = kend > kbeg ? (kend - kbeg) / TK : 0;
+
+  // the next chunk's operands are requested before the current chunk's MFMAs, and the tile of C before the first chunk (a second
+  // chunk in flight was measured: no faster - these launches are bound by their fixed costs, not by the K loop)
+  v2d ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!TA) ra[p] = *reinterpret_cast<const v2d*>(A + (long)(row0 + (tid >> 4) + 16 * p) * g.lda + k0 + 2 * (tid & 15));
+      else ra[p] = *reinterpret_cast<const v2d*>(A + (long)(k0 + (tid >> 5) + 8 * p) * g.lda + row0 + 2 * (tid & 31));
+      if (!TB) rb[p] = *reinterpret_cast<const v2d*>(B + (long)(k0 + (tid >> 5) + 8 * p) * g.ldb + col0 + 2 * (tid & 31));
+      else rb[p] = *reinterpret_cast<const v2d*>(B + (long)(col0 + (tid >> 4) + 16 * p) * g.ldb + k0 + 2 * (tid & 15));
+    }
+  };
+  auto place = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!TA) {
+        *reinterpret_cast<v2d*>(&As[(tid >> 4) + 16 * p][2 * (tid & 15)]) = ra[p];
+      } else {
+        As[2 * (tid & 31)][(tid >> 5) + 8 * p] = ra[p].x;
+        As[2 * (tid & 31) + 1][(tid >> 5) + 8 * p] = ra[p].y;
+      }
+      if (!TB) {
+        *reinterpret_cast<v2d*>(&Bs[(tid >> 5) + 8 * p][2 * (tid & 31)]) = rb[p];
+      } else {
+        Bs[2 * (tid & 15)][(tid >> 4) + 16 * p] = rb[p].x;
+        Bs[2 * (tid & 15) + 1][(tid >> 4) + 16 * p] = rb[p].y;
+      }
+    }
+  };
+  v4d acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = v4d{0, 0, 0, 0};
+  if (nchunk > 0) fetch(kbeg);
+  const bool accumulate = g.beta != 0.0;
+  real cv[4][4];
+  if (accumulate) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[j][r] = C[(long)(wave * 16 + acc_row(lk, r)) * g.ldc + j * 16 + lr];
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    BAYENS_LDS_BARRIER();                    // the previous chunk's operand reads are done
+    place();
+    BAYENS_LDS_BARRIER();
+    if (c + 1 < nchunk) fetch(kbeg + (c + 1) * TK);
+#pragma unroll
+    for (int kk = 0; kk < TK / 4; ++kk) {
+      const real a = As[wave * 16 + lr][kk * 4 + lk];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + acc_row(lk, r), col = j * 16 + lr;
+      double v = g.alpha * acc[j][r];
+      if (accumulate) v += g.beta * cv[j][r];
+      if (row0 + row == col0 + col) v += g.diag_add;
+      C[(long)row * g.ldc + col] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused triangular solve of a narrow diagonal block (n = 64 * nsub <= 256): B <- B L^-T (RLN=false) or
 // B <- B L^-1 (RLN=true).  Rows of a right-side solve are independent, so a workgroup owns 64 rows and walks
 // the column blocks itself:   X_j = (B_j - sum_k X_k op(L_jk)) op(M_j)   with M_j the inverted diagonal block.
@@ -673,6 +777,17 @@ double algorithmic_bytes(int nb, int m, int n, int k, int flags, double beta) {
 
 }  // namespace
 
+// does the 128 x 128 tiling leave most of the chip idle?  Measured per shape (profiles/r05_gemm_tile64.txt): with B stored n x k
+// (its chunk goes into LDS transposed, element by element) the small tiles win up to ~100 workgroups of the large tiling, otherwise
+// up to one resident round (512).  BAYENS_TILE64_MAX=n overrides both limits (0: never).
+static bool small_output(const GemmArgs& g, int flags) {
+  static const int forced = [] { const char* e = std::getenv("BAYENS_TILE64_MAX"); return e ? std::atoi(e) : -1; }();
+  const int limit = forced >= 0 ? forced : ((flags & GEMM_TB) ? 160 : 512);
+  long active = 0;
+  for (int tm = 0; tm < g.tiles_m; ++tm) active += (flags & GEMM_TRI_OUT) ? (tm + 1 < g.tiles_n ? tm + 1 : g.tiles_n) : g.tiles_n;
+  return active * g.nb <= limit;
+}
+
 void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, double beta, Mat C, int flags,
                     double diag_add) {
   if (nb <= 0 || m <= 0 || n <= 0) return;
@@ -710,6 +825,13 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
     dim3 pgrid((m / 64) * nb);
     if (tb) hipLaunchKernelGGL((gemm_panel64<true>), pgrid, block, 0, stream, g);
     else hipLaunchKernelGGL((gemm_panel64<false>), pgrid, block, 0, stream, g);
+  } else if (small_output(g, flags)) {
+    fam = FAM_TILE64;                        // (its own family: family 1-3 stay exactly the launches of gemm_f64_mfma<TA, TB>)
+    dim3 tgrid((m / 64) * (n / 64) * nb);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_tile64<false, true>), tgrid, block, 0, stream, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_tile64<true, false>), tgrid, block, 0, stream, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_tile64<false, false>), tgrid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_tile64<true, true>), tgrid, block, 0, stream, g);
   } else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_mfma<false, true>), grid, block, 0, stream, g);
   else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_mfma<true, false>), grid, block, 0, stream, g);
   else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_mfma<false, false>), grid, block, 0, stream, g);

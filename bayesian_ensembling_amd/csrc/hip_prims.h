@@ -29,16 +29,16 @@ struct HipError {
   } while (0)
 
 // kernel families of the per-launch accounting (bayens_profile_get): one per kernel symbol of the GEMM group
-enum { FAM_ALL = 0, FAM_GEMM_NT = 1, FAM_GEMM_NN = 2, FAM_GEMM_TN = 3, FAM_PANEL64 = 4, FAM_TRSM_PANEL = 5, FAM_COUNT = 6 };
+enum { FAM_ALL = 0, FAM_GEMM_NT = 1, FAM_GEMM_NN = 2, FAM_GEMM_TN = 3, FAM_PANEL64 = 4, FAM_TRSM_PANEL = 5, FAM_TILE64 = 6, FAM_COUNT = 7 };
 
 struct KernelProfile {
   bool enabled = false;
   struct Ev { hipEvent_t a, b; int fam; int m, n, k, flags; double flop; };
   std::vector<Ev> events;   // per launch
   std::vector<hipEvent_t> pool;
-  double flop[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
-  double bytes[FAM_COUNT] = {0, 0, 0, 0, 0, 0};   // algorithmic operand bytes (GEMM families; panel solves: B in+out, L)
-  long launches[FAM_COUNT] = {0, 0, 0, 0, 0, 0};
+  double flop[FAM_COUNT] = {};
+  double bytes[FAM_COUNT] = {};   // algorithmic operand bytes (GEMM families; panel solves: B in+out, L)
+  long launches[FAM_COUNT] = {};
   std::vector<std::pair<std::string, hipEvent_t>> marks;   // stage profile of the driver
 };
 

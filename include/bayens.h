@@ -59,7 +59,8 @@ int bayens_timer_start(bayens_ctx* ctx);
 int bayens_timer_stop(bayens_ctx* ctx, double* elapsed_ms);
 /* per-kernel accounting (HIP events around every launch; off by default).  family 0 = the whole GEMM group,
  * 1/2/3 = gemm_f64_mfma<false,true> (NT) / <false,false> (NN) / <true,false> (TN), 4 = gemm_panel64,
- * 5 = trsm_panel_kernel.  Returns summed device ms, algorithmic flop, launches. */
+ * 5 = trsm_panel_kernel, 6 = gemm_tile64 (the 64 x 64-tile form small outputs take, any layout).  Returns summed device ms,
+ * algorithmic flop, launches. */
 int bayens_profile_enable(bayens_ctx* ctx, int on);
 int bayens_profile_get(bayens_ctx* ctx, int family, double* ms, double* flop, long* launches);
 /* algorithmic operand bytes of the same launches (operands read once, computed part of C written, and read when
