@@ -129,6 +129,7 @@ def load():
     lib.bayens_test_trsm.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     lib.bayens_set_medium_min_batch.argtypes = [_vp, C.c_int]
     lib.bayens_set_fit_route.argtypes = [_vp, C.c_int]
+    lib.bayens_set_gemm_tile64_max.argtypes = [_vp, C.c_int]
     lib.bayens_chain_stalls.argtypes = [_vp, C.POINTER(C.c_long)]
     lib.bayens_small_wave_stamps.argtypes = [_vp, _vp]
     lib.bayens_potrf256_stamps.argtypes = [_vp, _vp]
@@ -327,6 +328,10 @@ class Context:
         n = C.c_long()
         self._check(self.lib.bayens_chain_stalls(self.h, C.byref(n)))
         return int(n.value)
+
+    def set_gemm_tile64_max(self, max_workgroups):
+        """-1: measured defaults; 0: the 128 x 128 kernel always; large: the 64 x 64-tile kernel always (fp64 context)."""
+        self._check(self.lib.bayens_set_gemm_tile64_max(self.h, int(max_workgroups)))
 
     def set_fit_route(self, route):
         """1: every fp64 fit takes the general path whatever its size; 0: the fused kernels by size (default)."""

@@ -507,6 +507,13 @@ int bayens_chain_stalls(bayens_ctx* c, long* count) {
   return 0;
 }
 
+int bayens_set_gemm_tile64_max(bayens_ctx* c, int max_workgroups) {
+  if (!c || max_workgroups < -1) return BAYENS_E_ARG;
+  c->prims->tile64_max = max_workgroups;
+  for (HipPrims* hp : c->gprims) hp->tile64_max = max_workgroups;
+  return 0;
+}
+
 int bayens_set_fit_route(bayens_ctx* c, int route) {
   if (!c || route < 0 || route > 1) return BAYENS_E_ARG;
   c->fit_route = route;

@@ -780,8 +780,9 @@ double algorithmic_bytes(int nb, int m, int n, int k, int flags, double beta) {
 // does the 128 x 128 tiling leave most of the chip idle?  Measured per shape (profiles/r05_gemm_tile64.txt): with B stored n x k
 // (its chunk goes into LDS transposed, element by element) the small tiles win up to ~100 workgroups of the large tiling, otherwise
 // up to one resident round (512).  BAYENS_TILE64_MAX=n overrides both limits (0: never).
-static bool small_output(const GemmArgs& g, int flags) {
-  static const int forced = [] { const char* e = std::getenv("BAYENS_TILE64_MAX"); return e ? std::atoi(e) : -1; }();
+static bool small_output(const GemmArgs& g, int flags, int override_max) {
+  static const int env_max = [] { const char* e = std::getenv("BAYENS_TILE64_MAX"); return e ? std::atoi(e) : -1; }();
+  const int forced = override_max >= 0 ? override_max : env_max;
   const int limit = forced >= 0 ? forced : ((flags & GEMM_TB) ? 160 : 512);
   long active = 0;
   for (int tm = 0; tm < g.tiles_m; ++tm) active += (flags & GEMM_TRI_OUT) ? (tm + 1 < g.tiles_n ? tm + 1 : g.tiles_n) : g.tiles_n;
@@ -825,7 +826,7 @@ void HipPrims::gemm(int nb, int m, int n, int k, double alpha, Mat A, Mat B, dou
     dim3 pgrid((m / 64) * nb);
     if (tb) hipLaunchKernelGGL((gemm_panel64<true>), pgrid, block, 0, stream, g);
     else hipLaunchKernelGGL((gemm_panel64<false>), pgrid, block, 0, stream, g);
-  } else if (small_output(g, flags)) {
+  } else if (small_output(g, flags, tile64_max)) {
     fam = FAM_TILE64;                        // (its own family: family 1-3 stay exactly the launches of gemm_f64_mfma<TA, TB>)
     dim3 tgrid((m / 64) * (n / 64) * nb);
     if (!ta && tb) hipLaunchKernelGGL((gemm_tile64<false, true>), tgrid, block, 0, stream, g);

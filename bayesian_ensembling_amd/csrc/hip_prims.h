@@ -56,6 +56,9 @@ struct HipPrims : Prims {
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   bool in_side = false, side_pending[2] = {false, false}, owns_side = true;
 
+  // gemm: largest launch (workgroups of the 128 x 128 tiling) that takes the 64 x 64-tile kernel; -1: the measured defaults
+  // (gemm.hip small_output), 0: never.  bayens_set_gemm_tile64_max - the primitive tests hold both kernels to the same cases.
+  int tile64_max = -1;
   explicit HipPrims(hipStream_t s) : stream(s) {}
   // per-launch accounting on/off: recorded events go back to the pool, counters are cleared
   void profile_reset(bool on) {

@@ -72,6 +72,10 @@ int bayens_set_medium_min_batch(bayens_ctx* ctx, int min_batch);
  * choice by size (fused kernels for N <= 254).  The parity tests use it to hold all routes to the same fixtures in one
  * process (the environment switches BAYENS_NO_SMALL / BAYENS_NO_MEDIUM are read once per process). */
 int bayens_set_fit_route(bayens_ctx* ctx, int route);
+/* Which fp64 product kernel a launch takes: a launch of at most max_workgroups workgroups of the 128 x 128 tiling goes to the
+ * 64 x 64-tile kernel (csrc/gemm.hip gemm_tile64).  -1 restores the measured defaults, 0 = never, a huge value = always.  The
+ * primitive tests hold both kernels to the same cases with it. */
+int bayens_set_gemm_tile64_max(bayens_ctx* ctx, int max_workgroups);
 /* Number of bayens_loglik_rows calls on this context whose one-launch chained substitution gave up (a consumer workgroup ran
  * out of polls - see the note at bayens_loglik_rows in bayens.h) and were recomputed through the blocked solve.  The results of
  * such a call are correct; its run time is that of the fallback.  bench.py reports the count beside its timing of the entry. */

@@ -9,11 +9,20 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12   # fp64 MFMA: products are exact fma chains; only the summation order differs from BLAS
 
 
+@pytest.fixture(params=["tile128", "tile64"])
+def gemm_kernel(request, ctx):
+    """Every product case runs through BOTH fp64 product kernels: the 128 x 128-tile one (gemm_f64_mfma, what the large launches
+    of a fit take) and the 64 x 64-tile one (gemm_tile64, small outputs) - by size these cases would all take the second."""
+    ctx.set_gemm_tile64_max(0 if request.param == "tile128" else 1 << 30)
+    yield request.param
+    ctx.set_gemm_tile64_max(-1)
+
+
 @pytest.mark.parametrize("nb,m,n,k", [(2, 128, 128, 64), (1, 192, 64, 128), (3, 320, 256, 192), (1, 64, 64, 64),
                                       (1, 448, 576, 64)])
 @pytest.mark.parametrize("ta", [0, 1])
 @pytest.mark.parametrize("tb", [0, 1])
-def test_gemm_all_layouts(ctx, nb, m, n, k, ta, tb):
+def test_gemm_all_layouts(ctx, gemm_kernel, nb, m, n, k, ta, tb):
     rng = np.random.default_rng(nb * 1000 + m + n + k + 2 * ta + tb)
     A = rng.standard_normal((nb, k, m) if ta else (nb, m, k))
     B = rng.standard_normal((nb, n, k) if tb else (nb, k, n))
@@ -26,7 +35,7 @@ def test_gemm_all_layouts(ctx, nb, m, n, k, ta, tb):
     assert relerr(out, ref) < TOL
 
 
-def test_gemm_is_exact_on_integer_data_with_asymmetric_operands(ctx):
+def test_gemm_is_exact_on_integer_data_with_asymmetric_operands(ctx, gemm_kernel):
     # catches a row/col swap in the fp64 MFMA fragment maps (which differ from the f32 ones)
     i = np.arange(128.0)
     A = (i[:, None] * 3 + i[None, :64])[None]          # 128 x 64, asymmetric
@@ -36,7 +45,7 @@ def test_gemm_is_exact_on_integer_data_with_asymmetric_operands(ctx):
 
 
 @pytest.mark.parametrize("nb", [2, 16, 32])
-def test_gemm_triangular_output_and_ktrim(ctx, nb):
+def test_gemm_triangular_output_and_ktrim(ctx, gemm_kernel, nb):
     # nb = 16 / 32: the member-interleaved tile dealing of triangular launches with nb % 8 == 0 and more than one
     # member per XCD (gemm.hip: mpc = nb >> 3 > 1) - the branch the 32-member bench and config 4's 16-member share run
     rng = np.random.default_rng(5 + nb)
@@ -55,7 +64,7 @@ def test_gemm_triangular_output_and_ktrim(ctx, nb):
 
 
 @pytest.mark.parametrize("m,k,n", [(320, 320, 192), (448, 256, 128), (128, 384, 64)])
-def test_gemm_lower_trapezoidal_a_stops_at_the_tiles_last_row(ctx, m, k, n):
+def test_gemm_lower_trapezoidal_a_stops_at_the_tiles_last_row(ctx, gemm_kernel, m, k, n):
     """GEMM_KTRIM_A_LOWER (the update product of the solve recursion with a lower-triangular right-hand side): A_ik = 0 for
     k > i, so the k loop of a 128-row tile ends at its last row - same result as the untrimmed product; and the elements
     beyond that row are really not read (NaNs planted there do not reach the result)."""
@@ -73,7 +82,7 @@ def test_gemm_lower_trapezoidal_a_stops_at_the_tiles_last_row(ctx, m, k, n):
     assert relerr(out, ref) < TOL
 
 
-def test_gemm_empty_k_writes_beta_c(ctx):
+def test_gemm_empty_k_writes_beta_c(ctx, gemm_kernel):
     # k-trimmed tile whose k range is empty cannot occur for square operands; beta path with alpha=0 instead
     rng = np.random.default_rng(6)
     A, B, C0 = rng.standard_normal((1, 64, 64)), rng.standard_normal((1, 64, 64)), rng.standard_normal((1, 64, 64))
