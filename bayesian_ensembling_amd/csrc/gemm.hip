@@ -515,7 +515,9 @@ constexpr int TK = 32, TLA = TK + 2, TLB = 64 + 2;
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_tile64(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) real As[64][TLA];   // [row][k]
-  __shared__ __attribute__((aligned(16))) real Bs[TK][TLB];   // [k][col]
+  // [k][col]; with B stored n x k the chunk stays as it lies, [col][k], and the operand read swaps its indices (a 2-way conflicted
+  // read instead of a transposing store, element by element, into the k-major image)
+  __shared__ __attribute__((aligned(16))) real Bs[TB ? 64 : TK][TB ? TLA : TLB];
   const int tiles_m = g.m / 64, tiles_n = g.n / 64;
   const int tiles = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -564,8 +566,7 @@ __global__ __launch_bounds__(256) void gemm_tile64(GemmArgs g) {
       if (!TB) {
         *reinterpret_cast<v2d*>(&Bs[(tid >> 5) + 8 * p][2 * (tid & 31)]) = rb[p];
       } else {
-        Bs[2 * (tid & 15)][(tid >> 4) + 16 * p] = rb[p].x;
-        Bs[2 * (tid & 15) + 1][(tid >> 4) + 16 * p] = rb[p].y;
+        *reinterpret_cast<v2d*>(&Bs[(tid >> 4) + 16 * p][2 * (tid & 15)]) = rb[p];
       }
     }
   };
@@ -590,7 +591,8 @@ __global__ __launch_bounds__(256) void gemm_tile64(GemmArgs g) {
     for (int kk = 0; kk < TK / 4; ++kk) {
       const real a = As[wave * 16 + lr][kk * 4 + lk];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = BAYENS_MFMA16(a, Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
+      for (int j = 0; j < 4; ++j)
+        acc[j] = BAYENS_MFMA16(a, TB ? Bs[j * 16 + lr][kk * 4 + lk] : Bs[kk * 4 + lk][j * 16 + lr], acc[j]);
     }
   }
 #pragma unroll
@@ -777,13 +779,13 @@ double algorithmic_bytes(int nb, int m, int n, int k, int flags, double beta) {
 
 }  // namespace
 
-// does the 128 x 128 tiling leave most of the chip idle?  Measured per shape (profiles/r05_gemm_tile64.txt): with B stored n x k
-// (its chunk goes into LDS transposed, element by element) the small tiles win up to ~100 workgroups of the large tiling, otherwise
-// up to one resident round (512).  BAYENS_TILE64_MAX=n overrides both limits (0: never).
+// does the 128 x 128 tiling leave most of the chip idle?  Measured per shape (profiles/r05_gemm_tile64.txt): the small tiles win
+// up to ~400 workgroups of the large tiling (at 480 - 1024 x 256 x 256, 32 members - they lose again).  BAYENS_TILE64_MAX=n /
+// bayens_set_gemm_tile64_max override the limit (0: never).
 static bool small_output(const GemmArgs& g, int flags, int override_max) {
   static const int env_max = [] { const char* e = std::getenv("BAYENS_TILE64_MAX"); return e ? std::atoi(e) : -1; }();
   const int forced = override_max >= 0 ? override_max : env_max;
-  const int limit = forced >= 0 ? forced : ((flags & GEMM_TB) ? 160 : 512);
+  const int limit = forced >= 0 ? forced : 400;
   long active = 0;
   for (int tm = 0; tm < g.tiles_m; ++tm) active += (flags & GEMM_TRI_OUT) ? (tm + 1 < g.tiles_n ? tm + 1 : g.tiles_n) : g.tiles_n;
   return active * g.nb <= limit;
