@@ -204,7 +204,9 @@ static void factor_with_basis(Prims& P, FitWorkspace& ws, int N, Mat src, const 
   if (!in_place) P.tri_copy(nb, Np, src, ws.T1);
   Mat rows = F.sub(in_pad ? N : Np, 0);
   if (basis) P.basis_rows_set(nb, N, Np, rows, mu_pad, in_pad ? 1 : 0);
-  potrf(P, nb, Np, F, ws.invL, ws.inv_stride(), ws.info, extra, chol, N);
+  static const bool no_col_export = std::getenv("BAYENS_NO_COL_EXPORT") != nullptr;      // (measurement switch)
+  potrf(P, nb, Np, F, ws.invL, ws.inv_stride(), ws.info, extra, no_col_export ? nullptr : chol, N);
+  if (no_col_export && chol) P.extract(nb, N, F, chol, 2);
   if (logdet) P.logdet(nb, N, F, logdet);
   if (basis) P.basis_rows_get(nb, N, Np, rows, basis);
 }
