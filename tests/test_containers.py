@@ -84,3 +84,23 @@ def test_distribution_fields_are_assignable_like_the_references_dataclass():
     assert np.array_equal(d.mean.values, np.ones(4)) and d != e
     d.covariance = np.full(4, 3.0)
     assert np.array_equal(d._dist.variance(), np.full(4, 9.0))            # scale quirk re-derived on assignment
+
+
+def test_ragged_layout_and_field_launch_size_are_pure_host_logic():
+    """The layout `bayens_gp_fit_batch_ragged{,_f32}` takes (members' (N, R_b) blocks one behind the other, offsets in elements) and
+    the number of general-path fits a per-gridpoint field puts into one launch (workspace budget / padded matrices per fit)."""
+    import numpy as np
+    from bayesian_ensembling_amd import _lib
+    from bayesian_ensembling_amd.models import GPDTW1D
+    Xs = [np.arange(12.0).reshape(4, 3), np.arange(20.0).reshape(4, 5) + 100, np.arange(4.0).reshape(4, 1) - 7]
+    R, off, X = _lib.Context.ragged_layout(Xs)
+    assert R.tolist() == [3, 5, 1] and off.tolist() == [0, 12, 32] and X.shape == (36,)
+    for r, o, x in zip(R, off, Xs):
+        assert np.array_equal(X[int(o):int(o) + 4 * int(r)].reshape(4, int(r)), x)
+    with pytest.raises(ValueError):
+        _lib.Context.ragged_layout([np.zeros((4, 2)), np.zeros((5, 2))])
+    m = GPDTW1D(per_gridpoint=True)
+    for N, itemsize in ((1980, 8), (1980, 4), (300, 8)):
+        Np = -(-N // 64) * 64
+        per_launch = int(m.FIELD_WS_BYTES // (m.FIELD_WS_MATRICES * Np * Np * itemsize))
+        assert per_launch >= 1 and per_launch * m.FIELD_WS_MATRICES * Np * Np * itemsize <= m.FIELD_WS_BYTES
