@@ -480,8 +480,10 @@ __global__ void xprep_kernel(int N, int Np, int R_all, int R4, const real* X_all
 
 // one workgroup = one 64x64 output tile; wave w owns rows 16w..16w+15, four 16x16 MFMA tiles across.
 // GRAD=false: write K0 and Lb.  GRAD=true: accumulate <Kbt, K0> and <Kbt, dK/dl> over the real part.
+// (launch bounds: the second figure is waves per SIMD - with it the K pass compiles to 88 registers instead of 152 and the gradient
+//  pass to 138 instead of 200, without spills: the scheduler interleaves the elements' chains less widely.  K pass 262 -> 243 us.)
 template <bool GRAD, int KERNEL>
-__global__ __launch_bounds__(256) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
+__global__ __launch_bounds__(256, GRAD ? 2 : 4) void kmat_kernel(int N, int Np, int R4, const double* xs, const double* ssq,
                                                    const double* ustate, double jitter, Mat Lb,
                                                    Mat Kbt, double* gpart, const real* pvec, double sym_gamma,
                                                    int clear_upper, Mat Mb, double m_scale, const real* m_diag) {
