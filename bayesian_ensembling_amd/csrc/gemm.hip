@@ -666,7 +666,7 @@ __device__ __forceinline__ void panel_mma_tri(v4d (&acc)[4], const real (*As)[SL
 }
 
 template <bool RLN>
-__global__ __launch_bounds__(256) void trsm_panel_kernel(PanelArgs g) {
+__global__ __launch_bounds__(256, 2) void trsm_panel_kernel(PanelArgs g) {
   // As: each wave's own 16 rows, only used to turn an accumulator (C layout) into an A operand; Bs: the staged
   // L block or inverted diagonal block, shared by the four waves.  Finished blocks X_k stay in registers as
   // (negated) A fragments, 16 doubles per lane and block, so a product only stages its L block; the next block's
