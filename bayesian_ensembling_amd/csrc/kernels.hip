@@ -513,15 +513,13 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void kmat_kernel(int N, int Np, 
   const bool mirror = GRAD && !sym && blockIdx.x < blockIdx.y;
   const int njt = (GRAD && blockIdx.x > blockIdx.y) ? 0 : 4;
   __shared__ real tmir[GRAD ? 64 : 1][GRAD ? 65 : 1];
+  // (the mirror tile is REQUESTED here and placed in LDS further down, behind the requests for everything else the workgroup
+  //  reads: one memory round trip in front of the first element, not two)
+  real mv[GRAD ? 16 : 1];
   if (mirror) {
-    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-    const real* src = Kbt.p + b * Kbt.stride + (long)j0 * Kbt.ld + blockIdx.y * 64 + c;
-    real v[16];
+    const real* src = Kbt.p + b * Kbt.stride + (long)j0 * Kbt.ld + blockIdx.y * 64 + (threadIdx.x & 63);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = src[(long)(r0 + 4 * q) * Kbt.ld];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tmir[r0 + 4 * q][c] = v[q];
-    __syncthreads();
+    for (int q = 0; q < 16; ++q) mv[q] = src[(long)((threadIdx.x >> 6) + 4 * q) * Kbt.ld];
   }
   // the weights of this thread's 16 elements are requested up front (one memory round trip; inside the guarded accumulation below
   // every load would be issued, and waited for, on its own); the padded rows / columns are valid memory and are masked by a select
@@ -574,6 +572,11 @@ __global__ __launch_bounds__(256, GRAD ? 2 : 4) void kmat_kernel(int N, int Np, 
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) accs[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb[jt], accs[jt], 0, 0, 0);
     }
+  }
+  if (mirror) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tmir[(threadIdx.x >> 6) + 4 * q][threadIdx.x & 63] = mv[q];
+    __syncthreads();
   }
   // (EDGE, and for the gradient pass SYM / MIRROR, are compile-time flags of the body: a uniform run-time test per element is a
   //  branch per element, and the elements of a thread then run one behind the other)
