@@ -18,6 +18,7 @@ cd $R
 if [[ $PART == *A* ]]; then
 timeout -k 10 500 python3 bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/${TAG}_bench_final.err || exit 1       # the plain command the driver runs
 BAYENS_PRINT_STAGES=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_stage_profile.txt || exit 1
+BAYENS_PRINT_SHAPES=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /dev/null 2> $OUT/${TAG}_gemm_shapes_final.txt || exit 1
 timeout -k 10 300 python3 bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err || exit 1
 timeout -k 10 300 python3 tools/small_phases.py > $OUT/${TAG}_small_phases.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
@@ -62,6 +63,8 @@ rm -rf $OUT/${TAG}_ktp
 fi
 if [[ $PART == *B* ]]; then
 timeout -k 10 300 python3 tools/paper_script.py > $OUT/${TAG}_paper_script.json 2> $OUT/${TAG}_paper_script.err || exit 30
+(timeout -k 10 300 python3 tools/monthly_field.py float64; timeout -k 10 300 python3 tools/monthly_field.py float32) > $OUT/${TAG}_monthly_field.json 2> /dev/null || exit 31
+timeout -k 10 300 python3 tools/determinism_check.py > $OUT/${TAG}_determinism.txt 2>&1 || exit 32
 # the fused mid-size kernel (csrc/medium.hip) at the reference's workload: timing table against the general path, phase stamps,
 # kernel trace and matrix-pipe utilisation of one collection fit
 (timeout -k 10 300 python3 tools/medium_check.py | grep timing; BAYENS_NO_MEDIUM=1 timeout -k 10 300 python3 tools/medium_check.py | grep timing; timeout -k 10 100 python3 tools/medium_phases.py 165 20 | tail -15) > $OUT/${TAG}_medium_kernel.txt 2>&1 || exit 14
