@@ -152,15 +152,24 @@ __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
   const real* w = W.p + b * W.stride;
   real* wt = Wt.p + b * Wt.stride;
   if (bj < bi) {   // strictly below the diagonal of the output: zeros
+#pragma unroll
     for (int q = 0; q < 16; ++q) wt[(long)(bi * 64 + r0 + 4 * q) * Wt.ld + bj * 64 + c] = 0.0;
     return;
   }
+  // (all sixteen loads of a thread requested before the first is placed: one memory round trip per tile)
+  real v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int gi = bj * 64 + r0 + 4 * q, gj = bi * 64 + c;   // input element (gi, gj), lower part only
+    v[q] = w[(long)gi * W.ld + gj];
+  }
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
-    const int gi = bj * 64 + r, gj = bi * 64 + c;   // input element (gi, gj), lower part only
-    tile[r][c] = gj <= gi ? w[(long)gi * W.ld + gj] : 0.0;
+    tile[r][c] = (bi * 64 + c <= bj * 64 + r) ? (double)v[q] : 0.0;
   }
   __syncthreads();
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
     wt[(long)(bi * 64 + r) * Wt.ld + bj * 64 + c] = tile[c][r];
@@ -222,19 +231,27 @@ __global__ void form_phi_kernel(int n, Mat GS, const real* u, const real* mvec, 
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const real* g = GS.p + b * GS.stride;
   real* p = Phi.p + b * Phi.stride;
+  if (blockIdx.x > blockIdx.y) {                 // a tile above the diagonal: zeros, nothing read
+#pragma unroll
+    for (int q = 0; q < 16; ++q) p[(long)(i0 + 4 * q) * Phi.ld + j] = 0.0;
+    return;
+  }
+  // (every load of the thread requested before the first value is formed - a load under `if (j <= i)` is a branch whose value is
+  //  awaited at its join, sixteen round trips one behind the other; the elements above the diagonal of a diagonal tile are valid memory)
   const double mj = mvec[(long)b * n + j];
-  double v[16];
+  real gv[16], uv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    gv[q] = g[(long)(i0 + 4 * q) * GS.ld + j];
+    uv[q] = u[(long)b * n + i0 + 4 * q];
+  }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    v[q] = 0.0;
-    if (j <= i) {
-      v[q] = u_scale * (double)u[(long)b * n + i] * mj + (scale * (double)g[(long)i * GS.ld + j] + (j == i ? diag_add : 0.0));
-      if (j == i) v[q] *= 0.5;
-    }
+    double v = u_scale * (double)uv[q] * mj + (scale * (double)gv[q] + (j == i ? diag_add : 0.0));
+    if (j == i) v *= 0.5;
+    p[(long)i * Phi.ld + j] = j <= i ? v : 0.0;
   }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) p[(long)(i0 + 4 * q) * Phi.ld + j] = v[q];
 }
 
 // natural-gradient precision update (prims.h lam_update): one workgroup per lower 64x64 block (bi >= bj) updates
@@ -328,20 +345,41 @@ __global__ void diag_init_kernel(int n, const real* nu, double add, Mat dst) {
 }
 
 __global__ void extract_kernel(int N, Mat src, real* dst, int mode) {
+  __shared__ real tile[64][65];
   const int b = blockIdx.z;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int i0 = blockIdx.y * 64 + r0;
   const real* s = src.p + b * src.stride;
   real* d = dst + (long)b * N * N;
-  if (j >= N) return;
   real v[16];
+  // mode 1 (the symmetric image of a lower triangle), output tile on or above the diagonal: its values are the TRANSPOSE of the
+  // source tile (bx, by), which is read along its rows and turned in LDS (read in place - lane j from row j - every lane would
+  // touch a cache line of its own).  src is a padded matrix: whole tiles are valid memory.
+  const bool turn = mode == 1 && blockIdx.x >= blockIdx.y;
+  if (turn) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = s[(long)(blockIdx.x * 64 + r0 + 4 * q) * src.ld + blockIdx.y * 64 + c];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[r0 + 4 * q][c] = v[q];
+    __syncthreads();
+    if (j >= N) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 4 * q, i = i0 + 4 * q;
+      // diagonal tile: the element on or below the diagonal is tile[r][c] itself, the one above it the mirror tile[c][r]
+      if (i < N) d[(long)i * N + j] = (blockIdx.x == blockIdx.y && j <= i) ? tile[r][c] : tile[c][r];
+    }
+    return;
+  }
+  if (j >= N) return;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
     v[q] = 0;
     if (i < N) {
       if (mode == 0) v[q] = s[(long)i * src.ld + j];
-      else if (mode == 1) v[q] = j <= i ? s[(long)i * src.ld + j] : s[(long)j * src.ld + i];
+      else if (mode == 1) v[q] = s[(long)i * src.ld + j];            // (below the diagonal tiles: j <= i everywhere)
       else v[q] = j <= i ? s[(long)i * src.ld + j] : (real)0;
     }
   }
