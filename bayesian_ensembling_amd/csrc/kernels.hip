@@ -212,15 +212,15 @@ __global__ void scale_rows_kernel(int n, Mat src, const real* nu, Mat dst) {
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const real* s = src.p + b * src.stride;
   real* d = dst.p + b * dst.stride;
-  real v[16], w[16];
+  real v[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = i0 + 4 * q;
-    v[q] = s[(long)i * src.ld + j];
-    w[q] = nu[(long)b * n + i];
-  }
+  for (int q = 0; q < 16; ++q) v[q] = s[(long)(i0 + 4 * q) * src.ld + j];
+  // the sixteen row factors of this wave's rows: lane q < 16 forms 1 / sqrt(nu) of row i0 + 4 q once, the others read it from
+  // there (every lane forming all sixteen was 16 square roots and divisions per thread)
+  const int lane = threadIdx.x & 63;
+  const double fac = 1.0 / sqrt((double)nu[(long)b * n + i0 + 4 * (lane & 15)]);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q] * (1.0 / sqrt((double)w[q]));
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q] * __shfl(fac, q, 64);
 }
 
 // Phi_ij = u_i m_j + GS_ij below the diagonal, half of it on the diagonal, 0 above (prims.h form_phi)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void lam_update_kernel(int n, Mat G, double ga
   for (int q = 0; q < 16; ++q) {
     const int i = bi * 64 + r0 + 4 * q;
     gv[q] = g[(long)i * G.ld + j];
-    lv[q] = (j <= i && (parts & 1)) ? lam[(long)i * Lam.ld + j] : (real)0;
+    lv[q] = (parts & 1) ? lam[(long)i * Lam.ld + j] : (real)0;       // (the whole tile: valid memory, masked below by j <= i)
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -309,26 +309,32 @@ __global__ __launch_bounds__(256) void at_from_linv_kernel(int n, Mat L, Mat Lin
   const real* l = L.p + b * L.stride;
   const real* li = Linv.p + b * Linv.stride;
   real* at = At.p + b * At.stride;
+  // (whole tiles are requested without conditions - both matrices are padded, every element is valid memory - and masked
+  //  afterwards: a load under a condition is a branch, and the sixteen of a thread then wait for one another)
+  real tv[16], lv[16];
   if (bj >= bi) {                    // upper (or diagonal) block: Linv tile (bj, bi) exists
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tv[q] = li[(long)(bj * 64 + r0 + 4 * q) * Linv.ld + bi * 64 + c];
+  }
+  if (bj <= bi) {                    // lower (or diagonal) block of L
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lv[q] = l[(long)(bi * 64 + r0 + 4 * q) * L.ld + bj * 64 + c];
+  }
+  if (bj >= bi) {
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int r = r0 + 4 * q;
-      const int gi = bj * 64 + r, gj = bi * 64 + c;
-      tile[r][c] = gj <= gi ? li[(long)gi * Linv.ld + gj] : 0.0;
+      tile[r][c] = (bi * 64 + c <= bj * 64 + r) ? (double)tv[q] : 0.0;
     }
     __syncthreads();
-  }
-  double lv[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = bi * 64 + r0 + 4 * q, j = bj * 64 + c;
-    lv[q] = j <= i ? (double)l[(long)i * L.ld + j] : 0.0;
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int r = r0 + 4 * q;
     const int i = bi * 64 + r, j = bj * 64 + c;
+    const double lval = (bj <= bi && j <= i) ? (double)lv[q] : 0.0;
     const double lit = bj >= bi ? tile[c][r] : 0.0;        // (Linv^T)_ij = Linv_ji
-    at[(long)i * At.ld + j] = lv[q] - jitter * lit;
+    at[(long)i * At.ld + j] = lval - jitter * lit;
   }
 }
 
