@@ -379,20 +379,13 @@ __global__ void extract_kernel(int N, Mat src, real* dst, int mode) {
     return;
   }
   if (j >= N) return;
+  // (unconditional loads: the rows up to the padded order are valid memory; the mask is on the store)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = s[(long)(i0 + 4 * q) * src.ld + j];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    v[q] = 0;
-    if (i < N) {
-      if (mode == 0) v[q] = s[(long)i * src.ld + j];
-      else if (mode == 1) v[q] = s[(long)i * src.ld + j];            // (below the diagonal tiles: j <= i everywhere)
-      else v[q] = j <= i ? s[(long)i * src.ld + j] : (real)0;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = i0 + 4 * q;
-    if (i < N) d[(long)i * N + j] = v[q];
+    if (i < N) d[(long)i * N + j] = (mode == 2 && j > i) ? (real)0 : v[q];      // (mode 1 below the diagonal tiles: j <= i everywhere)
   }
 }
 
