@@ -138,10 +138,10 @@ __global__ void copy_kernel(int n, Mat src, Mat dst, int mode) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    v[q] = (mode == 1 && j > i) ? (real)0 : s[(long)i * src.ld + j];
+    v[q] = s[(long)i * src.ld + j];
   }
 #pragma unroll
-  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
+  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = (mode == 1 && j > i0 + 4 * q) ? (real)0 : v[q];
 }
 
 __global__ void transpose_lower_kernel(int n, Mat W, Mat Wt) {
@@ -395,10 +395,18 @@ __global__ void pad_in_kernel(int N, int Np, const double* src, Mat dst) {
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const double* s = src + (long)b * N * N;
   real* d = dst.p + b * dst.stride;
+  // (loads from clamped addresses, all sixteen requested before the first store; the identity of the padding is a select)
+  const int jc = j < N ? j : N - 1;
+  double v[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    double v = (i < N && j < N) ? s[(long)i * N + j] : (i == j ? 1.0 : 0.0);
-    d[(long)i * dst.ld + j] = v;
+    v[q] = s[(long)(i < N ? i : N - 1) * N + jc];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    d[(long)i * dst.ld + j] = (i < N && j < N) ? v[q] : (i == j ? 1.0 : 0.0);
   }
 }
 
@@ -1200,14 +1208,18 @@ __global__ void pad_lower_kernel(int N, int Np, const double* src, Mat dst) {
   const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6);
   const double* s = src + (long)b * N * N;
   real* d = dst.p + b * dst.stride;
+  const int jc = j < N ? j : N - 1;
   double v[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + 4 * q;
-    v[q] = (i < N && j < N) ? (j <= i ? s[(long)i * N + j] : 0.0) : (i == j ? 1.0 : 0.0);
+    v[q] = s[(long)(i < N ? i : N - 1) * N + jc];          // (clamped address: no load under a condition)
   }
 #pragma unroll
-  for (int q = 0; q < 16; ++q) d[(long)(i0 + 4 * q) * dst.ld + j] = v[q];
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + 4 * q;
+    d[(long)i * dst.ld + j] = (i < N && j < N) ? (j <= i ? v[q] : 0.0) : (i == j ? 1.0 : 0.0);
+  }
 }
 // inverse of every 64x64 diagonal block of the padded factor: one workgroup per (block, member).  The triangular block
 // is inverted DIRECTLY by forward substitution (lane c solves T x = e_c in LDS; row i of T is a broadcast read), which is
