@@ -1569,16 +1569,27 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(int mode, Mat A, Mat B
   real* pa = A.p + b * A.stride;
   const real* pb = B.p ? B.p + b * B.stride : nullptr;
   double s0 = 0.0, s1 = 0.0;
+  // (every load of the thread first - a load behind the store of the element before it waits for that store - then the sums, in
+  //  the order they always had, then the stores)
+  real xv[16], bv[16];
+#pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const int i = i0 + 4 * q;
-    real* x = pa + (long)i * A.ld + j;
-    if (mode == 0) { s0 += (*x) * (*x); }
+    xv[q] = pa[(long)(i0 + 4 * q) * A.ld + j];
+    bv[q] = pb ? pb[(long)(i0 + 4 * q) * B.ld + j] : (real)0;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (mode == 0) { s0 += xv[q] * xv[q]; }
     else if (mode == 1) {
-      const double nv = a * (*x) + bcoef * pb[(long)i * B.ld + j];
-      const double d = nv - *x;
+      const double nv = a * xv[q] + bcoef * bv[q];
+      const double d = nv - xv[q];
       s0 += d * d; s1 += nv * nv;
-      *x = nv;
-    } else { s0 += (*x) * pb[(long)i * B.ld + j]; }
+      xv[q] = nv;
+    } else { s0 += xv[q] * bv[q]; }
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pa[(long)(i0 + 4 * q) * A.ld + j] = xv[q];
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
