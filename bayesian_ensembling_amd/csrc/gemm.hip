@@ -257,27 +257,28 @@ __device__ __forceinline__ void lds_dma16(const double* src, const double* dst_w
 // overwrites have returned (they were issued 48 MFMAs earlier; the wait is free, the guarantee is not optional)
 __device__ __forceinline__ void dl_wait() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
+// one of the four wave instructions of a tile's load (p = 0 .. 3)
+template <bool KIMG>
+__device__ __forceinline__ void dl_issue_part(const double* base, int ld, int row0, int nrows, int k0, int lane, int wave,
+                                              double* tile, int p) {
+  if (!KIMG) {
+    const int rb8 = 4 * p + wave;                         // blocks of this wave: wave, 4 + wave, 8 + wave, 12 + wave
+    int rr = row0 + rb8 * 8 + (lane & 7);
+    rr = rr < nrows ? rr : nrows - 1;
+    const int c8 = (lane >> 3) ^ (rb8 & 1);
+    lds_dma16(base + (long)rr * ld + k0 + 2 * c8, tile + rb8 * 128);
+  } else {
+    const int k = 4 * p + wave;
+    int cc = row0 + 2 * (lane ^ (8 * (k & 1)));
+    cc = cc <= nrows - 2 ? cc : nrows - 2;
+    lds_dma16(base + (long)(k0 + k) * ld + cc, tile + k * 128);
+  }
+}
 template <bool KIMG>
 __device__ __forceinline__ void dl_issue(const double* base, int ld, int row0, int nrows, int k0, int lane, int wave,
                                          double* tile) {
-  if (!KIMG) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int rb8 = 4 * p + wave;                         // blocks of this wave: wave, 4 + wave, 8 + wave, 12 + wave
-      int rr = row0 + rb8 * 8 + (lane & 7);
-      rr = rr < nrows ? rr : nrows - 1;
-      const int c8 = (lane >> 3) ^ (rb8 & 1);
-      lds_dma16(base + (long)rr * ld + k0 + 2 * c8, tile + rb8 * 128);
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int k = 4 * p + wave;
-      int cc = row0 + 2 * (lane ^ (8 * (k & 1)));
-      cc = cc <= nrows - 2 ? cc : nrows - 2;
-      lds_dma16(base + (long)(k0 + k) * ld + cc, tile + k * 128);
-    }
-  }
+  for (int p = 0; p < 4; ++p) dl_issue_part<KIMG>(base, ld, row0, nrows, k0, lane, wave, tile, p);
 }
 
 template <bool TA, bool TB>
@@ -393,14 +394,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
       dl_wait();                       // tile s + 1 has landed
       __syncthreads();                 // ... everywhere, and every wave has read the last of tile s
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < nk) {
-        dl_issue<TA>(A, g.lda, row0, g.m, kbeg + (s + 2) * BK, lane, wave, As[buf]);
-        dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 2) * BK, lane, wave, Bs[buf]);
-      }
+      // the next tile's first operand reads, then the step's last sixteen MFMAs with the eight load instructions of tile s + 2
+      // between their rows (issued in one block in front of them, the loads - ~45 instructions of address arithmetic - were a
+      // stretch with no MFMA of this wave in the pipe: 55.8 -> 55.2 ms per 32 x 2000 step, every shape 1-2 % faster)
       rd(buf ^ 1, 0, a0, b0);          // (after the last step: whatever the other buffer holds - never used)
       rd(buf ^ 1, 1, a1, b1);
       __builtin_amdgcn_sched_barrier(0);
-      mm(a3, b3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = BAYENS_MFMA16(a3[i], b3[j], acc[i][j]);
+        if (s + 2 < nk) {
+          dl_issue_part<TA>(A, g.lda, row0, g.m, kbeg + (s + 2) * BK, lane, wave, As[buf], i);
+          dl_issue_part<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 2) * BK, lane, wave, Bs[buf], i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   } else {
     for (int s = 0; s < nk; ++s) {     // a wave with no output block still moves its share of the tiles
