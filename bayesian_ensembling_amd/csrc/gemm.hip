@@ -394,16 +394,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
       dl_wait();                       // tile s + 1 has landed
       __syncthreads();                 // ... everywhere, and every wave has read the last of tile s
       __builtin_amdgcn_sched_barrier(0);
-      // the next tile's first operand reads, then the step's last sixteen MFMAs with the eight load instructions of tile s + 2
-      // between their rows (issued in one block in front of them, the loads - ~45 instructions of address arithmetic - were a
-      // stretch with no MFMA of this wave in the pipe: 55.8 -> 55.2 ms per 32 x 2000 step, every shape 1-2 % faster)
-      rd(buf ^ 1, 0, a0, b0);          // (after the last step: whatever the other buffer holds - never used)
-      rd(buf ^ 1, 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
+      // The step's last sixteen MFMAs (operands in registers since before the barrier) start at once; the next tile's first
+      // operand reads go behind their first two rows and the eight load instructions of tile s + 2 behind each row.  (Issued in
+      // one block in front of them, the loads - ~45 instructions of address arithmetic - and the reads were a stretch with no MFMA
+      // of this wave in the pipe: 55.8 -> 55.2 ms per 32 x 2000 step with the loads between the rows, 55.0 -> 54.8 with the reads there
+      // too; NT 2048 x 1024 x 1024 66.7 -> 69.1 TFLOP/s over the two.)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = BAYENS_MFMA16(a3[i], b3[j], acc[i][j]);
+        if (i == 0) rd(buf ^ 1, 0, a0, b0);        // (after the last step: whatever the other buffer holds - never used)
+        if (i == 1) rd(buf ^ 1, 1, a1, b1);
         if (s + 2 < nk) {
           dl_issue_part<TA>(A, g.lda, row0, g.m, kbeg + (s + 2) * BK, lane, wave, As[buf], i);
           dl_issue_part<!TB>(B, g.ldb, col0, g.n, kbeg + (s + 2) * BK, lane, wave, Bs[buf], i);
