@@ -368,17 +368,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         dst[j][r] = C[(long)(row0 + wm * 64 + i * 16 + acc_row(lk, r)) * g.ldc + col0 + wn * 64 + j * 16 + lr];
   };
   const bool accumulate = g.beta != 0.0;
+  // both buffers are free at the start: the first TWO tiles are requested together (the second used to be requested when the
+  // first had landed, i.e. one memory round trip later - and the first step of a short product then ended waiting for it); the
+  // first wait lets the second tile's eight loads stay in flight (loads return in the order they were issued)
   if (nk > 0) {
     dl_issue<TA>(A, g.lda, row0, g.m, kbeg, lane, wave, As[0]);
     dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg, lane, wave, Bs[0]);
   }
-  dl_wait();
-  __syncthreads();
-  if (accumulate && active) load_strip(0, cv[0]);
   if (nk > 1) {
     dl_issue<TA>(A, g.lda, row0, g.m, kbeg + BK, lane, wave, As[1]);
     dl_issue<!TB>(B, g.ldb, col0, g.n, kbeg + BK, lane, wave, Bs[1]);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  } else {
+    dl_wait();
   }
+  __syncthreads();
+  if (accumulate && active) load_strip(0, cv[0]);
   if (active) {
     double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
     rd(0, 0, a0, b0);
