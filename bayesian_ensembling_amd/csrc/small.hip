@@ -594,7 +594,14 @@ struct Layout {
 };
 
 template <int NT>
-__global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g) {   // two waves per SIMD: 256 registers each
+__global__ __launch_bounds__(NTH, 2) void small_fit_kernel(SmallArgs g_args) {   // two waves per SIMD: 256 registers each
+  // The arguments are READ WHERE THEY ARE USED, from the kernel-argument block (scalar loads from constant memory), not held in
+  // ~50 scalar registers from entry to exit: what does not fit is then reloaded from there instead of spilled into vector lanes
+  // (NT = 6: 467 -> 388 scalar spills, 2686 -> 1851 v_readlane in the listing, 172 -> 140 B of private segment; the run time of
+  // config 5 does not move - 40.6 ms either way: the spill traffic was not what it waits for).
+  (void)g_args;
+  typedef const __attribute__((address_space(4))) SmallArgs* KArgs;
+  const __attribute__((address_space(4))) SmallArgs& g = *(KArgs)__builtin_amdgcn_kernarg_segment_ptr();
   typedef Layout<NT> Y;
   constexpr int NTT = Y::NTT, NP = Y::NP, TPW = Y::TPW;
   double* lds = lds_base();
