@@ -168,30 +168,39 @@ __device__ __forceinline__ v4r acc_run(v4r acc, int k0, int k1, LoadA la, LoadB 
   v4r acc2 = {0, 0, 0, 0};
   int k = k0;
   if (k + 1 < k1) {
-    // software pipeline (round 4): the operands of the NEXT pair of steps are requested before the eight MFMAs of the current
-    // pair are issued, so a trip no longer starts by waiting out an LDS round trip
-    real a[8], b[8];
+    // Software pipeline (round 4): the operands of the NEXT pair of steps are requested before the eight MFMAs of the current pair
+    // are issued.  Round 5: TWO operand sets that swap roles, two pairs of steps per trip - with one set and a copy ("a = next a")
+    // the trip opened with seven to ten v_mov_b64 in a row in front of its first MFMA (hipcc -S), ~100 cycles per MFMA where the
+    // same MFMAs from registers take 70 (tools/diag16_bench.py).  Same products, same order, same two accumulator chains.
+    real pa[8], pb[8], qa[8], qb[8];
+    auto load = [&](int kk, real (&a)[8], real (&b)[8]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { a[q] = la(k, q); b[q] = lb(k, q); a[4 + q] = la(k + 1, q); b[4 + q] = lb(k + 1, q); }
-#pragma unroll 1
-    for (; k + 3 < k1; k += 2) {
-      real na[8], nb[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { na[q] = la(k + 2, q); nb[q] = lb(k + 2, q); na[4 + q] = la(k + 3, q); nb[4 + q] = lb(k + 3, q); }
+      for (int q = 0; q < 4; ++q) { a[q] = la(kk, q); b[q] = lb(kk, q); a[4 + q] = la(kk + 1, q); b[4 + q] = lb(kk + 1, q); }
+    };
+    auto mma8 = [&](const real (&a)[8], const real (&b)[8]) {
 #pragma unroll
       for (int q = 0; q < 8; q += 2) {
         acc = MFMAR(a[q], b[q], acc);
         acc2 = MFMAR(a[q + 1], b[q + 1], acc2);
       }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { a[q] = na[q]; b[q] = nb[q]; }
+    };
+    load(k, pa, pb);
+    k += 2;                                   // (invariant: the pair (k - 2, k - 1) is in pa / pb and not yet multiplied)
+#pragma unroll 1
+    for (; k + 3 < k1; k += 4) {
+      load(k, qa, qb);
+      mma8(pa, pb);
+      load(k + 2, pa, pb);
+      mma8(qa, qb);
     }
-#pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-      acc = MFMAR(a[q], b[q], acc);
-      acc2 = MFMAR(a[q + 1], b[q + 1], acc2);
+    if (k + 1 < k1) {
+      load(k, qa, qb);
+      mma8(pa, pb);
+      mma8(qa, qb);
+      k += 2;
+    } else {
+      mma8(pa, pb);
     }
-    k += 2;
   }
   if (k < k1) {
     real a[4], b[4];
